@@ -1,0 +1,356 @@
+"""Tensor-level wrappers over the C ABI (``include/coin_hip.h``).
+
+Each function checks device / dtype / contiguity, passes raw device pointers and the current
+HIP stream to ``libcoin_hip.so`` and raises :class:`coin_amd._lib.CoinHipError` on failure.
+Nothing here computes on the CPU and nothing falls back to torch ops.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, COIN_BF16, COIN_F32, COIN_NCHW, COIN_NHWC, CoinHipError, check
+
+__all__ = [
+    "roi_align_fwd", "roi_align_bwd", "gemm_nt", "transpose2d", "bias_act_bwd", "cosine_logits_fwd",
+    "cosine_logits_bwd", "mil_ce", "kl_div", "box_reg_l1", "l1_mean", "rpn_losses", "normalize_pad",
+    "SgdTable", "EmaTable",
+]
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return COIN_F32
+    if t.dtype == torch.bfloat16:
+        return COIN_BF16
+    raise CoinHipError(f"unsupported dtype {t.dtype} (float32 / bfloat16 only)")
+
+
+def _dev(*ts: Optional[torch.Tensor]) -> None:
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise CoinHipError("coin_amd kernels need device tensors (got a CPU tensor); there is no CPU path")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise CoinHipError(f"{name} must be contiguous float32")
+    return t
+
+
+# --------------------------------------------------------------------------- RoIAlign
+def _feat_dims(feat: torch.Tensor, layout: int) -> Tuple[int, int, int, int]:
+    if layout == COIN_NCHW:
+        n, c, h, w = feat.shape
+    else:
+        n, h, w, c = feat.shape
+    return n, c, h, w
+
+
+def roi_align_fwd(feat: torch.Tensor, rois: torch.Tensor, output_size: Tuple[int, int], spatial_scale: float,
+                  sampling_ratio: int = 0, aligned: bool = True, layout: int = COIN_NHWC) -> torch.Tensor:
+    """feat: contiguous [N,C,H,W] (NCHW) or [N,H,W,C] (NHWC); rois [R,5] f32 -> [R,C,ph,pw] / [R,ph,pw,C]."""
+    _dev(feat, rois)
+    if not feat.is_contiguous():
+        raise CoinHipError("feat must be contiguous in the declared layout")
+    rois = _f32c(rois, "rois")
+    n, c, h, w = _feat_dims(feat, layout)
+    ph, pw = output_size
+    r = rois.shape[0]
+    shape = (r, c, ph, pw) if layout == COIN_NCHW else (r, ph, pw, c)
+    out = torch.empty(shape, dtype=feat.dtype, device=feat.device)
+    check(_lib.lib().coin_roi_align_fwd(_p(feat), n, c, h, w, layout, _p(rois), r, ph, pw, float(spatial_scale),
+                                        int(sampling_ratio), int(aligned), _p(out), _dt(feat), _stream()),
+          "coin_roi_align_fwd")
+    return out
+
+
+def roi_align_bwd(grad_out: torch.Tensor, rois: torch.Tensor, feat_shape: Sequence[int], spatial_scale: float,
+                  sampling_ratio: int = 0, aligned: bool = True, layout: int = COIN_NHWC,
+                  grad_feat: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Returns (or accumulates into) the float32 gradient map of shape ``feat_shape``."""
+    _dev(grad_out, rois, grad_feat)
+    if not grad_out.is_contiguous():
+        raise CoinHipError("grad_out must be contiguous")
+    rois = _f32c(rois, "rois")
+    if grad_feat is None:
+        grad_feat = torch.zeros(tuple(feat_shape), dtype=torch.float32, device=grad_out.device)
+    else:
+        _f32c(grad_feat, "grad_feat")
+    if layout == COIN_NCHW:
+        n, c, h, w = feat_shape
+        ph, pw = grad_out.shape[2:]
+    else:
+        n, h, w, c = feat_shape
+        ph, pw = grad_out.shape[1:3]
+    r = rois.shape[0]
+    check(_lib.lib().coin_roi_align_bwd(_p(grad_out), n, c, h, w, layout, _p(rois), r, ph, pw, float(spatial_scale),
+                                        int(sampling_ratio), int(aligned), _p(grad_feat), _dt(grad_out), _stream()),
+          "coin_roi_align_bwd")
+    return grad_feat
+
+
+# --------------------------------------------------------------------------- box head
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+            act_alpha: float = 0.01, out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None
+            ) -> torch.Tensor:
+    """C[M,N] = act(A[M,K] @ B[N,K]^T + bias).  A, B row-major (last dim contiguous), same dtype."""
+    _dev(a, b, bias, out)
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1]:
+        raise CoinHipError(f"gemm_nt shape mismatch {tuple(a.shape)} x {tuple(b.shape)}^T")
+    if a.dtype != b.dtype or a.stride(1) != 1 or b.stride(1) != 1:
+        raise CoinHipError("gemm_nt operands must share dtype and be K-contiguous")
+    m, k = a.shape
+    n = b.shape[0]
+    out_dtype = out_dtype or a.dtype
+    if out is None:
+        out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+    elif out.stride(1) != 1 or out.shape != (m, n):
+        raise CoinHipError("gemm_nt: bad `out`")
+    if bias is not None:
+        _f32c(bias, "bias")
+    check(_lib.lib().coin_gemm_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), m, n, k, _p(bias),
+                                  act, float(act_alpha), _dt(a), _dt(out), _stream()), "coin_gemm_nt")
+    return out
+
+
+def transpose2d(x: torch.Tensor) -> torch.Tensor:
+    _dev(x)
+    if x.dim() != 2 or not x.is_contiguous():
+        raise CoinHipError("transpose2d needs a contiguous 2-D tensor")
+    m, n = x.shape
+    out = torch.empty((n, m), dtype=x.dtype, device=x.device)
+    check(_lib.lib().coin_transpose2d(_p(x), _p(out), m, n, _dt(x), _stream()), "coin_transpose2d")
+    return out
+
+
+def bias_act_bwd(dc: torch.Tensor, c: Optional[torch.Tensor], act: int, act_alpha: float = 0.01,
+                 dbias: Optional[torch.Tensor] = None, want_dz: bool = True):
+    """Returns (dZ, dbias) for C = act(Z + bias)."""
+    _dev(dc, c, dbias)
+    if dc.dim() != 2 or dc.stride(1) != 1:
+        raise CoinHipError("bias_act_bwd needs a row-major 2-D tensor")
+    m, n = dc.shape
+    if c is not None and (c.shape != dc.shape or c.stride() != dc.stride() or c.dtype != dc.dtype):
+        raise CoinHipError("bias_act_bwd: C must match dC")
+    dz = torch.empty_strided(dc.shape, dc.stride(), dtype=dc.dtype, device=dc.device) if want_dz else None
+    if dbias is None:
+        dbias = torch.zeros(n, dtype=torch.float32, device=dc.device)
+    check(_lib.lib().coin_bias_act_bwd(_p(dc), _p(c), _p(dz), dc.stride(0), m, n, _p(dbias), act, float(act_alpha),
+                                       _dt(dc), _stream()), "coin_bias_act_bwd")
+    return dz, dbias
+
+
+def cosine_logits_fwd(feats: torch.Tensor, text: torch.Tensor, inv_scale: float):
+    _dev(feats, text)
+    text = _f32c(text, "text")
+    if feats.dim() != 2 or feats.stride(1) != 1 or feats.shape[1] != text.shape[1]:
+        raise CoinHipError("cosine_logits: feats [R,D] row-major, text [Kc,D]")
+    r, d = feats.shape
+    kc = text.shape[0]
+    scores = torch.empty((r, kc), dtype=torch.float32, device=feats.device)
+    inv_norm = torch.empty((r,), dtype=torch.float32, device=feats.device)
+    check(_lib.lib().coin_cosine_logits_fwd(_p(feats), feats.stride(0), _p(text), r, d, kc, float(inv_scale), _p(scores),
+                                            _p(inv_norm), _dt(feats), _stream()), "coin_cosine_logits_fwd")
+    return scores, inv_norm
+
+
+def cosine_logits_bwd(d_scores: torch.Tensor, feats: torch.Tensor, text: torch.Tensor, scores: torch.Tensor,
+                      inv_norm: torch.Tensor, inv_scale: float, need_text_grad: bool = True):
+    _dev(d_scores, feats, text, scores, inv_norm)
+    d_scores = _f32c(d_scores.contiguous(), "d_scores")
+    r, d = feats.shape
+    kc = text.shape[0]
+    d_feats = torch.empty_strided(feats.shape, feats.stride(), dtype=feats.dtype, device=feats.device)
+    d_text = torch.zeros_like(text) if need_text_grad else None
+    check(_lib.lib().coin_cosine_logits_bwd(_p(d_scores), _p(feats), feats.stride(0), _p(text), _p(scores), _p(inv_norm),
+                                            r, d, kc, float(inv_scale), _p(d_feats), _p(d_text), _dt(feats), _stream()),
+          "coin_cosine_logits_bwd")
+    return d_feats, d_text
+
+
+# --------------------------------------------------------------------------- losses
+def _scalar(device) -> torch.Tensor:
+    return torch.empty((), dtype=torch.float32, device=device)
+
+
+def mil_ce(x: torch.Tensor, target: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
+           weights: Optional[torch.Tensor] = None, avg_positives: bool = False, reduction: str = "mean",
+           want_grad: bool = True):
+    _dev(x, target, labels, weights)
+    x = _f32c(x, "x")
+    r, c = x.shape
+    if target is not None:
+        target = _f32c(target, "target")
+    if labels is not None and (labels.dtype != torch.int64 or not labels.is_contiguous()):
+        raise CoinHipError("labels must be contiguous int64")
+    if weights is not None:
+        weights = _f32c(weights, "weights")
+    loss = _scalar(x.device)
+    grad = torch.empty_like(x) if want_grad else None
+    check(_lib.lib().coin_mil_ce_fwd_bwd(_p(x), x.stride(0) if r else c, _p(target), _p(labels), _p(weights), r, c,
+                                         int(avg_positives), int(reduction == "mean"), _p(loss), _p(grad), _stream()),
+          "coin_mil_ce_fwd_bwd")
+    return loss, grad
+
+
+def kl_div(x: torch.Tensor, q: torch.Tensor, mode: int, row_mask: Optional[torch.Tensor] = None, eps: float = 1e-7,
+           want_grad: bool = True):
+    """mode 0: x logits [R,C]; 1: x probabilities [R,C]; 2: x binary logits [R], q [R]."""
+    _dev(x, q, row_mask)
+    x = _f32c(x, "x")
+    q = _f32c(q, "q")
+    if mode == 2:
+        r, c, ldx, ldq = x.shape[0], 2, 1, 1
+    else:
+        r, c = x.shape
+        ldx, ldq = c, c
+    if row_mask is not None:
+        if row_mask.dtype == torch.bool:
+            row_mask = row_mask.to(torch.uint8)
+        if row_mask.dtype != torch.uint8 or not row_mask.is_contiguous():
+            raise CoinHipError("row_mask must be contiguous bool/uint8")
+    loss = _scalar(x.device)
+    grad = torch.empty_like(x) if want_grad else None
+    check(_lib.lib().coin_kl_div_fwd_bwd(_p(x), ldx, _p(q), ldq, _p(row_mask), r, c, mode, float(eps), _p(loss), _p(grad),
+                                         _stream()), "coin_kl_div_fwd_bwd")
+    return loss, grad
+
+
+def box_reg_l1(proposals: torch.Tensor, gt_boxes: torch.Tensor, pred_deltas: torch.Tensor, gt_classes: torch.Tensor,
+               num_fg_classes: int, weights: Sequence[float], normalizer: float, want_grad: bool = True):
+    _dev(proposals, gt_boxes, pred_deltas, gt_classes)
+    proposals, gt_boxes, pred_deltas = _f32c(proposals, "proposals"), _f32c(gt_boxes, "gt_boxes"), _f32c(pred_deltas, "pred_deltas")
+    if gt_classes.dtype != torch.int64 or not gt_classes.is_contiguous():
+        raise CoinHipError("gt_classes must be contiguous int64")
+    r = proposals.shape[0]
+    loss = _scalar(pred_deltas.device)
+    grad = torch.empty_like(pred_deltas) if want_grad else None
+    wx, wy, ww, wh = [float(v) for v in weights]
+    check(_lib.lib().coin_box_reg_l1_fwd_bwd(_p(proposals), _p(gt_boxes), _p(pred_deltas), _p(gt_classes), r,
+                                             int(num_fg_classes), wx, wy, ww, wh, float(normalizer), _p(loss), _p(grad),
+                                             _stream()), "coin_box_reg_l1_fwd_bwd")
+    return loss, grad
+
+
+def l1_mean(a: torch.Tensor, b: torch.Tensor, want_grad: bool = True):
+    _dev(a, b)
+    a, b = _f32c(a, "a"), _f32c(b, "b")
+    if a.shape != b.shape:
+        raise CoinHipError("l1_mean: shape mismatch")
+    loss = _scalar(a.device)
+    grad = torch.empty_like(a) if want_grad else None
+    check(_lib.lib().coin_l1_mean_fwd_bwd(_p(a), _p(b), a.numel(), _p(loss), _p(grad), _stream()), "coin_l1_mean_fwd_bwd")
+    return loss, grad
+
+
+def rpn_losses(logits: torch.Tensor, labels: torch.Tensor, deltas: torch.Tensor, anchors: torch.Tensor,
+               matched_gt: torch.Tensor, min_label: int = 0, want_grad: bool = True):
+    """logits [N,A] f32, labels [N,A] int8, deltas [N,A,4], anchors [A,4], matched_gt [N,A,4] -> sums."""
+    _dev(logits, labels, deltas, anchors, matched_gt)
+    logits, deltas, anchors, matched_gt = (_f32c(logits, "logits"), _f32c(deltas, "deltas"), _f32c(anchors, "anchors"),
+                                           _f32c(matched_gt, "matched_gt"))
+    if labels.dtype != torch.int8 or not labels.is_contiguous():
+        raise CoinHipError("labels must be contiguous int8")
+    a_total, a_img = logits.numel(), anchors.shape[0]
+    out = torch.empty(2, dtype=torch.float32, device=logits.device)
+    g_logits = torch.empty_like(logits) if want_grad else None
+    g_deltas = torch.empty_like(deltas) if want_grad else None
+    check(_lib.lib().coin_rpn_losses_fwd_bwd(_p(logits), _p(labels), _p(deltas), _p(anchors), _p(matched_gt), a_total,
+                                             a_img, int(min_label), ctypes.c_void_p(out.data_ptr()),
+                                             ctypes.c_void_p(out.data_ptr() + 4), _p(g_logits), _p(g_deltas), _stream()),
+          "coin_rpn_losses_fwd_bwd")
+    return out[0], out[1], g_logits, g_deltas
+
+
+# --------------------------------------------------------------------------- streams of bytes
+def normalize_pad(images: Sequence[torch.Tensor], mean: Sequence[float], std: Sequence[float],
+                  size_divisibility: int = 0, layout: int = COIN_NCHW, dtype: torch.dtype = torch.float32):
+    """uint8 [3,h,w] device images -> one zero-padded normalised batch (+ list of true sizes)."""
+    _dev(*images)
+    sizes = [(int(im.shape[1]), int(im.shape[2])) for im in images]
+    hp, wp = max(s[0] for s in sizes), max(s[1] for s in sizes)
+    if size_divisibility > 1:
+        d = size_divisibility
+        hp, wp = (hp + d - 1) // d * d, (wp + d - 1) // d * d
+    nb = len(images)
+    shape = (nb, 3, hp, wp) if layout == COIN_NCHW else (nb, hp, wp, 3)
+    out = torch.empty(shape, dtype=dtype, device=images[0].device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    for i, im in enumerate(images):
+        if im.dtype != torch.uint8 or not im.is_contiguous() or im.shape[0] != 3:
+            raise CoinHipError("images must be contiguous uint8 [3,h,w]")
+        check(_lib.lib().coin_normalize_pad(_p(im), sizes[i][0], sizes[i][1], m, s, _p(out), i, hp, wp, layout, _dt(out),
+                                            _stream()), "coin_normalize_pad")
+    return out, sizes
+
+
+class SgdTable:
+    """Device table of (param, grad, momentum, lr, wd) descriptors for the one-launch SGD step."""
+
+    def __init__(self, params: Sequence[torch.Tensor], lrs: Sequence[float], wds: Sequence[float],
+                 shadows: Optional[Sequence[Optional[torch.Tensor]]] = None):
+        _dev(*params)
+        self.params = list(params)
+        self.bufs = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
+        self.shadows = list(shadows) if shadows is not None else [None] * len(self.params)
+        self.lrs, self.wds = list(lrs), list(wds)
+        self.first = True
+        self.max_numel = max((p.numel() for p in self.params), default=0)
+        self._host = (_lib.SgdTensor * max(len(self.params), 1))()
+        self._dev = torch.empty(ctypes.sizeof(self._host), dtype=torch.uint8, device=self.params[0].device) if self.params else None
+        self._grads_key = None
+
+    def _upload(self, grads):
+        for i, (p, g, b, s) in enumerate(zip(self.params, grads, self.bufs, self.shadows)):
+            if not (p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32 and g.dtype == torch.float32):
+                raise CoinHipError("SGD needs contiguous float32 params and grads")
+            e = self._host[i]
+            e.param, e.grad, e.momentum_buf = p.data_ptr(), g.data_ptr(), b.data_ptr()
+            e.bf16_shadow = s.data_ptr() if s is not None else None
+            e.numel, e.lr, e.weight_decay = p.numel(), float(self.lrs[i]), float(self.wds[i])
+        host = torch.frombuffer(memoryview(self._host).cast("B"), dtype=torch.uint8)
+        self._dev.copy_(host, non_blocking=False)
+
+    def step(self, grads: Sequence[torch.Tensor], momentum: float, inv_loss_scale: float = 1.0,
+             lrs: Optional[Sequence[float]] = None):
+        key = (tuple(g.data_ptr() for g in grads), tuple(lrs) if lrs is not None else tuple(self.lrs))
+        if lrs is not None:
+            self.lrs = list(lrs)
+        if key != self._grads_key:
+            self._upload(grads)
+            self._grads_key = key
+        check(_lib.lib().coin_sgd_step(_p(self._dev), len(self.params), self.max_numel, float(momentum),
+                                       float(inv_loss_scale), int(self.first), _stream()), "coin_sgd_step")
+        self.first = False
+
+
+class EmaTable:
+    def __init__(self, teacher: Sequence[torch.Tensor], student: Sequence[torch.Tensor]):
+        _dev(*teacher, *student)
+        self.n = len(teacher)
+        self.max_numel = max((t.numel() for t in teacher), default=0)
+        host = (_lib.EmaTensor * max(self.n, 1))()
+        for i, (t, s) in enumerate(zip(teacher, student)):
+            if not (t.is_contiguous() and s.is_contiguous() and t.dtype == torch.float32 and s.dtype == torch.float32):
+                raise CoinHipError("EMA needs contiguous float32 tensors")
+            host[i].teacher, host[i].student, host[i].numel = t.data_ptr(), s.data_ptr(), t.numel()
+        self._keep = (list(teacher), list(student))
+        self._dev = torch.frombuffer(memoryview(host).cast("B"), dtype=torch.uint8).to(teacher[0].device) if self.n else None
+
+    def update(self, keep: float):
+        check(_lib.lib().coin_ema_update(_p(self._dev), self.n, self.max_numel, float(keep), _stream()), "coin_ema_update")

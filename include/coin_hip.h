@@ -1,0 +1,220 @@
+/*
+ * coin_hip.h - C ABI of libcoin_hip.so: the MI355X (gfx950) kernels behind COIN's
+ * adaptation-training hot path.
+ *
+ * The reference (Flashkong/COIN) has no native boundary of its own: its hot path sits
+ * behind Python registries and bottoms out in torchvision / cuDNN / cuBLAS.
+ * This header is the boundary a maintainer binds instead (ctypes stub: INTEGRATION.md).
+ * Each entry point names the reference call site it replaces (file:line under
+ * /root/reference).
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes; no C++ / torch types.
+ *   - every pointer is a DEVICE pointer owned by the caller and kept alive by the caller
+ *     until the stream has passed the call; the library allocates nothing and keeps no
+ *     global state (re-entrant, thread-safe per stream).
+ *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null stream).
+ *   - returns 0 on success, a NEGATIVE COIN_E* code for bad arguments, or a POSITIVE
+ *     hipError_t if the launch failed.  Never throws, never aborts.
+ *   - `dtype`: COIN_F32 = float, COIN_BF16 = bfloat16 (round-to-nearest-even on store);
+ *     accumulation is always fp32.
+ */
+#ifndef COIN_HIP_H
+#define COIN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COIN_ABI_VERSION 1
+
+enum { COIN_F32 = 0, COIN_BF16 = 1 };
+enum { COIN_NCHW = 0, COIN_NHWC = 1 };
+enum { COIN_ACT_NONE = 0, COIN_ACT_LEAKY_RELU = 1, COIN_ACT_RELU = 2 };
+
+enum {
+  COIN_OK = 0,
+  COIN_EINVAL = -1,   /* null pointer / negative size / unknown enum */
+  COIN_ESHAPE = -2,   /* shape not supported by this kernel (see the entry point) */
+  COIN_EALIGN = -3    /* pointer or leading dimension not aligned as required */
+};
+
+/* Library / ABI version and the offload arch the code objects were built for ("gfx950"). */
+int coin_abi_version(void);
+const char* coin_build_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * RoIAlign   (replaces coin/modeling/roi_heads/clip_roi_heads.py:172-176 `self.pooler(...)`
+ *             -> detectron2 ROIPooler -> torchvision.ops.roi_align(aligned, sampling_ratio))
+ *
+ * feat  : [N,C,H,W] (COIN_NCHW) or [N,H,W,C] (COIN_NHWC), dtype `dtype`
+ * rois  : [R,5] float32 rows (batch_index, x0, y0, x1, y1) in input-image pixels
+ * out   : [R,C,ph,pw] (COIN_NCHW) or [R,ph,pw,C] (COIN_NHWC), dtype `dtype`
+ * sampling_ratio <= 0 selects the adaptive grid ceil(roi_size / pooled_size).
+ * NHWC requires C % 8 == 0 (bf16) / C % 4 == 0 (f32) and 16-byte aligned feat/out.
+ * ---------------------------------------------------------------------------------------- */
+int coin_roi_align_fwd(const void* feat, int N, int C, int H, int W, int layout,
+                       const float* rois, int R, int ph, int pw, float spatial_scale,
+                       int sampling_ratio, int aligned, void* out, int dtype, void* stream);
+
+/* Adjoint of coin_roi_align_fwd (torchvision roi_align backward).
+ * grad_out : same shape/layout/dtype as `out` above.
+ * grad_feat: [N,C,H,W] / [N,H,W,C] FLOAT32, ACCUMULATED INTO (caller zeroes it; several calls
+ *            may add into the same map, e.g. the proposal pass and the C-box pass of
+ *            clip_roi_heads.py:201-219).  Float atomics: summation order is not fixed.
+ * workspace: none. */
+int coin_roi_align_bwd(const void* grad_out, int N, int C, int H, int W, int layout,
+                       const float* rois, int R, int ph, int pw, float spatial_scale,
+                       int sampling_ratio, int aligned, float* grad_feat, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Box-head GEMM   (replaces the nn.Linear calls of FastRCNNOutputLayers.forward,
+ *                  coin/modeling/roi_heads/fast_rcnn.py:331-337: `trans` MLP, `cls_score`,
+ *                  `bbox_pred`; and their autograd backward)
+ *
+ *   C[M,N] = act( A[M,K] . B[N,K]^T + bias[N] )          ("NT": both operands K-contiguous)
+ *
+ * A, B: dtype `dtype`, row-major with leading dimensions lda, ldb (elements).
+ * C   : dtype `out_dtype`, leading dimension ldc.  bias: float32 or NULL.
+ * act : COIN_ACT_*; leaky slope is `act_alpha` (0.01 for nn.LeakyReLU()).
+ * bf16 path: MFMA 16x16x32 bf16, fp32 accumulate; requires K % 64 == 0, lda/ldb % 8 == 0,
+ *            16-byte aligned A/B.  M, N arbitrary.
+ * f32 path : MFMA 16x16x4 f32 (exact fp32 FMA chain in k order); requires K % 16 == 0.
+ * ---------------------------------------------------------------------------------------- */
+int coin_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                 int M, int N, int K, const float* bias, int act, float act_alpha,
+                 int dtype, int out_dtype, void* stream);
+
+/* out[N,M] = in[M,N]^T (row-major, contiguous), same dtype; used to present the NN / TN
+ * products of the backward pass (dX = dY.W, dW = dY^T.X) to coin_gemm_nt. */
+int coin_transpose2d(const void* in, void* out, int M, int N, int dtype, void* stream);
+
+/* Backward of bias + activation for C = act(Z + bias):
+ *   dZ[M,N] = dC * act'(C)   (leaky/relu derivative recovered from the sign of C)
+ *   dbias[N] += sum_m dZ[m,n]  (float32, ACCUMULATED; may be NULL)
+ * dC, C, dZ share dtype `dtype` and leading dimension ld. */
+int coin_bias_act_bwd(const void* dC, const void* C, void* dZ, int ld, int M, int N,
+                      float* dbias, int act, float act_alpha, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Cosine-similarity classifier  (replaces FastRCNNOutputLayers.do_classify,
+ *                                fast_rcnn.py:343-346)
+ *   scores[r,k] = <f_r/|f_r|, t_k/|t_k|> * inv_scale          (inv_scale = 1/logit_scale = 100)
+ * feats [R,D] dtype `dtype`; text [Kc,D] float32; scores [R,Kc] float32;
+ * inv_norm_f [R] float32 (saved for backward; may be NULL in inference).  Kc <= 64.
+ * ---------------------------------------------------------------------------------------- */
+int coin_cosine_logits_fwd(const void* feats, int ldf, const float* text, int R, int D, int Kc,
+                           float inv_scale, float* scores, float* inv_norm_f, int dtype,
+                           void* stream);
+
+/* d_feats[R,D] (dtype `dtype`) and d_text[Kc,D] (float32, ACCUMULATED) given d_scores[R,Kc]. */
+int coin_cosine_logits_bwd(const float* d_scores, const void* feats, int ldf, const float* text,
+                           const float* scores, const float* inv_norm_f, int R, int D, int Kc,
+                           float inv_scale, void* d_feats, float* d_text, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused losses: each computes the scalar loss AND the gradient w.r.t. its differentiable
+ * input for a unit upstream gradient, in one launch.  `loss` is a single float32 that is
+ * OVERWRITTEN.  Rows are independent; per-row reductions use wavefront shuffles.
+ * ---------------------------------------------------------------------------------------- */
+
+/* MIL soft-target cross entropy (coin/utils/losses.py:13-34; call sites fast_rcnn.py:462-467,
+ * 580).  NO max-subtraction (reference quirk, losses.py:15-18):
+ *   p = exp(x) / sum(exp(x));  l_r = -log( sum_c t*p / (avg_positives ? sum_c t + 1e-6 : 1) ) * w_r
+ *   loss = mean_r l_r  (reduction_mean) or sum_r l_r;   R == 0 -> loss = 0.
+ * x [R,C] float32 (row stride ldx); exactly one of {target [R,C] float32, labels [R] int64
+ * (one-hot target)} is non-NULL; weights [R] float32 or NULL;  grad_x [R,C] float32 or NULL. */
+int coin_mil_ce_fwd_bwd(const float* x, int ldx, const float* target, const int64_t* labels,
+                        const float* weights, int R, int C, int avg_positives, int reduction_mean,
+                        float* loss, float* grad_x, void* stream);
+
+/* nn.KLDivLoss(reduction='mean')(log(p + eps), q)  -  ELEMENT mean over R*C, not batchmean
+ * (fast_rcnn.py:273,526,538,544; rpn.py:335):   loss = 1/(R*C) * sum q * (log q - log(p+eps)),
+ * terms with q == 0 contribute 0.
+ * mode 0: p = softmax(x) over C (x are logits);       grad_x = d loss / d x
+ * mode 1: p = x (already probabilities);              grad_x = d loss / d p
+ * mode 2: binary, C must be 2 on the q side: x [R] logits, p = [sigmoid(x), 1-sigmoid(x)],
+ *         q [R] teacher prob -> [q, 1-q]  (rpn.py:331-335); grad_x [R].
+ * row_mask [R] uint8 or NULL selects rows (masked rows are excluded from R in the mean). */
+int coin_kl_div_fwd_bwd(const float* x, int ldx, const float* q, int ldq, const uint8_t* row_mask,
+                        int R, int C, int mode, float eps, float* loss, float* grad_x,
+                        void* stream);
+
+/* Box regression L1 (FastRCNNOutputLayers.box_reg_loss, fast_rcnn.py:601-646, smooth_l1 with
+ * beta = 0; Box2BoxTransform.get_deltas with weights (wx,wy,ww,wh)):
+ *   fg rows: 0 <= gt_classes[r] < num_fg_classes
+ *   loss = sum_{fg r} sum_j | pred_deltas[r,j] - get_deltas(proposal_r, gt_r)_j | / normalizer
+ * proposals, gt_boxes [R,4] float32 xyxy; pred_deltas [R,4] float32 (class-agnostic);
+ * grad_deltas [R,4] float32 (zero on non-fg rows) or NULL. */
+int coin_box_reg_l1_fwd_bwd(const float* proposals, const float* gt_boxes, const float* pred_deltas,
+                            const int64_t* gt_classes, int R, int num_fg_classes,
+                            float wx, float wy, float ww, float wh, float normalizer,
+                            float* loss, float* grad_deltas, void* stream);
+
+/* mean |a - b| over n elements (nn.L1Loss(reduction='mean'), fast_rcnn.py:351 loss_text_align);
+ * grad_a = sign(a-b)/n or NULL. */
+int coin_l1_mean_fwd_bwd(const float* a, const float* b, int64_t n, float* loss, float* grad_a,
+                         void* stream);
+
+/* RPN objectness BCE-with-logits, sum over anchors with labels >= min_label, and the anchor
+ * L1 localisation loss over labels == 1 (DualTeacherRPN.losses, rpn.py:300-324):
+ *   loss_cls = sum_{label>=min_label} bce(logit, label) ; loss_loc = sum_{label==1} |d - get_deltas(anchor, gt)|_1
+ * logits [A_total] float32, labels [A_total] int8 (-1 ignore, 0 neg, 1 pos), deltas [A_total,4],
+ * anchors [A_per_image,4] (broadcast over images), matched_gt [A_total,4].
+ * Outputs are SUMS (caller divides by batch_size_per_image * num_images).
+ * grad_logits [A_total], grad_deltas [A_total,4] (unit upstream for each loss) or NULL. */
+int coin_rpn_losses_fwd_bwd(const float* logits, const int8_t* labels, const float* deltas,
+                            const float* anchors, const float* matched_gt, int64_t A_total,
+                            int64_t A_per_image, int min_label, float* loss_cls, float* loss_loc,
+                            float* grad_logits, float* grad_deltas, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Input normalisation  (replaces OpenVocabularyRCNN.preprocess_image, clip_rcnn.py:287-298:
+ *                       ToTensor + Normalize + ImageList.from_tensors zero padding)
+ * img   : [3,h,w] uint8 (CHW, as the dataset mapper emits)
+ * out   : image `n` of a batch [Nb,3,Hp,Wp] (COIN_NCHW) or [Nb,Hp,Wp,3] (COIN_NHWC), dtype
+ *         `dtype`; pixels outside h x w are written as 0.
+ * ---------------------------------------------------------------------------------------- */
+int coin_normalize_pad(const uint8_t* img, int h, int w, const float mean[3], const float std_[3],
+                       void* out, int n, int Hp, int Wp, int layout, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused SGD with momentum over a table of parameter tensors (replaces the per-tensor loop of
+ * torch.optim.SGD over ~170 param groups, coin/solver/build.py:96-103, engine/pre_train.py:201):
+ *   g = grad * inv_loss_scale + wd * p ; buf = momentum * buf + g (buf = g on first step) ; p -= lr * buf
+ * `table` is a DEVICE array of coin_sgd_tensor descriptors; one launch updates all of them.
+ * Optionally also refreshes a bf16 shadow copy of each parameter (shadow may be NULL).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct coin_sgd_tensor {
+  float* param;
+  const float* grad;
+  float* momentum_buf;
+  uint16_t* bf16_shadow; /* may be NULL */
+  int64_t numel;
+  float lr;
+  float weight_decay;
+} coin_sgd_tensor;
+
+int coin_sgd_step(const coin_sgd_tensor* table, int num_tensors, int64_t max_numel, float momentum,
+                  float inv_loss_scale, int first_step, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Teacher EMA (replaces EnsembleTSModel.update_params, coin/modeling/meta_arch/ts_ensemble.py:39-69)
+ *   teacher = student * (1 - keep) + teacher * keep      over a table of float32 tensors.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct coin_ema_tensor {
+  float* teacher;
+  const float* student;
+  int64_t numel;
+} coin_ema_tensor;
+
+int coin_ema_update(const coin_ema_tensor* table, int num_tensors, int64_t max_numel, float keep,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COIN_HIP_H */

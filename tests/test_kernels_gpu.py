@@ -1,0 +1,364 @@
+"""Parity of every C-ABI kernel against the CPU oracle (run with ``-m gpu`` on the MI355X box).
+
+fp32 paths: tolerance 1e-4 (north_star); integer/index outputs exact; bf16 paths: bf16 rounding
+tolerance stated per test.  Inputs are seeded; sizes are what the oracle finishes in seconds; the
+full BASELINE sizes are covered through size-independent properties (constant-map identity,
+linearity, adjointness <Ax,y> = <x,A^T y>).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    from coin_amd import kernels
+
+    return kernels
+
+
+def dev(t):
+    return t.to("cuda")
+
+
+def make_rois(n_img, r, h_img, w_img, g, extremes=True):
+    bw = torch.rand(r, generator=g) * (w_img * 0.6) + 8
+    bh = torch.rand(r, generator=g) * (h_img * 0.6) + 8
+    x0 = torch.rand(r, generator=g) * (w_img - 8)
+    y0 = torch.rand(r, generator=g) * (h_img - 8)
+    rois = torch.stack([torch.randint(0, n_img, (r,), generator=g).float(), x0, y0, x0 + bw, y0 + bh], dim=1)
+    if extremes and r >= 8:
+        rois[0, 1:] = torch.tensor([-40.0, -30.0, 20.0, 25.0])                 # partly outside (top-left)
+        rois[1, 1:] = torch.tensor([w_img - 10.0, h_img - 10.0, w_img + 60.0, h_img + 50.0])  # partly outside
+        rois[2, 1:] = torch.tensor([0.0, 0.0, float(w_img), float(h_img)])      # whole image
+        rois[3, 1:] = torch.tensor([50.0, 40.0, 50.5, 40.25])                   # sub-pixel box
+        rois[4, 1:] = torch.tensor([30.0, 30.0, 20.0, 20.0])                    # inverted (negative size)
+        rois[5, 1:] = torch.tensor([-500.0, -500.0, -400.0, -300.0])            # entirely outside
+        rois[6, 1:] = torch.tensor([-300.0, -200.0, w_img + 300.0, h_img + 200.0])  # much larger than the image
+    return rois
+
+
+# ------------------------------------------------------------------------------------------ RoIAlign
+@pytest.mark.parametrize("layout", ["nhwc", "nchw"])
+@pytest.mark.parametrize("sr,aligned", [(0, True), (2, True), (0, False)])
+def test_roi_align_fwd_bwd_f32_vs_loops(K, layout, sr, aligned):
+    from oracle import d2
+
+    g = torch.Generator().manual_seed(5)
+    n, c, h, w = 2, 8, 13, 17
+    feat = torch.randn(n, c, h, w, generator=g)
+    rois = make_rois(n, 12, h * 16, w * 16, g)
+    ref = d2.roi_align_forward_np(feat.numpy(), rois.numpy(), (7, 7), 1 / 16.0, sr, aligned)
+    lay = K.COIN_NHWC if layout == "nhwc" else K.COIN_NCHW
+    fd = dev(feat.permute(0, 2, 3, 1).contiguous() if layout == "nhwc" else feat)
+    out = K.roi_align_fwd(fd, dev(rois), (7, 7), 1 / 16.0, sr, aligned, lay)
+    out = out.permute(0, 3, 1, 2) if layout == "nhwc" else out
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
+    go = torch.randn(ref.shape, generator=g)
+    gref = d2.roi_align_backward_np(go.numpy(), rois.numpy(), (n, c, h, w), 1 / 16.0, sr, aligned)
+    gd = dev(go.permute(0, 2, 3, 1).contiguous() if layout == "nhwc" else go)
+    shape = (n, h, w, c) if layout == "nhwc" else (n, c, h, w)
+    gin = K.roi_align_bwd(gd, dev(rois), shape, 1 / 16.0, sr, aligned, lay)
+    gin = gin.permute(0, 3, 1, 2) if layout == "nhwc" else gin
+    np.testing.assert_allclose(gin.cpu().numpy(), gref, rtol=1e-4, atol=2e-5)
+
+
+def test_roi_align_empty_and_errors(K):
+    from coin_amd._lib import CoinHipError
+
+    feat = torch.zeros(1, 4, 4, 8, device="cuda")
+    out = K.roi_align_fwd(feat, torch.zeros(0, 5, device="cuda"), (14, 14), 1 / 16.0)
+    assert out.shape == (0, 14, 14, 8)
+    gin = K.roi_align_bwd(out, torch.zeros(0, 5, device="cuda"), (1, 4, 4, 8), 1 / 16.0)
+    assert float(gin.abs().sum()) == 0.0
+    with pytest.raises(CoinHipError):  # C not a multiple of the 16-byte vector
+        K.roi_align_fwd(torch.zeros(1, 4, 4, 6, device="cuda"), torch.zeros(1, 5, device="cuda"), (2, 2), 1.0)
+    with pytest.raises(CoinHipError):  # CPU tensor: no fallback
+        K.roi_align_fwd(torch.zeros(1, 4, 4, 8), torch.zeros(1, 5), (2, 2), 1.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_roi_align_res4_shape_vs_oracle(K, dtype):
+    """res4-shaped map (C=256 slice of channels, 50x83), 14x14, 1/16: vectorised oracle in fp64."""
+    from oracle import d2
+
+    g = torch.Generator().manual_seed(6)
+    n, c, h, w = 2, 256, 50, 83
+    feat = torch.randn(n, h, w, c, generator=g)
+    rois = make_rois(n, 96, 800, 1333, g)
+    fq = feat.to(dtype)
+    ref = d2.roi_align_torch(fq.double().permute(0, 3, 1, 2), rois.double(), (14, 14), 1 / 16.0, 0, True)
+    out = K.roi_align_fwd(dev(fq), dev(rois), (14, 14), 1 / 16.0).float().permute(0, 3, 1, 2).cpu()
+    tol = 1e-4 if dtype == torch.float32 else 2e-2  # bf16: one rounding of the output (2^-8 relative)
+    torch.testing.assert_close(out.double(), ref, rtol=tol, atol=tol)
+    go = torch.randn(96, 14, 14, c, generator=g).to(dtype)
+    fd = fq.double().permute(0, 3, 1, 2).requires_grad_(True)
+    d2.roi_align_torch(fd, rois.double(), (14, 14), 1 / 16.0, 0, True).backward(go.double().permute(0, 3, 1, 2))
+    gin = K.roi_align_bwd(dev(go), dev(rois), (n, h, w, c), 1 / 16.0).permute(0, 3, 1, 2).cpu()
+    torch.testing.assert_close(gin.double(), fd.grad, rtol=2e-4, atol=2e-4)
+
+
+def test_roi_align_full_size_properties(K):
+    """BASELINE size (4 views x 512 RoIs, C=1024, bf16): constant map -> 1 inside the image; adjointness."""
+    g = torch.Generator().manual_seed(7)
+    n, c, h, w, r = 4, 1024, 50, 83, 2048
+    rois = make_rois(n, r, 800, 1333, g, extremes=False)
+    rois[:, 3] = rois[:, 3].clamp(max=1320.0)
+    rois[:, 4] = rois[:, 4].clamp(max=790.0)
+    ones = torch.ones(n, h, w, c, device="cuda", dtype=torch.bfloat16)
+    out = K.roi_align_fwd(ones, dev(rois), (14, 14), 1 / 16.0)
+    assert out.shape == (r, 14, 14, c)
+    assert float((out.float() - 1).abs().max()) < 1e-2  # every sample lies inside -> weights sum to 1
+    x = torch.randn(n, h, w, c, generator=g).to(torch.bfloat16).cuda()
+    y = torch.randn(r, 14, 14, c, generator=g).to(torch.bfloat16).cuda()
+    ax = K.roi_align_fwd(x, dev(rois), (14, 14), 1 / 16.0)
+    aty = K.roi_align_bwd(y, dev(rois), (n, h, w, c), 1 / 16.0)
+    lhs = (ax.double() * y.double()).sum()
+    rhs = (x.double() * aty.double()).sum()
+    assert abs(float(lhs - rhs)) / abs(float(lhs)) < 5e-3  # bf16 rounding of A x
+    # linearity: A(2x) = 2 A(x) exactly in bf16 (power-of-two scale)
+    ax2 = K.roi_align_fwd(x * 2, dev(rois), (14, 14), 1 / 16.0)
+    assert torch.equal(ax2, ax * 2)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("m,n,k", [(512, 1024, 2048), (200, 136, 64), (1, 4, 2048), (2048, 2048, 1024), (77, 1024, 512)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_gemm_nt_bf16(K, m, n, k, act):
+    g = torch.Generator().manual_seed(m + n + k)
+    a = (torch.randn(m, k, generator=g) * 0.5).to(torch.bfloat16)
+    b = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(n, generator=g)
+    ref = a.double() @ b.double().t() + bias.double()
+    if act == 1:
+        ref = F.leaky_relu(ref, 0.01)
+    out = K.gemm_nt(dev(a), dev(b), dev(bias), act, 0.01, out_dtype=torch.float32).cpu()
+    torch.testing.assert_close(out.double(), ref, rtol=2e-3, atol=2e-3)  # fp32 accumulate of exact bf16 products
+    out16 = K.gemm_nt(dev(a), dev(b), dev(bias), act, 0.01).cpu()
+    torch.testing.assert_close(out16.double(), ref, rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("m,n,k", [(130, 70, 48), (512, 256, 256), (3, 4, 16)])
+def test_gemm_nt_f32_exact_path(K, m, n, k):
+    g = torch.Generator().manual_seed(m * n)
+    a, b, bias = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g), torch.randn(n, generator=g)
+    ref = (a.double() @ b.double().t() + bias.double()).float()
+    out = K.gemm_nt(dev(a), dev(b), dev(bias)).cpu()
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+    # asymmetric-B / A = I check of the MFMA C layout (cdna_hip_programming.md §3)
+    eye = torch.eye(16, 16)
+    basym = torch.arange(16 * 16, dtype=torch.float32).reshape(16, 16)
+    out = K.gemm_nt(dev(eye), dev(basym)).cpu()
+    assert torch.equal(out, basym.t())
+
+
+def test_gemm_rejects_bad_shapes(K):
+    from coin_amd._lib import CoinHipError
+
+    a = torch.zeros(8, 40, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(CoinHipError):
+        K.gemm_nt(a, a)  # K % 64 != 0 on the bf16 path
+
+
+def test_transpose_and_bias_act_bwd(K):
+    g = torch.Generator().manual_seed(3)
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn(130, 77, generator=g).to(dt)
+        assert torch.equal(K.transpose2d(dev(x)).cpu(), x.t().contiguous())
+    z = torch.randn(300, 96, generator=g, dtype=torch.float64, requires_grad=True)
+    bias = torch.randn(96, generator=g, dtype=torch.float64, requires_grad=True)
+    c = F.leaky_relu(z + bias, 0.01)
+    dc = torch.randn(300, 96, generator=g, dtype=torch.float64)
+    c.backward(dc)
+    dz, db = K.bias_act_bwd(dev(dc.float()), dev(c.detach().float()), 1, 0.01)
+    torch.testing.assert_close(dz.cpu().double(), z.grad, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(db.cpu().double(), bias.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("r,d,kc", [(70, 128, 9), (2048, 1024, 9), (33, 512, 21)])
+def test_cosine_logits(K, dtype, r, d, kc):
+    g = torch.Generator().manual_seed(r + kc)
+    f = torch.randn(r, d, generator=g).to(dtype)
+    t = torch.randn(kc, d, generator=g)
+    fd, td = f.double().requires_grad_(True), t.double().requires_grad_(True)
+    s_ref = (fd / fd.norm(dim=1, keepdim=True)) @ (td / td.norm(dim=1, keepdim=True)).t() / 0.01
+    ds = torch.randn(r, kc, generator=g)
+    s_ref.backward(ds.double())
+    s, inv = K.cosine_logits_fwd(dev(f), dev(t), 100.0)
+    torch.testing.assert_close(s.cpu().double(), s_ref.detach(), rtol=1e-4, atol=1e-4)
+    df, dtx = K.cosine_logits_bwd(dev(ds), dev(f), dev(t), s, inv, 100.0)
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    torch.testing.assert_close(df.cpu().double(), fd.grad, rtol=tol, atol=tol * float(fd.grad.abs().max()))
+    torch.testing.assert_close(dtx.cpu().double(), td.grad, rtol=1e-3, atol=1e-3 * float(td.grad.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------ losses
+def test_mil_ce_golden_and_grad(K):
+    z = load_golden("mil_losses")
+    x, hard, soft, w = (torch.from_numpy(z[k]) for k in ("x", "hard", "soft", "weights"))
+    l, gr = K.mil_ce(dev(x), target=dev(hard), weights=dev(w), avg_positives=True)
+    assert abs(float(l) - float(z["ce_hard_avg_w_mean"])) < 1e-4
+    np.testing.assert_allclose(gr.cpu().numpy(), z["ce_hard_avg_w_mean_grad"], rtol=1e-4, atol=1e-6)
+    l, _ = K.mil_ce(dev(x), labels=dev(hard.argmax(1)), weights=dev(w), avg_positives=True)
+    assert abs(float(l) - float(z["ce_hard_avg_w_mean"])) < 1e-4
+    l, _ = K.mil_ce(dev(x), target=dev(hard), avg_positives=False)
+    assert abs(float(l) - float(z["ce_hard_noavg_mean"])) < 1e-4
+    l, _ = K.mil_ce(dev(x), target=dev(soft + 1e-3), weights=dev(w), avg_positives=True, reduction="sum")
+    assert abs(float(l) - float(z["ce_soft_avg_sum"])) < 1e-4 * max(1.0, abs(float(z["ce_soft_avg_sum"])))
+    l, _ = K.mil_ce(dev(x), target=dev(soft + 1e-3), weights=dev(w), avg_positives=False)
+    assert abs(float(l) - float(z["ce_soft_noavg_w_mean"])) < 1e-4
+    l, gr = K.mil_ce(dev(x[:0]), target=dev(hard[:0]), weights=dev(w[:0]), avg_positives=True)
+    assert float(l) == 0.0 == float(z["ce_empty"])
+
+
+def test_mil_ce_vs_oracle_large(K):
+    from oracle import losses as OL
+
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(2048, 9, generator=g) * 20).requires_grad_(True)  # logits = cos/0.01 are O(10)
+    t = torch.rand(2048, 9, generator=g)
+    w = torch.rand(2048, generator=g)
+    ref = OL.mil_cross_entropy(x, t, w, avg_positives=True)
+    ref.backward()
+    l, gr = K.mil_ce(dev(x.detach()), target=dev(t), weights=dev(w), avg_positives=True)
+    assert abs(float(l) - float(ref)) < 1e-4 * max(1.0, abs(float(ref)))
+    torch.testing.assert_close(gr.cpu(), x.grad, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_kl_div(K, mode):
+    from oracle import losses as OL
+
+    g = torch.Generator().manual_seed(10 + mode)
+    r, c = 333, 9
+    q = torch.softmax(torch.randn(r, c, generator=g) * 2, dim=1)
+    q[5] = F.one_hot(torch.tensor(2), c).float()  # exact zeros in the target (xlogy branch)
+    mask = torch.rand(r, generator=g) > 0.3
+    if mode == 0:
+        x = (torch.randn(r, c, generator=g) * 5).requires_grad_(True)
+        ref = OL.kl_div_mean(torch.softmax(x[mask], dim=1), q[mask])
+    elif mode == 1:
+        x = torch.softmax(torch.randn(r, c, generator=g), dim=1).requires_grad_(True)
+        ref = OL.kl_div_mean(x[mask], q[mask])
+    else:
+        x = (torch.randn(r, generator=g) * 3).requires_grad_(True)
+        q = torch.rand(r, generator=g)
+        p = torch.sigmoid(x[mask])
+        ref = OL.kl_div_mean(torch.stack((p, 1 - p), 1), torch.stack((q[mask], 1 - q[mask]), 1))
+    ref.backward()
+    l, gr = K.kl_div(dev(x.detach()), dev(q), mode, row_mask=dev(mask))
+    assert abs(float(l) - float(ref)) < 1e-5 + 1e-4 * abs(float(ref))
+    torch.testing.assert_close(gr.cpu(), x.grad, rtol=2e-4, atol=1e-7)
+    # unmasked + empty selection
+    l2, _ = K.kl_div(dev(x.detach()), dev(q), mode, row_mask=dev(torch.zeros(r, dtype=torch.bool)))
+    assert float(l2) == 0.0
+
+
+def test_box_reg_and_l1(K):
+    from oracle import losses as OL
+
+    g = torch.Generator().manual_seed(12)
+    r = 500
+    x0 = torch.rand(r, 2, generator=g) * 500
+    p = torch.cat([x0, x0 + torch.rand(r, 2, generator=g) * 200 + 4], 1)
+    gt = p + torch.randn(r, 4, generator=g) * 3
+    cls = torch.randint(-1, 10, (r,), generator=g)
+    pred = torch.randn(r, 4, generator=g, requires_grad=True)
+    ref = OL.box_reg_loss(p, gt, pred, cls, 8)
+    ref.backward()
+    l, gr = K.box_reg_l1(dev(p), dev(gt), dev(pred.detach()), dev(cls), 8, (10, 10, 5, 5), float(r))
+    assert abs(float(l) - float(ref)) < 1e-4 * max(1.0, float(ref))
+    torch.testing.assert_close(gr.cpu(), pred.grad)
+    a = torch.randn(9, 1024, generator=g, requires_grad=True)
+    b = torch.randn(9, 1024, generator=g)
+    ref = F.l1_loss(a, b)
+    ref.backward()
+    l, gr = K.l1_mean(dev(a.detach()), dev(b))
+    assert abs(float(l) - float(ref)) < 1e-5
+    torch.testing.assert_close(gr.cpu(), a.grad)
+
+
+def test_rpn_losses_vs_golden_inputs(K):
+    """Same labels / matched boxes as the reference run in tests/golden/rpn.npz (sampling is RNG: an input)."""
+    from oracle import d2
+
+    z = load_golden("rpn")
+    feat = torch.from_numpy(z["feat"])
+    head = d2.StandardRPNHead(128, 9)
+    head.load_state_dict({k[len("w::rpn_head."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w::rpn_head.")})
+    lg, dl = head([feat])
+    logits = lg[0].permute(0, 2, 3, 1).flatten(1).detach()
+    deltas = dl[0].view(2, -1, 4, 6, 8).permute(0, 3, 4, 1, 2).flatten(1, -2).detach().contiguous()
+    labels = torch.from_numpy(z["labels"]).to(torch.int8)
+    matched = torch.from_numpy(z["matched_boxes"])
+    anchors = torch.from_numpy(z["anchors"])
+    cls, loc, g_l, g_d = K.rpn_losses(dev(logits.contiguous()), dev(labels), dev(deltas), dev(anchors), dev(matched))
+    norm = 64 * 2
+    assert abs(float(cls) / norm - float(z["loss::loss_rpn_cls"])) < 1e-4
+    assert abs(float(loc) / norm - float(z["loss::loss_rpn_loc"])) < 1e-4
+    lx = logits.clone().requires_grad_(True)
+    dx = deltas.clone().requires_grad_(True)
+    from oracle import losses as OL
+
+    c2, l2 = OL.rpn_losses(anchors, lx, labels.long(), dx, matched, 64)
+    (c2 * norm).backward(retain_graph=True)
+    torch.testing.assert_close(g_l.cpu(), lx.grad, rtol=1e-4, atol=1e-6)
+    (l2 * norm).backward()
+    torch.testing.assert_close(g_d.cpu(), dx.grad, rtol=1e-4, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------ streams
+def test_normalize_pad(K):
+    g = torch.Generator().manual_seed(13)
+    imgs = [torch.randint(0, 256, (3, 37, 50), generator=g, dtype=torch.uint8),
+            torch.randint(0, 256, (3, 40, 41), generator=g, dtype=torch.uint8)]
+    mean, std = [0.48145466, 0.4578275, 0.40821073], [0.26862954, 0.26130258, 0.27577711]
+    ref = torch.zeros(2, 3, 40, 50)
+    for i, im in enumerate(imgs):
+        v = (im.float() / 255 - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)
+        ref[i, :, : im.shape[1], : im.shape[2]] = v
+    out, sizes = K.normalize_pad([dev(i) for i in imgs], mean, std)
+    assert sizes == [(37, 50), (40, 41)]
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-6, atol=1e-6)
+    out, _ = K.normalize_pad([dev(i) for i in imgs], mean, std, layout=K.COIN_NHWC, dtype=torch.bfloat16)
+    torch.testing.assert_close(out.float().cpu().permute(0, 3, 1, 2), ref, rtol=1e-2, atol=1e-2)
+
+
+def test_sgd_table_matches_torch_sgd(K):
+    g = torch.Generator().manual_seed(14)
+    shapes = [(1024, 2048), (1024,), (7,), (3, 3, 5, 2), (128, 129)]
+    ps = [torch.randn(s, generator=g) for s in shapes]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    lrs = [0.01, 0.001, 0.01, 0.0001, 0.02]
+    wds = [1e-4, 0.0, 1e-4, 1e-4, 0.0]
+    opt = torch.optim.SGD([{"params": [p], "lr": lr, "weight_decay": wd} for p, lr, wd in zip(ref, lrs, wds)], lr=0.01, momentum=0.9)
+    dp = [dev(p.clone()) for p in ps]
+    shadows = [torch.empty_like(p, dtype=torch.bfloat16) for p in dp]
+    table = K.SgdTable(dp, lrs, wds, shadows)
+    for step in range(3):
+        grads = [torch.randn(s, generator=g) for s in shapes]
+        for p, gr in zip(ref, grads):
+            p.grad = gr.clone()
+        opt.step()
+        table.step([dev(gr) for gr in grads], momentum=0.9)
+    for p, r, s in zip(dp, ref, shadows):
+        torch.testing.assert_close(p.cpu(), r.detach(), rtol=1e-5, atol=1e-6)
+        assert torch.equal(s.cpu(), p.cpu().to(torch.bfloat16))
+
+
+def test_ema_golden(K):
+    z = load_golden("ema")
+    keys = [k[3:] for k in z.files if k.startswith("t::") and z[k].dtype == np.float32]
+    t = [dev(torch.from_numpy(z["t::" + k]).clone()) for k in keys]
+    s = [dev(torch.from_numpy(z["s::" + k]).clone()) for k in keys]
+    K.EmaTable(t, s).update(0.9996)
+    for k, tt in zip(keys, t):
+        np.testing.assert_allclose(tt.cpu().numpy(), z["after::" + k], rtol=1e-6, atol=1e-7)
