@@ -138,16 +138,29 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// backward, NHWC: LDS footprint accumulation
+// backward, NHWC: separable gather.
+//   d feat[y][x][c] = sum_py sum_px Wy[py][y] * Wx[px][x] * gout[py][px][c] / count
+// Wy[py][y] (resp. Wx) is the summed bilinear weight of all samples of bin row py that touch map row y.
+// A block owns one RoI x 64 channels (lane = channel): it builds the two small weight tables in LDS,
+// stages the RoI's [ph*pw][64] gradient tile in LDS once, then each wave walks footprint pixels,
+// contracts the (few) bins that touch the pixel out of LDS and issues ONE 256-byte-contiguous float
+// atomic per footprint pixel.  No per-tap atomics, no LDS atomics.
 // ------------------------------------------------------------------------------------------
-constexpr int BWD_LDS_FLOATS = 16384;  // 64 KiB window -> 2 blocks per CU
-constexpr int BWD_CH = 64;             // channels per block (lane = channel)
+constexpr int BWD_CH = 64;  // channels per block (lane = channel)
 
 template <typename T>
 __global__ __launch_bounds__(256) void roi_align_bwd_nhwc_kernel(
     const T* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gfeat, int C, int H, int W,
-    int R, int ph, int pw, float scale, int sampling_ratio, int aligned) {
-  __shared__ float acc[BWD_LDS_FLOATS];
+    int R, int ph, int pw, float scale, int sampling_ratio, int aligned, int tile_bytes) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* tile = reinterpret_cast<T*>(smem);                       // [ph*pw][64]
+  float* wy = reinterpret_cast<float*>(smem + tile_bytes);    // [ph][H]
+  float* wx = wy + ph * H;                                    // [pw][W]
+  int* ylo = reinterpret_cast<int*>(wx + pw * W);             // [H] first bin row touching y
+  int* yhi = ylo + H;                                         // [H] last bin row (+1)
+  int* xlo = yhi + H;                                         // [W]
+  int* xhi = xlo + W;                                         // [W]
+  int* box = xhi + W;                                         // fy0, fy1, fx0, fx1
   const int roi = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.y * BWD_CH + lane;
@@ -157,97 +170,77 @@ __global__ __launch_bounds__(256) void roi_align_bwd_nhwc_kernel(
   float* __restrict__ gmap = gfeat + (size_t)g.n * H * W * C;
   const T* __restrict__ go = gout + (size_t)roi * ph * pw * C;
 
-  // horizontal footprint of the RoI (conservative; every tap is re-checked against it)
-  int fx0, fx1;
-  {
-    float xf = g.x0 + 0.5f * g.bw / (float)g.gw;
-    float xl = g.x0 + (float)(pw - 1) * g.bw + ((float)g.gw - 0.5f) * g.bw / (float)g.gw;
-    if (xf > xl) { float t = xf; xf = xl; xl = t; }
-    fx0 = (int)fmaxf(floorf(xf) - 1.f, 0.f);
-    fx1 = (int)fminf(fmaxf(floorf(xl) + 2.f, 0.f), (float)(W - 1));
-    if (fx0 > W - 1) fx0 = W - 1;
-    if (fx1 < fx0) fx1 = fx0;
-  }
-  const int fw = fx1 - fx0 + 1;
-  const int rows_cap = BWD_LDS_FLOATS / (fw * BWD_CH);  // 0 for footprints wider than 256 px: direct atomics
-  int wb = 0, wrows = 0;                                 // current window [wb, wb + wrows)
-
-  auto flush = [&]() {
-    const int n = wrows * fw * BWD_CH;
-    for (int i = threadIdx.x; i < n; i += 256) {
-      const int pix = i >> 6;  // BWD_CH == 64: lane == i & 63
-      const float v = acc[i];
-      if (c_ok && v != 0.f) {
-        const int row = pix / fw, col = pix - row * fw;
-        atomicAdd(gmap + ((size_t)(wb + row) * W + (fx0 + col)) * C + c, v);
-      }
+  for (int i = threadIdx.x; i < ph * H + pw * W; i += 256) wy[i] = 0.f;  // wy and wx are adjacent
+  // stage the gradient tile (coalesced over channels)
+  for (int p = wave; p < ph * pw; p += 4) tile[p * BWD_CH + lane] = c_ok ? go[(size_t)p * C + c] : (T)0.f;
+  __syncthreads();
+  // one thread per bin row / bin column accumulates its own table row: no conflicts
+  if ((int)threadIdx.x < ph) {
+    const int py = threadIdx.x;
+    float* row = wy + py * H;
+    for (int iy = 0; iy < g.gh; ++iy) {
+      const float y = g.y0 + (float)py * g.bh + ((float)iy + 0.5f) * g.bh / (float)g.gh;
+      int lo, hi;
+      float wl, wh;
+      if (!axis_taps(y, H, lo, hi, wl, wh)) continue;
+      row[lo] += wl;
+      row[hi] += wh;
     }
-  };
-  auto clear = [&](int rows) {
-    const int n = rows * fw * BWD_CH;
-    for (int i = threadIdx.x; i < n; i += 256) acc[i] = 0.f;
-  };
-
-  for (int py = 0; py < ph; ++py) {
-    const float ybase = g.y0 + (float)py * g.bh;
-    // rows this bin row can touch (conservative)
-    float yf = ybase + 0.5f * g.bh / (float)g.gh;
-    float yl_ = ybase + ((float)g.gh - 0.5f) * g.bh / (float)g.gh;
-    if (yf > yl_) { float t = yf; yf = yl_; yl_ = t; }
-    int a = (int)fmaxf(floorf(yf) - 1.f, 0.f);
-    int b = (int)fminf(fmaxf(floorf(yl_) + 2.f, 0.f), (float)(H - 1));
-    if (a > H - 1) a = H - 1;
-    if (b < a) b = a;
-    const bool fits = (b - a + 1) <= rows_cap;
-    if (fits && (wrows == 0 || b >= wb + rows_cap || a < wb)) {
-      // open a new window starting at row a
-      __syncthreads();
-      if (wrows > 0) flush();
-      __syncthreads();
-      wb = a;
-      wrows = rows_cap < (H - a) ? rows_cap : (H - a);
-      clear(wrows);
-      __syncthreads();
-    }
-    for (int px = wave; px < pw; px += 4) {
-      float gv = 0.f;
-      if (c_ok) gv = (float)go[((size_t)py * pw + px) * C + c] * g.inv_count;
-      const float xbase = g.x0 + (float)px * g.bw;
-      for (int iy = 0; iy < g.gh; ++iy) {
-        const float y = ybase + ((float)iy + 0.5f) * g.bh / (float)g.gh;
-        int yl, yh;
-        float wyl, wyh;
-        if (!axis_taps(y, H, yl, yh, wyl, wyh)) continue;
-        for (int ix = 0; ix < g.gw; ++ix) {
-          const float x = xbase + ((float)ix + 0.5f) * g.bw / (float)g.gw;
-          int xl, xh;
-          float wxl, wxh;
-          if (!axis_taps(x, W, xl, xh, wxl, wxh)) continue;
-          if (!c_ok) continue;
-          const int ys[2] = {yl, yh};
-          const int xs[2] = {xl, xh};
-          const float wy[2] = {wyl, wyh};
-          const float wx[2] = {wxl, wxh};
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              const float w = wy[j] * wx[i] * gv;
-              const int yy = ys[j], xx = xs[i];
-              // wave-uniform test: (yy, xx) do not depend on the lane
-              if (fits && yy >= wb && yy < wb + wrows && xx >= fx0 && xx <= fx1) {
-                atomicAdd(&acc[((yy - wb) * fw + (xx - fx0)) * BWD_CH + lane], w);
-              } else {
-                atomicAdd(gmap + ((size_t)yy * W + xx) * C + c, w);
-              }
-            }
-          }
-        }
-      }
+  } else if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + pw) {
+    const int px = threadIdx.x - 64;
+    float* row = wx + px * W;
+    for (int ix = 0; ix < g.gw; ++ix) {
+      const float x = g.x0 + (float)px * g.bw + ((float)ix + 0.5f) * g.bw / (float)g.gw;
+      int lo, hi;
+      float wl, wh;
+      if (!axis_taps(x, W, lo, hi, wl, wh)) continue;
+      row[lo] += wl;
+      row[hi] += wh;
     }
   }
   __syncthreads();
-  if (wrows > 0) flush();
+  // per map row / column: contiguous range of bins with non-zero weight
+  for (int i = threadIdx.x; i < H + W; i += 256) {
+    const bool isy = i < H;
+    const int k = isy ? i : i - H;
+    const int nb = isy ? ph : pw, ld = isy ? H : W;
+    const float* tab = isy ? wy : wx;
+    int lo = nb, hi = 0;
+    for (int b = 0; b < nb; ++b) {
+      if (tab[b * ld + k] != 0.f) {
+        lo = b < lo ? b : lo;
+        hi = b + 1;
+      }
+    }
+    (isy ? ylo : xlo)[k] = lo;
+    (isy ? yhi : xhi)[k] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int a = H, b = -1, l = W, r = -1;
+    for (int y = 0; y < H; ++y)
+      if (yhi[y] > ylo[y]) { a = y < a ? y : a; b = y; }
+    for (int x = 0; x < W; ++x)
+      if (xhi[x] > xlo[x]) { l = x < l ? x : l; r = x; }
+    box[0] = a; box[1] = b; box[2] = l; box[3] = r;
+  }
+  __syncthreads();
+  const int fy0 = box[0], fy1 = box[1], fx0 = box[2], fx1 = box[3];
+  if (fy1 < fy0 || fx1 < fx0) return;
+  const int fw = fx1 - fx0 + 1, npx = (fy1 - fy0 + 1) * fw;
+  for (int q = wave; q < npx; q += 4) {
+    const int y = fy0 + q / fw, x = fx0 + q % fw;
+    const int pl = ylo[y], phh = yhi[y], ql = xlo[x], qh = xhi[x];
+    if (phh <= pl || qh <= ql) continue;
+    float acc = 0.f;
+    for (int py = pl; py < phh; ++py) {
+      const float a = wy[py * H + y];
+      float rowacc = 0.f;
+      for (int px = ql; px < qh; ++px) rowacc += wx[px * W + x] * (float)tile[(py * pw + px) * BWD_CH + lane];
+      acc += a * rowacc;
+    }
+    if (c_ok) atomicAdd(gmap + ((size_t)y * W + x) * C + c, acc * g.inv_count);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -318,7 +311,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_nchw_kernel(
 
 int check_common(const void* a, const void* rois, const void* b, int N, int C, int H, int W, int layout, int R,
                  int ph, int pw, int dtype) {
-  if (!a || !b || (!rois && R > 0)) return COIN_EINVAL;
+  if (R > 0 && (!a || !b || !rois)) return COIN_EINVAL;
   if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || R < 0 || ph <= 0 || pw <= 0) return COIN_EINVAL;
   if (layout != COIN_NCHW && layout != COIN_NHWC) return COIN_EINVAL;
   if (dtype != COIN_F32 && dtype != COIN_BF16) return COIN_EINVAL;
@@ -369,12 +362,21 @@ extern "C" int coin_roi_align_bwd(const void* grad_out, int N, int C, int H, int
   hipStream_t st = (hipStream_t)stream;
   if (layout == COIN_NHWC) {
     dim3 grid(R, (C + BWD_CH - 1) / BWD_CH);
-    if (dtype == COIN_F32)
-      roi_align_bwd_nhwc_kernel<float><<<grid, 256, 0, st>>>((const float*)grad_out, rois, grad_feat, C, H, W, R, ph,
-                                                               pw, spatial_scale, sampling_ratio, aligned);
-    else
-      roi_align_bwd_nhwc_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)grad_out, rois, grad_feat, C, H, W, R,
-                                                                ph, pw, spatial_scale, sampling_ratio, aligned);
+    const int es = dtype == COIN_F32 ? 4 : 2;
+    const int tile_bytes = ((ph * pw * BWD_CH * es) + 15) & ~15;
+    const size_t lds = (size_t)tile_bytes + sizeof(float) * ((size_t)ph * H + (size_t)pw * W) + sizeof(int) * (2 * (size_t)(H + W) + 4);
+    if (lds > 160 * 1024) return COIN_ESHAPE;  // feature map too large for the LDS weight tables
+    if (dtype == COIN_F32) {
+      if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_nhwc_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      roi_align_bwd_nhwc_kernel<float><<<grid, 256, lds, st>>>((const float*)grad_out, rois, grad_feat, C, H, W, R, ph,
+                                                                 pw, spatial_scale, sampling_ratio, aligned, tile_bytes);
+    } else {
+      if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_nhwc_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      roi_align_bwd_nhwc_kernel<bf16_t><<<grid, 256, lds, st>>>((const bf16_t*)grad_out, rois, grad_feat, C, H, W, R,
+                                                                  ph, pw, spatial_scale, sampling_ratio, aligned, tile_bytes);
+    }
   } else {
     const size_t total = (size_t)R * C * ph * pw;
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);

@@ -675,7 +675,7 @@ def case_roi_sampling():
     sampled = rh.label_and_sample_proposals([copy.deepcopy(p) for p in props], [b["RCNN"] for b in batch], branch="pre_train")
     out = {}
     for i, (p, b, (fg, bg)) in enumerate(zip(props, batch, sampled)):
-        out[f"in{i}.boxes"], out[f"in{i}.logits"] = p.proposal_boxes.tensor, p.objectness_logits
+        out[f"in{i}.boxes"], out[f"in{i}.logits"] = p.proposal_boxes.tensor.clone(), p.objectness_logits.clone()
         out.update(instances_arrays(f"t{i}", b["RCNN"]))
         out.update(instances_arrays(f"o{i}.fg", fg))
         out.update(instances_arrays(f"o{i}.bg", bg))
