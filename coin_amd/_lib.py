@@ -56,6 +56,7 @@ SIGNATURES = {
     "coin_l1_mean_fwd_bwd": [_P, _P, _L, _P, _P, _P],
     "coin_rpn_losses_fwd_bwd": [_P, _P, _P, _P, _P, _L, _L, _I, _P, _P, _P, _P, _P],
     "coin_normalize_pad": [_P, _I, _I, ctypes.POINTER(c_float), ctypes.POINTER(c_float), _P, _I, _I, _I, _I, _I, _P],
+    "coin_nms_batched": [_P, _P, _I, _I, _F, _I, _P, _P, _P, _P],
     "coin_sgd_step": [_P, _I, _L, _F, _F, _I, _P],
     "coin_ema_update": [_P, _I, _L, _F, _P],
 }
@@ -93,6 +94,8 @@ def lib() -> ctypes.CDLL:
         fn = getattr(l, name)
         fn.argtypes = argtypes
         fn.restype = c_int
+    l.coin_nms_workspace_bytes.argtypes = [c_int, c_int]
+    l.coin_nms_workspace_bytes.restype = ctypes.c_size_t
     l.coin_abi_version.restype = c_int
     l.coin_build_arch.restype = c_char_p
     _lib = l

@@ -1,0 +1,174 @@
+"""Box arithmetic, matching, sampling and proposal selection on the device.
+
+Restates the detectron2 0.5 behaviour the reference relies on (Matcher, subsample_labels,
+Box2BoxTransform, DefaultAnchorGenerator, find_top_rpn_proposals; SURVEY.md §8c lists the call
+sites) with device tensors throughout; NMS runs in the HIP kernel ``coin_nms_batched``.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Sequence, Tuple
+
+import torch
+
+from . import kernels as K
+from .structures import Boxes, Instances
+
+SCALE_CLAMP = math.log(1000.0 / 16)
+
+
+class Matcher:
+    """Column-wise argmax over an IoU matrix [num_gt, num_pred] + threshold bands -> labels in {-1,0,1}."""
+
+    def __init__(self, thresholds: Sequence[float], labels: Sequence[int], allow_low_quality_matches: bool = False):
+        th = [-float("inf")] + list(thresholds) + [float("inf")]
+        assert all(lo <= hi for lo, hi in zip(th[:-1], th[1:])) and len(labels) == len(th) - 1
+        self.thresholds, self.labels, self.allow_low_quality_matches = th, list(labels), allow_low_quality_matches
+
+    def __call__(self, iou: torch.Tensor):
+        if iou.numel() == 0:
+            n = iou.size(1)
+            return iou.new_zeros((n,), dtype=torch.int64), iou.new_full((n,), self.labels[0], dtype=torch.int8)
+        vals, matches = iou.max(dim=0)
+        labels = matches.new_full(matches.size(), 1, dtype=torch.int8)
+        for l, lo, hi in zip(self.labels, self.thresholds[:-1], self.thresholds[1:]):
+            labels[(vals >= lo) & (vals < hi)] = l
+        if self.allow_low_quality_matches:
+            best_per_gt = iou.max(dim=1, keepdim=True).values
+            labels[(iou == best_per_gt).any(dim=0)] = 1
+        return matches, labels
+
+
+def subsample_labels(labels: torch.Tensor, num_samples: int, positive_fraction: float, bg_label: int):
+    """Random fg / bg index subsets: two randperm draws, positives first (detectron2 sampling.py)."""
+    positive = ((labels != -1) & (labels != bg_label)).nonzero()[:, 0]
+    negative = (labels == bg_label).nonzero()[:, 0]
+    num_pos = min(positive.numel(), int(num_samples * positive_fraction))
+    num_neg = min(negative.numel(), num_samples - num_pos)
+    p1 = torch.randperm(positive.numel(), device=positive.device)[:num_pos]
+    p2 = torch.randperm(negative.numel(), device=negative.device)[:num_neg]
+    return positive[p1], negative[p2]
+
+
+class Box2BoxTransform:
+    def __init__(self, weights, scale_clamp: float = SCALE_CLAMP):
+        self.weights, self.scale_clamp = tuple(float(w) for w in weights), scale_clamp
+
+    def get_deltas(self, src: torch.Tensor, tgt: torch.Tensor) -> torch.Tensor:
+        sw, sh = src[:, 2] - src[:, 0], src[:, 3] - src[:, 1]
+        sx, sy = src[:, 0] + 0.5 * sw, src[:, 1] + 0.5 * sh
+        tw, th = tgt[:, 2] - tgt[:, 0], tgt[:, 3] - tgt[:, 1]
+        tx, ty = tgt[:, 0] + 0.5 * tw, tgt[:, 1] + 0.5 * th
+        wx, wy, ww, wh = self.weights
+        return torch.stack((wx * (tx - sx) / sw, wy * (ty - sy) / sh, ww * torch.log(tw / sw), wh * torch.log(th / sh)), dim=1)
+
+    def apply_deltas(self, deltas: torch.Tensor, boxes: torch.Tensor) -> torch.Tensor:
+        deltas = deltas.float()
+        boxes = boxes.to(deltas.dtype)
+        w, h = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+        cx, cy = boxes[:, 0] + 0.5 * w, boxes[:, 1] + 0.5 * h
+        wx, wy, ww, wh = self.weights
+        dx, dy = deltas[:, 0::4] / wx, deltas[:, 1::4] / wy
+        dw = torch.clamp(deltas[:, 2::4] / ww, max=self.scale_clamp)
+        dh = torch.clamp(deltas[:, 3::4] / wh, max=self.scale_clamp)
+        pcx, pcy = dx * w[:, None] + cx[:, None], dy * h[:, None] + cy[:, None]
+        pw, ph = torch.exp(dw) * w[:, None], torch.exp(dh) * h[:, None]
+        return torch.stack((pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph), dim=-1).reshape(deltas.shape)
+
+
+def cell_anchors(sizes: Sequence[float], aspect_ratios: Sequence[float]) -> torch.Tensor:
+    out = []
+    for s in sizes:
+        area = s ** 2.0
+        for ar in aspect_ratios:
+            w = math.sqrt(area / ar)
+            h = ar * w
+            out.append([-w / 2.0, -h / 2.0, w / 2.0, h / 2.0])
+    return torch.tensor(out, dtype=torch.float32)
+
+
+def grid_anchors(base: torch.Tensor, grid_hw: Tuple[int, int], stride: int, offset: float, device) -> torch.Tensor:
+    """[H*W*A, 4] anchors ordered (y, x, anchor), matching logits.permute(0,2,3,1).flatten(1)."""
+    gh, gw = grid_hw
+    sx = torch.arange(offset * stride, gw * stride, step=stride, dtype=torch.float32, device=device)
+    sy = torch.arange(offset * stride, gh * stride, step=stride, dtype=torch.float32, device=device)
+    yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+    xx, yy = xx.reshape(-1), yy.reshape(-1)
+    shifts = torch.stack((xx, yy, xx, yy), dim=1)
+    return (shifts.view(-1, 1, 4) + base.to(device).view(1, -1, 4)).reshape(-1, 4)
+
+
+def add_ground_truth_to_proposals(gt, proposals: List[Instances]) -> List[Instances]:
+    logit = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))
+    out = []
+    for g, p in zip(gt, proposals):
+        gb = g if isinstance(g, Boxes) else g.gt_boxes
+        gp = Instances(p.image_size)
+        gp.proposal_boxes = gb
+        gp.objectness_logits = torch.full((len(gb),), logit, device=p.objectness_logits.device)
+        out.append(Instances.cat([p, gp]))
+    return out
+
+
+def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float, max_keep: int = -1) -> torch.Tensor:
+    """Indices kept by greedy NMS in descending-score order (HIP kernel; device only)."""
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    order = torch.argsort(scores, descending=True, stable=True)
+    b = boxes.float()[order].contiguous().unsqueeze(0)
+    counts = torch.tensor([n], dtype=torch.int32, device=boxes.device)
+    keep, num = K.nms_batched(b, counts, iou_threshold, n if max_keep < 0 else max_keep)
+    return order[keep[0, : int(num[0])].long()]
+
+
+def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, iou_threshold: float) -> torch.Tensor:
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    boxes = boxes.float()
+    offsets = idxs.to(boxes) * (boxes.max() + 1.0)
+    return nms(boxes + offsets[:, None], scores, iou_threshold)
+
+
+@torch.no_grad()
+def find_top_rpn_proposals(proposals: torch.Tensor, logits: torch.Tensor, image_sizes: List[Tuple[int, int]], nms_thresh: float,
+                           pre_nms_topk: int, post_nms_topk: int, min_box_size: float, training: bool) -> List[Instances]:
+    """Single-level detectron2 find_top_rpn_proposals, batched: top-k -> clip -> drop empties -> NMS -> top-k.
+    proposals [N, A, 4], logits [N, A].  One host sync (the per-image keep counts)."""
+    n, a = logits.shape
+    k = min(a, pre_nms_topk)
+    top_logits, idx = logits.float().sort(descending=True, dim=1)
+    top_logits, idx = top_logits[:, :k], idx[:, :k]
+    boxes = torch.gather(proposals.float(), 1, idx.unsqueeze(-1).expand(-1, -1, 4))
+    if training and not bool(torch.isfinite(boxes).all() & torch.isfinite(top_logits).all()):
+        raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")
+    hw = torch.tensor(image_sizes, dtype=torch.float32, device=boxes.device)  # [N, 2] (h, w)
+    wmax, hmax = hw[:, 1].view(n, 1), hw[:, 0].view(n, 1)
+    boxes = torch.stack((torch.minimum(boxes[..., 0].clamp(min=0), wmax), torch.minimum(boxes[..., 1].clamp(min=0), hmax),
+                         torch.minimum(boxes[..., 2].clamp(min=0), wmax), torch.minimum(boxes[..., 3].clamp(min=0), hmax)), dim=-1)
+    valid = ((boxes[..., 2] - boxes[..., 0]) > min_box_size) & ((boxes[..., 3] - boxes[..., 1]) > min_box_size)
+    valid &= torch.isfinite(boxes).all(dim=-1) & torch.isfinite(top_logits)
+    # stable partition: valid boxes first, still in descending score order
+    order = torch.argsort((~valid).to(torch.int8), dim=1, stable=True)
+    boxes = torch.gather(boxes, 1, order.unsqueeze(-1).expand(-1, -1, 4)).contiguous()
+    top_logits = torch.gather(top_logits, 1, order)
+    counts = valid.sum(dim=1).to(torch.int32)
+    keep, num = K.nms_batched(boxes, counts, nms_thresh, post_nms_topk)
+    num_host = num.tolist()
+    out = []
+    for i, size in enumerate(image_sizes):
+        ki = keep[i, : num_host[i]].long()
+        res = Instances(size)
+        res.proposal_boxes = Boxes(boxes[i][ki])
+        res.objectness_logits = top_logits[i][ki]
+        out.append(res)
+    return out
+
+
+def detector_postprocess(results: Instances, output_height: int, output_width: int) -> Instances:
+    sx, sy = output_width / results.image_size[1], output_height / results.image_size[0]
+    results = Instances((output_height, output_width), **results.get_fields())
+    boxes = results.pred_boxes if results.has("pred_boxes") else results.proposal_boxes
+    boxes.scale(sx, sy)
+    boxes.clip(results.image_size)
+    return results[boxes.nonempty()]

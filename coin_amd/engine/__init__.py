@@ -1,0 +1,2 @@
+from .base import BASE_Trainer  # noqa: F401
+from .pre_train import PRETrainer  # noqa: F401

@@ -1,0 +1,95 @@
+"""PRETrainer: the CLIPDET pre-training step (coin/engine/pre_train.py:26-327) on one MI355X per process.
+
+``run_step`` follows pre_train.py:178-211: fetch (strong, weak) views, attach the cached teacher targets
+(``set_boxes``), run the detector with ``branch="pre_train"`` on strong + weak views together, sum the loss
+dict, backward, SGD step.  Differences that do not change values: bf16 autocast needs no GradScaler (the
+reference's fp16 autocast does, pre_train.py:84,199-202); no per-step ``empty_cache()/gc.collect()``
+(pre_train.py:210-211); metrics are read back every ``log_period`` steps instead of every step.
+Data parallelism = torch DistributedDataParallel over RCCL (one process per GPU), gradients all-reduced in
+buckets overlapped with backward; BatchNorm statistics stay per GPU (broadcast_buffers=False) as in
+pre_train.py:59-62.
+"""
+from __future__ import annotations
+
+import time
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from ..data import SyntheticTwoViewLoader
+from ..modeling import build_model
+from ..solver import build_lr_scheduler, build_optimizer
+from .base import BASE_Trainer
+
+
+class PRETrainer(BASE_Trainer):
+    def __init__(self, cfg, data_loader=None, collect_model=None):
+        self.cfg = cfg
+        self.device = torch.device(cfg.MODEL.DEVICE)
+        self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world_size > 1 else 0
+        assert cfg.CLOUD.PRE_TRAIN_NAME == "CLIP", "only the CLIP pre-train flavour exists (pre_train.py:40,55)"
+        self.model = build_model(cfg)
+        self.model.train()
+        self.optimizer = build_optimizer(cfg, self.model, name="all")
+        self.ddp_model = self.model
+        if self.world_size > 1:
+            self.ddp_model = torch.nn.parallel.DistributedDataParallel(
+                self.model, device_ids=[self.device.index] if self.device.type == "cuda" else None, broadcast_buffers=False,
+                gradient_as_bucket_view=True, bucket_cap_mb=32)
+        self.scheduler = build_lr_scheduler(cfg, self.optimizer)
+        if data_loader is None:
+            assert cfg.AMD.SYNTHETIC.ENABLED, "only the synthetic loader is built in (the input pipeline is out of scope)"
+            per_gpu = cfg.SOLVER.IMG_PER_BATCH_UNLABEL // self.world_size
+            assert per_gpu >= 1 and cfg.SOLVER.IMG_PER_BATCH_UNLABEL % self.world_size == 0  # coin/data/build.py:153-157
+            data_loader = SyntheticTwoViewLoader(per_gpu, cfg.AMD.SYNTHETIC.HEIGHT, cfg.AMD.SYNTHETIC.WIDTH, len(cfg.AMD.CLASS_NAMES),
+                                                 cfg.AMD.SYNTHETIC.BOXES_PER_IMAGE, seed=cfg.SEED + self.rank, device=self.device,
+                                                 num_images=max(per_gpu, cfg.AMD.SYNTHETIC.NUM_IMAGES // self.world_size))
+            collect_model = data_loader.cache
+        self._data_loader_iter = iter(data_loader)
+        self.collect_model = collect_model
+        self.iter = self.start_iter = 0
+        self.max_iter = cfg.SOLVER.MAX_ITER
+        self.last_losses: Optional[Dict[str, torch.Tensor]] = None
+
+    def set_boxes(self, unlabel_datas: List[List[Dict]], thresh=None):
+        for unlabel_data in unlabel_datas:
+            for d in unlabel_data:
+                res = self.collect_model(d["file_name"])
+                assert res["height"] == d["height"] and res["width"] == d["width"] and res["image_id"] == d["image_id"]
+                res = self.preprocess_results(res, tuple(d["image"].shape[1:]), d["random_flip"], thresh=thresh)
+                rc = res["RCNN"]
+                rc.gt_classes_offline, rc.gt_probs_offline, rc.gt_scores_offline = rc.gt_classes, rc.probs, rc.scores
+                for k in ("scores", "gt_classes", "probs"):
+                    rc.remove(k)
+                rp = res["RPN"]
+                rp.remove("scores")
+                rp.remove("probs")
+                d["RCNN"], d["RPN"] = rc, rp
+        return unlabel_datas
+
+    def run_step(self):
+        assert self.model.training, "[PTrainer] model was changed to eval mode!"
+        strong, weak = next(self._data_loader_iter)
+        thresh = 0.5 if tuple(self.cfg.DATASETS.TRAIN_UNLABEL) == ("cliparttrain",) else None
+        strong, weak = self.set_boxes([strong, weak], thresh=thresh)
+        strong.extend(weak)
+        start = self.cfg.CLOUD.PROTOTYPE_UPDATE_START
+        update_prototype = start != -1 and self.iter >= start
+        record = self.ddp_model(strong, branch="pre_train", update_prototype=update_prototype)
+        losses = sum(record.values())
+        self.optimizer.zero_grad()
+        losses.backward()
+        self.optimizer.step()
+        self.scheduler.step()
+        self.last_losses = record
+        self.iter += 1
+        return record
+
+    def train(self):
+        for _ in range(self.start_iter, self.max_iter):
+            rec = self.run_step()
+            m = self._write_metrics(rec, self.iter)
+            if m is not None and self.rank == 0:
+                print(f"iter {self.iter}: " + "  ".join(f"{k} {v:.4f}" for k, v in m.items()), flush=True)

@@ -16,7 +16,7 @@ from ._lib import ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, COIN_BF16, COIN_F32, COIN_
 
 __all__ = [
     "roi_align_fwd", "roi_align_bwd", "gemm_nt", "transpose2d", "bias_act_bwd", "cosine_logits_fwd",
-    "cosine_logits_bwd", "mil_ce", "kl_div", "box_reg_l1", "l1_mean", "rpn_losses", "normalize_pad",
+    "cosine_logits_bwd", "nms_batched", "mil_ce", "kl_div", "box_reg_l1", "l1_mean", "rpn_losses", "normalize_pad",
     "SgdTable", "EmaTable",
 ]
 
@@ -274,6 +274,24 @@ def rpn_losses(logits: torch.Tensor, labels: torch.Tensor, deltas: torch.Tensor,
                                              ctypes.c_void_p(out.data_ptr() + 4), _p(g_logits), _p(g_deltas), _stream()),
           "coin_rpn_losses_fwd_bwd")
     return out[0], out[1], g_logits, g_deltas
+
+
+# --------------------------------------------------------------------------- NMS
+def nms_batched(boxes: torch.Tensor, counts: torch.Tensor, iou_threshold: float, max_keep: int):
+    """boxes [B,n_max,4] f32 (rows sorted by descending score), counts [B] int32 -> (keep [B,n_max] int32, num_keep [B])."""
+    _dev(boxes, counts)
+    boxes = _f32c(boxes, "boxes")
+    if counts.dtype != torch.int32 or not counts.is_contiguous():
+        raise CoinHipError("counts must be contiguous int32")
+    b, n_max = boxes.shape[0], boxes.shape[1]
+    keep = torch.empty((b, n_max), dtype=torch.int32, device=boxes.device)
+    num = torch.zeros((b,), dtype=torch.int32, device=boxes.device)
+    if b == 0 or n_max == 0:
+        return keep, num
+    ws = torch.empty(_lib.lib().coin_nms_workspace_bytes(b, n_max), dtype=torch.uint8, device=boxes.device)
+    check(_lib.lib().coin_nms_batched(_p(boxes), _p(counts), b, n_max, float(iou_threshold), int(max_keep), _p(ws), _p(keep),
+                                      _p(num), _stream()), "coin_nms_batched")
+    return keep, num
 
 
 # --------------------------------------------------------------------------- streams of bytes

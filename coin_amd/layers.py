@@ -1,0 +1,207 @@
+"""Autograd bindings of the HIP kernels (``coin_amd.kernels``): the differentiable ops the modules use.
+
+Every op here runs ONLY on the GPU through ``libcoin_hip.so``; there is no torch-composite fallback.
+Reference call sites are cited per class (paths under /root/reference).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import kernels as K
+from ._lib import ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, COIN_NHWC, CoinHipError
+
+
+def _pad_rows(x: torch.Tensor, mult: int) -> torch.Tensor:
+    m = x.shape[0]
+    if m % mult == 0:
+        return x
+    pad = x.new_zeros((mult - m % mult,) + tuple(x.shape[1:]))
+    return torch.cat([x, pad], dim=0)
+
+
+# --------------------------------------------------------------------------- RoIAlign
+class _ROIAlignNHWC(Function):
+    """clip_roi_heads.py:172-176 -> ROIPooler -> torchvision roi_align(aligned=True, sampling_ratio=0)."""
+
+    @staticmethod
+    def forward(ctx, feat_nhwc, rois, output_size, spatial_scale, sampling_ratio, aligned):
+        out = K.roi_align_fwd(feat_nhwc, rois, output_size, spatial_scale, sampling_ratio, aligned, COIN_NHWC)
+        ctx.save_for_backward(rois)
+        ctx.meta = (tuple(feat_nhwc.shape), feat_nhwc.dtype, spatial_scale, sampling_ratio, aligned)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        (rois,) = ctx.saved_tensors
+        shape, dtype, scale, sr, aligned = ctx.meta
+        g = K.roi_align_bwd(grad_out.contiguous(), rois, shape, scale, sr, aligned, COIN_NHWC)
+        return g.to(dtype), None, None, None, None, None
+
+
+def roi_align(feat: torch.Tensor, rois: torch.Tensor, output_size: Tuple[int, int], spatial_scale: float,
+              sampling_ratio: int = 0, aligned: bool = True) -> torch.Tensor:
+    """feat: logical [N,C,H,W] in channels_last memory format (NHWC bytes); returns logical
+    [R,C,ph,pw], also channels_last, so that the res5 convolutions consume it without a copy."""
+    if feat.dim() != 4:
+        raise CoinHipError("roi_align expects a 4-D feature map")
+    nhwc = feat.permute(0, 2, 3, 1)
+    if not nhwc.is_contiguous():
+        nhwc = nhwc.contiguous()  # one-off layout change if the producer was not channels_last
+    out = _ROIAlignNHWC.apply(nhwc, rois.float().contiguous(), tuple(output_size), float(spatial_scale), int(sampling_ratio), bool(aligned))
+    return out.permute(0, 3, 1, 2)
+
+
+# --------------------------------------------------------------------------- box-head linear
+class _LinearAct(Function):
+    """nn.Linear (+ LeakyReLU) of FastRCNNOutputLayers (fast_rcnn.py:237-251,331-337) on the MFMA GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, alpha, out_dtype):
+        wq = weight.to(x.dtype) if weight.dtype != x.dtype else weight
+        y = K.gemm_nt(x, wq.contiguous(), bias.float() if bias is not None else None, act, alpha, out_dtype=out_dtype)
+        ctx.act, ctx.alpha, ctx.has_bias = act, alpha, bias is not None
+        ctx.save_for_backward(x, wq, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, wq, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        if y is not None and y.dtype != dy.dtype:
+            y = y.to(dy.dtype)
+        n = dy.shape[1]
+        dbias = torch.zeros(n, dtype=torch.float32, device=dy.device) if ctx.has_bias else None
+        if ctx.act != ACT_NONE or ctx.has_bias:
+            dz, dbias = K.bias_act_bwd(dy, y, ctx.act, ctx.alpha, dbias=dbias if ctx.has_bias else torch.zeros(n, dtype=torch.float32, device=dy.device),
+                                       want_dz=ctx.act != ACT_NONE)
+            if dz is None:
+                dz = dy
+        else:
+            dz = dy
+        dx = dw = None
+        kmult = 64 if x.dtype == torch.bfloat16 else 16
+        if ctx.needs_input_grad[0]:
+            # dX[M,K] = dZ[M,N] . W[N,K]  ==  gemm_nt(dZ, W^T[K,N]); contraction N padded to the MFMA K-step
+            wt = K.transpose2d(wq)                      # [K, N]
+            if n % kmult:
+                padn = kmult - n % kmult
+                dzp = torch.cat([dz, dz.new_zeros(dz.shape[0], padn)], dim=1)
+                wt = torch.cat([wt, wt.new_zeros(wt.shape[0], padn)], dim=1)
+            else:
+                dzp = dz
+            dx = K.gemm_nt(dzp, wt)
+        if ctx.needs_input_grad[1]:
+            # dW[N,K] = dZ^T[N,M] . X[M,K]  ==  gemm_nt(dZ^T, X^T); contraction M zero-padded
+            dzt = K.transpose2d(_pad_rows(dz, kmult))   # [N, Mp]
+            xt = K.transpose2d(_pad_rows(x, kmult))     # [K, Mp]
+            dw = K.gemm_nt(dzt, xt, out_dtype=torch.float32)
+        return dx, dw, (dbias if ctx.has_bias else None), None, None, None
+
+
+def linear_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE, alpha: float = 0.01,
+               out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    return _LinearAct.apply(x.contiguous(), weight, bias, act, alpha, out_dtype or x.dtype)
+
+
+# --------------------------------------------------------------------------- cosine classifier
+class _CosineLogits(Function):
+    """FastRCNNOutputLayers.do_classify (fast_rcnn.py:343-346): L2-normalise both sides, dot, / logit_scale."""
+
+    @staticmethod
+    def forward(ctx, feats, text, inv_scale):
+        scores, inv_norm = K.cosine_logits_fwd(feats, text, inv_scale)
+        ctx.save_for_backward(feats, text, scores, inv_norm)
+        ctx.inv_scale = inv_scale
+        return scores
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ds):
+        feats, text, scores, inv_norm = ctx.saved_tensors
+        df, dt = K.cosine_logits_bwd(ds.float().contiguous(), feats, text, scores, inv_norm, ctx.inv_scale,
+                                     need_text_grad=ctx.needs_input_grad[1])
+        return df, dt, None
+
+
+def cosine_logits(feats: torch.Tensor, text: torch.Tensor, inv_scale: float) -> torch.Tensor:
+    return _CosineLogits.apply(feats.contiguous(), text.float().contiguous(), float(inv_scale))
+
+
+# --------------------------------------------------------------------------- fused losses
+class _ScalarLoss(Function):
+    """Common shape: the kernel returns (loss, dloss/dinput for unit upstream); backward rescales."""
+
+    @staticmethod
+    def forward(ctx, inp, fn):
+        loss, grad = fn(inp.detach())
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None
+
+
+def mil_cross_entropy(x, target=None, labels=None, weights=None, avg_positives=False, reduction="mean"):
+    """coin/utils/losses.py:13-34."""
+    x = x.float().contiguous()
+    return _ScalarLoss.apply(x, lambda t: K.mil_ce(t, target=target, labels=labels, weights=weights,
+                                                   avg_positives=avg_positives, reduction=reduction))
+
+
+def kl_div_from_logits(scores, q, row_mask=None):
+    """KLDivLoss('mean')(log(softmax(scores)+1e-7), q)  (fast_rcnn.py:538,544)."""
+    return _ScalarLoss.apply(scores.float().contiguous(), lambda t: K.kl_div(t, q.float().contiguous(), 0, row_mask))
+
+
+def kl_div_from_probs(p, q, row_mask=None):
+    """KLDivLoss('mean')(log(p+1e-7), q)  (fast_rcnn.py:526)."""
+    return _ScalarLoss.apply(p.float().contiguous(), lambda t: K.kl_div(t, q.float().contiguous(), 1, row_mask))
+
+
+def kl_div_binary(logits, q, row_mask):
+    """RPN objectness distillation (rpn.py:331-335)."""
+    return _ScalarLoss.apply(logits.float().contiguous(), lambda t: K.kl_div(t, q.float().contiguous(), 2, row_mask))
+
+
+def box_reg_l1(proposals, gt_boxes, pred_deltas, gt_classes, num_fg_classes, weights, normalizer):
+    """fast_rcnn.py:601-646."""
+    return _ScalarLoss.apply(pred_deltas.float().contiguous(),
+                             lambda t: K.box_reg_l1(proposals.float().contiguous(), gt_boxes.float().contiguous(), t,
+                                                    gt_classes.contiguous(), num_fg_classes, weights, normalizer))
+
+
+def l1_mean(a, b):
+    """nn.L1Loss('mean') (fast_rcnn.py:351)."""
+    return _ScalarLoss.apply(a.float().contiguous(), lambda t: K.l1_mean(t, b.detach().float().contiguous()))
+
+
+class _RpnLosses(Function):
+    """DualTeacherRPN.losses BCE + L1 (rpn.py:300-324); returns the two SUMS."""
+
+    @staticmethod
+    def forward(ctx, logits, deltas, labels, anchors, matched_gt, min_label):
+        cls, loc, gl, gd = K.rpn_losses(logits.detach(), labels, deltas.detach(), anchors, matched_gt, min_label)
+        ctx.save_for_backward(gl, gd)
+        return cls, loc
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gcls, gloc):
+        gl, gd = ctx.saved_tensors
+        return gl * gcls, gd * gloc, None, None, None, None
+
+
+def rpn_losses(logits, deltas, labels, anchors, matched_gt, min_label=0):
+    return _RpnLosses.apply(logits.float().contiguous(), deltas.float().contiguous(), labels.to(torch.int8).contiguous(),
+                            anchors.float().contiguous(), matched_gt.float().contiguous(), int(min_label))

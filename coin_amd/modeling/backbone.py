@@ -1,0 +1,231 @@
+"""CLIP ModifiedResNet backbone (C4) for the MI355X path.
+
+Mirrors coin/modeling/backbone/clip_backbone.py:150-287 (``CLIP_IMAGE``, registered builder
+``build_clip_image_backbone``) and coin/modeling/utils.py:26-292 (``Bottleneck``, ``ModifiedResNet``):
+identical module tree and state-dict keys (``encoder.visual.*``), ``layer4`` kept for the RoI head.
+
+MI355X execution choices (values unchanged):
+  * activations are channels-last (NHWC bytes) end to end, so RoIAlign reads coalesced channel vectors and
+    res5 consumes its output without a layout change;
+  * the frozen prefix (stem + layer1 at FREEZE_AT=2) runs under no_grad with FrozenBatchNorm folded into the
+    convolution (w*scale, shift as bias) - no activations are kept for a backward that never happens;
+  * convolutions go through torch (MIOpen) in the compute dtype; BatchNorm of the trainable stages uses
+    batch statistics per GPU exactly like the reference (no SyncBN).
+Weights are random-initialised as CLIP does (bn3.weight = 0) - there is no network to download RN50.pt.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..registry import BACKBONE_REGISTRY
+from ..structures import ShapeSpec
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """detectron2 FrozenBatchNorm2d: y = x * w/sqrt(var+eps) + (b - mean * w/sqrt(var+eps)); buffers only."""
+
+    def __init__(self, num_features: int, eps: float = 1e-5):
+        super().__init__()
+        self.num_features, self.eps = num_features, eps
+        self.register_buffer("weight", torch.ones(num_features))
+        self.register_buffer("bias", torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features) - eps)
+
+    def scale_shift(self):
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        return scale, self.bias - self.running_mean * scale
+
+    def forward(self, x):
+        s, b = self.scale_shift()
+        return x * s.reshape(1, -1, 1, 1).to(x.dtype) + b.reshape(1, -1, 1, 1).to(x.dtype)
+
+    @classmethod
+    def convert(cls, module: nn.Module) -> nn.Module:
+        if isinstance(module, (nn.BatchNorm2d, nn.SyncBatchNorm)):
+            res = cls(module.num_features, module.eps)
+            res.weight.data = module.weight.data.clone().detach()
+            res.bias.data = module.bias.data.clone().detach()
+            res.running_mean.data = module.running_mean.data
+            res.running_var.data = module.running_var.data
+            return res
+        for name, child in module.named_children():
+            new = cls.convert(child)
+            if new is not child:
+                module.add_module(name, new)
+        return module
+
+
+def _conv_bn(x, conv: nn.Conv2d, bn: nn.Module, relu: bool):
+    """conv -> norm (-> relu).  In the bf16 throughput mode a frozen norm is folded into the convolution; the fp32
+    parity mode keeps the reference's operation order (conv, then x*scale + shift)."""
+    if isinstance(bn, FrozenBatchNorm2d) and x.dtype != torch.float32:
+        s, b = bn.scale_shift()
+        w = conv.weight * s.view(-1, 1, 1, 1)
+        y = F.conv2d(x, w.to(x.dtype), b.to(x.dtype), conv.stride, conv.padding)
+    else:
+        y = bn(conv(x))
+    return F.relu(y) if relu else y
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes: int, planes: int, stride: int = 1):
+        super().__init__()
+        out = planes * self.expansion
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.avgpool = nn.AvgPool2d(stride) if stride > 1 else nn.Identity()
+        self.conv3 = nn.Conv2d(planes, out, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(out)
+        self.relu = nn.ReLU(inplace=True)
+        self.stride = stride
+        self.downsample = None
+        if stride > 1 or inplanes != out:
+            self.downsample = nn.Sequential(OrderedDict([
+                ("-1", nn.AvgPool2d(stride)), ("0", nn.Conv2d(inplanes, out, 1, stride=1, bias=False)), ("1", nn.BatchNorm2d(out))]))
+
+    def forward(self, x):
+        y = _conv_bn(x, self.conv1, self.bn1, True)
+        y = _conv_bn(y, self.conv2, self.bn2, True)
+        y = _conv_bn(self.avgpool(y), self.conv3, self.bn3, False)
+        if self.downsample is not None:
+            x = _conv_bn(self.downsample[0](x), self.downsample[1], self.downsample[2], False)
+        return F.relu(y + x)
+
+
+class ModifiedResNet(nn.Module):
+    def __init__(self, layers, width: int = 64, out_features=("res4",), freeze_at: int = 0):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, width // 2, 3, stride=2, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width // 2)
+        self.conv2 = nn.Conv2d(width // 2, width // 2, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(width // 2)
+        self.conv3 = nn.Conv2d(width // 2, width, 3, padding=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(width)
+        self.avgpool = nn.AvgPool2d(2)
+        self._inplanes = width
+        self.layer1 = self._make_layer(width, layers[0])
+        self.layer2 = self._make_layer(width * 2, layers[1], stride=2)
+        self.layer3 = self._make_layer(width * 4, layers[2], stride=2)
+        self.layer4 = self._make_layer(width * 8, layers[3], stride=2)  # used by the RoI head (C4)
+        self._out_features = list(out_features)
+        self._out_feature_channels = {"stem": width, "res2": width * 4, "res3": width * 8, "res4": width * 16}
+        self._out_feature_strides = {"stem": 4, "res2": 4, "res3": 8, "res4": 16}
+        self.freeze_at = freeze_at
+        self.freeze(freeze_at)
+
+    def _make_layer(self, planes, blocks, stride=1):
+        mods = [Bottleneck(self._inplanes, planes, stride)]
+        self._inplanes = planes * Bottleneck.expansion
+        mods += [Bottleneck(self._inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*mods)
+
+    def freeze(self, freeze_at: int = 0):
+        """coin/modeling/utils.py:243-284."""
+        def fz(m):
+            for p in m.parameters():
+                p.requires_grad = False
+            return FrozenBatchNorm2d.convert(m)
+
+        if freeze_at >= 1:
+            for name in ("conv1", "bn1", "conv2", "bn2", "conv3", "bn3"):
+                setattr(self, name, fz(getattr(self, name)))
+        for idx, stage in enumerate([self.layer1, self.layer2, self.layer3, self.layer4], start=2):
+            if freeze_at >= idx:
+                for block in stage.children():
+                    fz(block)
+        return self
+
+    def _stem(self, x):
+        for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)):
+            x = _conv_bn(x, conv, bn, True)
+        return self.avgpool(x)
+
+    def forward(self, x) -> Dict[str, torch.Tensor]:
+        assert x.dim() == 4
+        frozen_prefix = self.freeze_at  # stages [1, freeze_at] have no trainable parameter
+        stages = [self._stem, self.layer1, self.layer2, self.layer3]
+        for i, stage in enumerate(stages, start=1):
+            if i <= frozen_prefix and not x.requires_grad:
+                with torch.no_grad():
+                    x = stage(x)
+            else:
+                x = stage(x)
+        return {"res4": x}
+
+    def output_shape(self):
+        return {n: ShapeSpec(channels=self._out_feature_channels[n], stride=self._out_feature_strides[n]) for n in self._out_features}
+
+
+class _ImageEncoder(nn.Module):
+    def __init__(self, visual):
+        super().__init__()
+        self.visual = visual
+        self.attnpool = None  # meanpool configs delete it (clip_rcnn.py:226-227)
+
+
+_ARCH = {"RN50": ((3, 4, 6, 3), 64, 1024), "RN101": ((3, 4, 23, 3), 64, 512), "RN50x4": ((4, 6, 10, 6), 80, 640)}
+
+
+class CLIP_IMAGE(nn.Module):
+    size_divisibility = 0
+
+    def __init__(self, type: str = "RN50", out_features=("res4",), freeze_at: int = 2, update_backbone: bool = True,
+                 layers=None, width=None):
+        super().__init__()
+        l, w, _ = _ARCH.get(type, _ARCH["RN50"])
+        layers, width = layers or l, width or w
+        self.type = type
+        self.encoder = _ImageEncoder(ModifiedResNet(layers, width, out_features, freeze_at))
+        for name, p in self.encoder.visual.named_parameters():  # clip_backbone.py:56-61
+            if name.endswith("bn3.weight") and name.startswith("layer"):
+                nn.init.zeros_(p)
+        self.update_backbone = update_backbone
+        if not update_backbone:  # clip_backbone.py:211-217
+            for n, p in self.encoder.visual.named_parameters():
+                if "layer4" not in n:
+                    p.requires_grad = False
+
+    @classmethod
+    def from_config(cls, cfg):
+        a = cfg.AMD.ARCH
+        return cls(type=cfg.MODEL.TEACHER_OFFLINE.TYPE or "RN50", out_features=cfg.MODEL.RESNETS.OUT_FEATURES,
+                   freeze_at=cfg.MODEL.BACKBONE.FREEZE_AT, update_backbone=cfg.CLOUD.UPDATE_BACKBONE,
+                   layers=tuple(a.LAYERS) or None, width=a.WIDTH or None)
+
+    layer4 = property(lambda self: self.encoder.visual.layer4)
+    attnpool = property(lambda self: self.encoder.attnpool)
+
+    def del_attnpool(self):
+        self.encoder.attnpool = None
+
+    def output_shape(self):
+        return self.encoder.visual.output_shape()
+
+    def train(self, mode: bool = True):  # clip_backbone.py:223-234
+        if self.update_backbone:
+            return super().train(mode)
+        self.training = False
+        self.encoder.training = False
+        for m in self.encoder.children():
+            if m is not None:
+                m.eval()
+        self.encoder.visual.layer4.train(mode)
+        return self
+
+    def forward(self, image: torch.Tensor):
+        return self.encoder.visual(image)
+
+
+@BACKBONE_REGISTRY.register()
+def build_clip_image_backbone(cfg, input_shape=None):
+    return CLIP_IMAGE.from_config(cfg)

@@ -1,0 +1,277 @@
+"""FastRCNNOutputLayers on the HIP box-head kernels.
+
+Mirrors coin/modeling/roi_heads/fast_rcnn.py:182-752: same constructor surface, state-dict keys
+(``trans.{0,2,4}``, ``cls_score``, ``bbox_pred``, ``logit_scale``, ``text_encoder.*``), loss names and
+weights.  Execution: every Linear is ``coin_gemm_nt`` (MFMA) with bias + LeakyReLU fused in the epilogue;
+the cosine classifier, MIL-CE, KL, box-regression L1 and text-align L1 are one fused HIP launch each
+(forward value + gradient).  Row selection (fg / bg / A / B of each image) is done with index tensors
+built once per call instead of per-image split/cat lists.
+The CKG terms (`loss_merge_*`) stay torch-composite: they are tens of rows and need double backward
+(coin/utils/losses.py:75-96).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import layers as L
+from .._lib import ACT_LEAKY_RELU, ACT_NONE
+from ..box_ops import Box2BoxTransform, batched_nms
+from ..structures import Boxes, Instances
+from .text_encoder import TEXT_DIMS, text_dim_of
+
+
+def weight_init(m):
+    if isinstance(m, nn.Linear):
+        nn.init.xavier_normal_(m.weight)
+        nn.init.constant_(m.bias, 0)
+
+
+def _cat(ts, dim=0):
+    return ts[0] if len(ts) == 1 else torch.cat(ts, dim)
+
+
+def _ranges(starts: List[int], lens: List[int], device) -> torch.Tensor:
+    parts = [torch.arange(s, s + l, device=device) for s, l in zip(starts, lens) if l > 0]
+    return torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device=device)
+
+
+@torch.no_grad()
+def _prototype_ema(proto, feats, one_hot, rate):
+    new = proto.clone().float()
+    cnt = one_hot.sum(0)
+    present = cnt != 0
+    mean = one_hot.t() @ feats.float() / cnt.clamp(min=1).unsqueeze(1)
+    new = torch.where(present.unsqueeze(1), mean, new)
+    return proto * rate + (1 - rate) * new
+
+
+def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, nms_thresh, topk_per_image):
+    """fast_rcnn.py:116-175."""
+    valid = torch.isfinite(boxes).all(dim=1) & torch.isfinite(scores).all(dim=1)
+    if not bool(valid.all()):
+        boxes, scores = boxes[valid], scores[valid]
+    probs = scores.clone()
+    scores = scores[:, :-1]
+    nreg = boxes.shape[1] // 4
+    b = Boxes(boxes.reshape(-1, 4))
+    b.clip(image_shape)
+    boxes = b.tensor.view(-1, nreg, 4)
+    mask = scores > score_thresh
+    inds = mask.nonzero()
+    boxes = boxes[inds[:, 0], 0] if nreg == 1 else boxes[mask]
+    scores = scores[mask]
+    probs = probs[inds[:, 0]]
+    keep = batched_nms(boxes, scores, inds[:, 1], nms_thresh)
+    if topk_per_image >= 0:
+        keep = keep[:topk_per_image]
+    res = Instances(image_shape)
+    res.pred_boxes = Boxes(boxes[keep])
+    res.scores = scores[keep]
+    res.probs = probs[keep]
+    res.pred_classes = inds[keep][:, 1]
+    return res, inds[keep][:, 0]
+
+
+class FastRCNNOutputLayers(nn.Module):
+    def __init__(self, input_shape, *, text_encoder, pooling_type, box2box_transform, text_dim, classes_weight, loss_type,
+                 test_score_thresh=0.0, test_nms_thresh=0.5, test_topk_per_image=100, cls_agnostic_bbox_reg=False,
+                 smooth_l1_beta=0.0, box_reg_loss_type="smooth_l1", loss_weight=1.0, batch_size_per_image, cls_b_thresh,
+                 dataset, prototype_update_rate):
+        super().__init__()
+        input_size = input_shape.channels * (input_shape.width or 1) * (input_shape.height or 1)
+        assert pooling_type in ("attnpool", "meanpool")
+        assert cls_agnostic_bbox_reg and box_reg_loss_type == "smooth_l1" and smooth_l1_beta == 0.0, \
+            "the fused box-regression kernel implements COIN's configuration (class-agnostic L1)"
+        self.text_dim = text_dim
+        self.trans = nn.Sequential(nn.Linear(input_size, input_size // 2), nn.LeakyReLU(), nn.Linear(input_size // 2, input_size // 2),
+                                   nn.LeakyReLU(), nn.Linear(input_size // 2, input_size))
+        self.cls_score = nn.Linear(input_size, text_dim)
+        self.logit_scale = nn.Parameter(torch.FloatTensor([0.01]), requires_grad=False)
+        self.num_classes = text_encoder.num_classes - 1
+        self.bbox_pred = nn.Linear(input_size, 4)
+        self.trans.apply(weight_init)
+        nn.init.normal_(self.cls_score.weight, std=0.01)
+        nn.init.normal_(self.bbox_pred.weight, std=0.001)
+        nn.init.constant_(self.cls_score.bias, 0)
+        nn.init.constant_(self.bbox_pred.bias, 0)
+        self.box2box_transform = box2box_transform
+        self.test_score_thresh, self.test_nms_thresh, self.test_topk_per_image = test_score_thresh, test_nms_thresh, test_topk_per_image
+        self.loss_weight = loss_weight if isinstance(loss_weight, dict) else {}
+        self.text_encoder = text_encoder
+        self.loss_type, self.classes_weight = loss_type, list(classes_weight)
+        self.batch_size_per_image, self.cls_b_thresh = batch_size_per_image, cls_b_thresh
+        self.dataset, self.prototype_update_rate = tuple(dataset), prototype_update_rate
+        self._inv_scale = 1.0 / 0.01
+
+    @classmethod
+    def from_config(cls, cfg, text_encoder, input_shape):
+        lw = {"loss_box_reg": cfg.CLOUD.LOSS_BOX_REG_WEIGHT, "loss_box_reg_offline": cfg.CLOUD.LOSS_BOX_REG_OFFLINE_WEIGHT,
+              "loss_box_reg_online": cfg.CLOUD.LOSS_BOX_REG_ONLINE_WEIGHT, "loss_cls": cfg.CLOUD.LOSS_CLS_WEIGHT,
+              "loss_text_align": cfg.CLOUD.LOSS_TEXT_ALIGN_WEIGHT, "loss_distillation": cfg.CLOUD.LOSS_DISTILLATION_WEIGHT,
+              "loss_cls_b": cfg.CLOUD.LOSS_CLS_B_WEIGHT}
+        return cls(input_shape, text_encoder=text_encoder, pooling_type=cfg.MODEL.ROI_HEADS.POOLING_TYPE,
+                   box2box_transform=Box2BoxTransform(cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS),
+                   text_dim=text_dim_of(cfg), classes_weight=cfg.CLOUD.CLASSES_WEIGHT,
+                   loss_type=cfg.CLOUD.LOSS_TYPE, test_score_thresh=cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST,
+                   test_nms_thresh=cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST, test_topk_per_image=cfg.TEST.DETECTIONS_PER_IMAGE,
+                   cls_agnostic_bbox_reg=cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG, smooth_l1_beta=cfg.MODEL.ROI_BOX_HEAD.SMOOTH_L1_BETA,
+                   box_reg_loss_type=cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE, loss_weight=lw,
+                   batch_size_per_image=cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE, cls_b_thresh=cfg.CLOUD.CLS_B_THRESH,
+                   dataset=cfg.DATASETS.TRAIN_UNLABEL, prototype_update_rate=cfg.CLOUD.PROTOTYPE_UPDATE_WEIGHT)
+
+    # ------------------------------------------------------------------ forward (fast_rcnn.py:318-353)
+    def forward(self, x, branch, return_feats=True):
+        if x.dim() > 2:
+            x = torch.flatten(x, start_dim=1)
+        t = self.trans
+        h = L.linear_act(x, t[0].weight, t[0].bias, ACT_LEAKY_RELU, 0.01)
+        h = L.linear_act(h, t[2].weight, t[2].bias, ACT_LEAKY_RELU, 0.01)
+        h = L.linear_act(h, t[4].weight, t[4].bias, ACT_NONE)
+        class_feats = L.linear_act(h, self.cls_score.weight, self.cls_score.bias, ACT_NONE)
+        scores = self.do_classify(class_feats, branch)
+        proposal_deltas = L.linear_act(h, self.bbox_pred.weight, self.bbox_pred.bias, ACT_NONE, out_dtype=torch.float32)
+        if return_feats and self.training and branch != "test":
+            return scores, proposal_deltas, class_feats
+        return scores, proposal_deltas
+
+    def do_classify(self, image_features, branch):
+        text = self.text_encoder(added=True)
+        # the kernel L2-normalises both operands (the encoder output is already unit-norm: normalising twice, as the
+        # reference does at fast_rcnn.py:344, is the identity up to rounding)
+        scores = L.cosine_logits(image_features, text, self._inv_scale)
+        if self.training and branch != "test":
+            fixed = self.text_encoder(added=False).detach()
+            fixed = fixed / fixed.norm(dim=1, keepdim=True)
+            tn = text / text.norm(dim=1, keepdim=True)
+            return scores, L.l1_mean(tn, fixed)
+        return scores
+
+    # ------------------------------------------------------------------ helpers
+    def _mil(self, scores, labels_or_target, n_fg, n_bg, avg_positives=True, soft=False):
+        if self.loss_type != "MILCrossEntropy":
+            raise NotImplementedError("MILFocalLoss is not on the HIP path (CLOUD.LOSS_TYPE MILCrossEntropy is the shipped config)")
+        w = torch.cat([torch.ones(n_fg, device=scores.device), torch.full((n_bg,), float(self.classes_weight[-1]), device=scores.device)])
+        if soft:
+            return L.mil_cross_entropy(scores, target=labels_or_target, weights=w, avg_positives=avg_positives)
+        return L.mil_cross_entropy(scores, labels=labels_or_target, weights=w, avg_positives=avg_positives)
+
+    def box_reg_loss(self, proposal_boxes, gt_boxes, pred_deltas, gt_classes, normalizer=None):
+        norm = float(normalizer) if normalizer is not None else float(max(gt_classes.numel(), 1))
+        return L.box_reg_l1(proposal_boxes, gt_boxes, pred_deltas, gt_classes, self.num_classes, self.box2box_transform.weights, norm)
+
+    # ------------------------------------------------------------------ losses (fast_rcnn.py:355-571)
+    def losses(self, predictions, proposals, merge_module, branch, update_prototype=False):
+        kc = self.num_classes + 1
+        te = self.text_encoder
+        if branch == "pre_train":
+            (scores, lta), deltas, feats = predictions
+            dev = scores.device
+            losses = {"loss_text_align": lta}
+            nfg = [len(p[0]) for p in proposals]
+            nbg = [len(p[1]) for p in proposals]
+            assert all(b > 0 or a == 0 for a, b in zip(nfg, nbg)), "image with foreground but no background RoIs (fast_rcnn.py:383-385)"
+            starts = [0]
+            for a, b in zip(nfg, nbg):
+                starts.append(starts[-1] + a + b)
+            fg_idx = _ranges(starts[:-1], nfg, dev)
+            bg_idx = _ranges([s + a for s, a in zip(starts[:-1], nfg)], nbg, dev)
+            cls_fg = _cat([p[0].gt_classes_offline for p in proposals])
+            cls_bg = _cat([p[1].gt_classes for p in proposals])
+            any_fg = sum(nfg) != 0
+            if any_fg:
+                s = scores[torch.cat([fg_idx, bg_idx])]
+                if self.dataset != ("cliparttrain",):
+                    losses["loss_cls"] = self._mil(s, torch.cat([cls_fg, cls_bg]), len(fg_idx), len(bg_idx), True)
+                else:
+                    probs_fg = _cat([p[0].gt_probs_offline for p in proposals])
+                    tgt = torch.cat([F.one_hot(cls_fg, kc) * probs_fg.max(1)[0].unsqueeze(1), F.one_hot(cls_bg, kc)]).float()
+                    losses["loss_cls"] = self._mil(s, tgt, len(fg_idx), len(bg_idx), False, soft=True)
+            else:
+                losses["loss_cls"] = torch.zeros_like(lta)
+            if update_prototype and any_fg:
+                with torch.no_grad():
+                    fn = feats.detach().float()
+                    fn = fn / fn.norm(dim=1, keepdim=True)
+                    f = fn[torch.cat([fg_idx, bg_idx])]
+                    oh = F.one_hot(torch.cat([cls_fg, cls_bg]), kc).float()
+                    te.per_class_feat.data = _prototype_ema(te.per_class_feat.data, f, oh, self.prototype_update_rate)
+            cls_all = _cat([torch.cat([p[0].gt_classes_offline, p[1].gt_classes]) for p in proposals])
+            pboxes = _cat([torch.cat([p[0].proposal_boxes.tensor, p[1].proposal_boxes.tensor]) for p in proposals])
+            gboxes = _cat([torch.cat([p[0].gt_boxes.tensor, p[1].proposal_boxes.tensor]) for p in proposals])
+            losses["loss_box_reg"] = self.box_reg_loss(pboxes, gboxes, deltas, cls_all)
+            return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
+
+        assert branch in ("step_one", "step_two")
+        ((scores, lta), deltas, feats), ((scores_c, _), _) = predictions
+        proposals, inst_c = proposals
+        dev = scores.device
+        na = [len(p[0]) for p in proposals]
+        nb = [len(p[1]) for p in proposals]
+        ng = [len(p[2]) for p in proposals]
+        starts = [0]
+        for a, b, g in zip(na, nb, ng):
+            starts.append(starts[-1] + a + b + g)
+        ia = _ranges(starts[:-1], na, dev)
+        ib = _ranges([s + a for s, a in zip(starts[:-1], na)], nb, dev)
+        ig = _ranges([s + a + b for s, a, b in zip(starts[:-1], na, nb)], ng, dev)
+        calc_bg = sum(ng) != 0
+        losses = {"loss_text_align": lta}
+        cls_a = _cat([p[0].gt_classes for p in proposals])
+        cls_g = _cat([p[2].gt_classes for p in proposals])
+        s_a = scores[ia]
+        losses["loss_cls"] = self._mil(torch.cat([s_a, scores[ig]]), torch.cat([cls_a, cls_g]), len(ia), len(ig), True)
+        oh_a, oh_g = F.one_hot(cls_a, kc), F.one_hot(cls_g, kc)
+        if update_prototype:
+            with torch.no_grad():
+                fn = feats.detach().float()
+                fn = fn / fn.norm(dim=1, keepdim=True)
+                f_a, f_b, f_g = fn[ia], fn[ib], fn[ig]
+                rate = self.prototype_update_rate
+                te.per_class_feat.data = _prototype_ema(te.per_class_feat.data, torch.cat([f_a, f_g]), torch.cat([oh_a, oh_g]).float(), rate)
+            if sum(nb) != 0:
+                pb_on = _cat([p[1].gt_probs_online for p in proposals])
+                pb_off = _cat([p[1].gt_probs_offline for p in proposals])
+                with torch.no_grad():
+                    oh_b_on = F.one_hot(_cat([p[1].gt_classes_online for p in proposals]), kc)
+                    oh_b_off = F.one_hot(_cat([p[1].gt_classes_offline for p in proposals]), kc)
+                    f_abg = torch.cat([f_a, f_b, f_g])
+                    te.prototype_b_online.data = _prototype_ema(te.prototype_b_online.data, f_abg, torch.cat([oh_a, oh_b_on, oh_g]).float(), rate)
+                    te.prototype_b_offline.data = _prototype_ema(te.prototype_b_offline.data, f_abg, torch.cat([oh_a, oh_b_off, oh_g]).float(), rate)
+                pa_on = _cat([p[0].gt_probs_online for p in proposals])
+                pa_off = _cat([p[0].gt_probs_offline for p in proposals])
+                m_a = merge_module(f_a, te.prototype_b_offline.data, te.prototype_b_online.data, pa_off, pa_on)
+                losses["loss_merge_base"] = L.kl_div_from_probs(m_a, oh_a.float())
+                m_b = merge_module(f_b, te.prototype_b_offline.data, te.prototype_b_online.data, pb_off, pb_on)
+                s_b = scores[ib]
+                p_b = F.softmax(s_b, dim=1)
+                p_a = F.softmax(s_a, dim=1)
+                losses["loss_merge_b"] = F.mse_loss(p_b, m_b)
+                losses["loss_merge_a"] = F.mse_loss(p_a, oh_a.float())
+                if branch == "step_two":
+                    keep = (m_b.max(1)[0] >= self.cls_b_thresh).detach()
+                    if bool(keep.any()):
+                        losses["loss_cls_b"] = L.kl_div_from_logits(s_b, m_b.detach(), row_mask=keep)
+        if scores_c is not None:
+            q = _cat([c.gt_probs for c in inst_c])
+            losses["loss_distillation"] = L.kl_div_from_logits(scores_c, q)
+        cls_on = _cat([torch.cat([p[0].gt_classes, p[1].gt_classes_online, p[2].gt_classes]) for p in proposals])
+        pboxes = _cat([torch.cat([p[0].proposal_boxes.tensor, p[1].proposal_boxes.tensor, p[2].proposal_boxes.tensor]) for p in proposals])
+        gboxes = _cat([torch.cat([p[0].gt_boxes.tensor, p[1].gt_boxes.tensor, p[2].proposal_boxes.tensor]) for p in proposals])
+        norm = None if calc_bg else self.batch_size_per_image * len(proposals)
+        losses["loss_box_reg"] = self.box_reg_loss(pboxes, gboxes, deltas, cls_on, normalizer=norm)
+        return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
+
+    # ------------------------------------------------------------------ inference (fast_rcnn.py:648-671)
+    def inference(self, predictions, proposals: List[Instances]):
+        scores, deltas = predictions
+        n = [len(p) for p in proposals]
+        pb = _cat([p.proposal_boxes.tensor for p in proposals])
+        boxes = self.box2box_transform.apply_deltas(deltas.float(), pb).split(n)
+        probs = F.softmax(scores.float(), dim=-1).split(n)
+        out = [fast_rcnn_inference_single_image(b, s, p.image_size, self.test_score_thresh, self.test_nms_thresh, self.test_topk_per_image)
+               for b, s, p in zip(boxes, probs, proposals)]
+        return [o[0] for o in out], [o[1] for o in out]

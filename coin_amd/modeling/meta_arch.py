@@ -1,0 +1,130 @@
+"""OpenVocabularyRCNN (registered under the reference's name) and the model builders.
+
+Mirrors coin/modeling/meta_arch/clip_rcnn.py:187-426 and coin/modeling/meta_arch/build.py:7-78
+(``build_model`` dispatch on ``cfg.CLOUD.Trainer``).  ``preprocess_image`` replaces the reference's per-image
+GPU -> CPU -> numpy -> GPU bounce (clip_rcnn.py:295-296) with one HIP launch per image that normalises and
+zero-pads the uint8 pixels straight into the channels-last batch (``coin_normalize_pad``).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from .. import kernels as K
+from .._lib import COIN_NHWC
+from ..box_ops import detector_postprocess
+from ..registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY
+from ..structures import ImageList, Instances
+from .roi_heads import build_roi_heads
+from .rpn import build_proposal_generator
+
+
+def build_backbone(cfg):
+    return BACKBONE_REGISTRY.get(cfg.MODEL.BACKBONE.NAME)(cfg, None)
+
+
+@META_ARCH_REGISTRY.register()
+class OpenVocabularyRCNN(nn.Module):
+    def __init__(self, *, backbone, proposal_generator, roi_heads, pixel_mean, pixel_std, device="cuda", vis_period=0,
+                 input_format="RGB", compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.backbone, self.proposal_generator, self.roi_heads = backbone, proposal_generator, roi_heads
+        self.target_device = device
+        self.register_buffer("pixel_mean", torch.tensor(pixel_mean), False)
+        self.register_buffer("pixel_std", torch.tensor(pixel_std), False)
+        self._mean, self._std = [float(v) for v in pixel_mean], [float(v) for v in pixel_std]
+        self.input_format, self.vis_period = input_format, vis_period
+        self.set_compute_dtype(compute_dtype)
+
+    def set_compute_dtype(self, dtype: torch.dtype):
+        assert dtype in (torch.bfloat16, torch.float32)
+        self.compute_dtype = dtype
+        self.roi_heads.compute_dtype = dtype
+
+    @classmethod
+    def from_config(cls, cfg):
+        backbone = build_backbone(cfg)
+        if cfg.MODEL.ROI_HEADS.POOLING_TYPE != "attnpool":
+            backbone.del_attnpool()
+        roi_heads = build_roi_heads(cfg, backbone.output_shape(), backgroud=True, name=cfg.MODEL.ROI_HEADS.NAME)
+        return cls(backbone=backbone, roi_heads=roi_heads, pixel_mean=cfg.INPUT.TEACHER_OFFLINE.PIXEL_MEAN,
+                   pixel_std=cfg.INPUT.TEACHER_OFFLINE.PIXEL_STD, device=cfg.MODEL.DEVICE, input_format=cfg.INPUT.FORMAT,
+                   vis_period=cfg.VIS_PERIOD, proposal_generator=build_proposal_generator(cfg, backbone.output_shape()),
+                   compute_dtype=torch.bfloat16 if cfg.AMD.COMPUTE_DTYPE == "bf16" else torch.float32)
+
+    @property
+    def device(self):
+        return self.target_device
+
+    def to(self, device, *args, **kwargs):
+        result = super().to(device, *args, **kwargs)
+        self.target_device = device
+        return result
+
+    def _autocast(self):
+        return torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.compute_dtype == torch.bfloat16)
+
+    def preprocess_image(self, batched_inputs: List[Dict]) -> ImageList:
+        imgs = [x["image"].to(self.pixel_mean.device, non_blocking=True).contiguous() for x in batched_inputs]
+        batch, sizes = K.normalize_pad(imgs, self._mean, self._std, self.backbone.size_divisibility, COIN_NHWC, self.compute_dtype)
+        return ImageList(batch.permute(0, 3, 1, 2), sizes)  # logical NCHW, channels-last bytes
+
+    def forward(self, batched_inputs, merge_module=None, dual_teacher_instances=None, branch=None, step_two_data=None,
+                update_prototype=False):
+        if not self.training or branch == "test":
+            return self.inference(batched_inputs, branch=branch)
+        dev = self.pixel_mean.device
+        images = self.preprocess_image(batched_inputs)
+        with self._autocast():
+            features = self.backbone(images.tensor)
+            if branch == "pre_train":
+                rcnn = [x["RCNN"].to(dev) for x in batched_inputs]
+                rpn = [x["RPN"].to(dev) for x in batched_inputs]
+                merge_module = None
+            elif branch in ("step_one", "step_two"):
+                assert dual_teacher_instances is not None, "dual_teacher_instances must not be None when brach is step_one and step_two"
+                rcnn, rpn = dual_teacher_instances
+            else:
+                raise NotImplementedError
+            if self.proposal_generator is not None:
+                proposals, proposal_losses = self.proposal_generator(images, features, rpn, branch=branch)
+            else:
+                proposals, proposal_losses = [x["proposals"].to(dev) for x in batched_inputs], {}
+            _, detector_losses = self.roi_heads(images, features, proposals, self.backbone.layer4, self.backbone.attnpool, branch=branch,
+                                                merge_module=merge_module, targets=rcnn, update_prototype=update_prototype)
+        losses = {}
+        losses.update(detector_losses)
+        losses.update(proposal_losses)
+        return losses
+
+    @torch.no_grad()
+    def inference(self, batched_inputs, branch=None, detected_instances=None, do_postprocess=True):
+        assert (not self.training) or branch == "test"
+        images = self.preprocess_image(batched_inputs)
+        with self._autocast():
+            features = self.backbone(images.tensor)
+            if self.proposal_generator is not None:
+                proposals, _ = self.proposal_generator(images, features, None, branch)
+            else:
+                proposals = [x["proposals"].to(self.pixel_mean.device) for x in batched_inputs]
+            results, _ = self.roi_heads(images, features, proposals, self.backbone.layer4, self.backbone.attnpool, branch=branch, targets=None)
+        if not do_postprocess:
+            return results
+        out = []
+        for r, inp, size in zip(results, batched_inputs, images.image_sizes):
+            out.append({"instances": detector_postprocess(r, inp.get("height", size[0]), inp.get("width", size[1]))})
+        return out
+
+
+def build_model(cfg):
+    """coin/modeling/meta_arch/build.py:7-78 for the trainers of the hot path.  The cloud / CLIP collectors
+    (GroundingDINO, GLIP) are out of scope: their cached outputs are an input of this path."""
+    dev = torch.device(cfg.MODEL.DEVICE)
+    arch = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)
+    if cfg.CLOUD.Trainer in ("PRETRAIN", "ORACLE", "ModelZoo_test"):
+        return arch.from_config(cfg).to(dev)
+    if cfg.CLOUD.Trainer == "CoinTrainer":
+        return arch.from_config(cfg).to(dev), arch.from_config(cfg).to(dev)
+    raise NotImplementedError(f"CLOUD.Trainer={cfg.CLOUD.Trainer!r} is outside the adaptation-training hot path")

@@ -1,0 +1,164 @@
+"""OpenVocabularyRes5ROIHeads (registered under the reference's name) on the HIP RoIAlign.
+
+Mirrors coin/modeling/roi_heads/clip_roi_heads.py:90-399: proposal labelling / sampling into (fg, bg) or
+(A, B, bg), RoIAlign 14x14 on res4, ``backbone.layer4`` on the RoI tiles, mean pool, box predictor, and the
+extra pass over the raw private (C) boxes.  RoIAlign is ``coin_roi_align_fwd/bwd`` on channels-last
+activations; its output feeds the res5 convolutions without a layout change.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from .. import layers as L
+from ..box_ops import Matcher, add_ground_truth_to_proposals, subsample_labels
+from ..registry import ROI_HEADS_REGISTRY
+from ..structures import Boxes, Instances, ShapeSpec, pairwise_iou
+from .fast_rcnn import FastRCNNOutputLayers
+from .text_encoder import TEXT_DIMS, build_text_encoder
+
+
+class ROIPooler(nn.Module):
+    """Single-level detectron2 ROIPooler (ROIAlignV2 = aligned)."""
+
+    def __init__(self, output_size, scales, sampling_ratio, pooler_type="ROIAlignV2"):
+        super().__init__()
+        self.output_size = (output_size, output_size) if isinstance(output_size, int) else tuple(output_size)
+        assert len(scales) == 1 and pooler_type in ("ROIAlignV2", "ROIAlign")
+        self.scale, self.sampling_ratio, self.aligned = float(scales[0]), int(sampling_ratio), pooler_type == "ROIAlignV2"
+
+    def forward(self, x: List[torch.Tensor], box_lists: List[Boxes]) -> torch.Tensor:
+        rois = torch.cat([torch.cat([b.tensor.new_full((len(b), 1), float(i)), b.tensor], dim=1) for i, b in enumerate(box_lists)], dim=0)
+        return L.roi_align(x[0], rois, self.output_size, self.scale, self.sampling_ratio, self.aligned)
+
+
+@ROI_HEADS_REGISTRY.register()
+class OpenVocabularyRes5ROIHeads(nn.Module):
+    def __init__(self, *, in_features, pooler, box_predictor, pooling_type, num_classes, batch_size_per_image, positive_fraction,
+                 proposal_matcher, proposal_append_gt=True, BG_TRAIN=True, mask_head=None):
+        super().__init__()
+        assert mask_head is None, "MODEL.MASK_ON is False in every COIN config"
+        self.in_features, self.pooler, self.box_predictor, self.pooling_type = in_features, pooler, box_predictor, pooling_type
+        self.num_classes, self.batch_size_per_image, self.positive_fraction = num_classes, batch_size_per_image, positive_fraction
+        self.proposal_matcher, self.proposal_append_gt, self.BG_TRAIN = proposal_matcher, proposal_append_gt, BG_TRAIN
+        self.compute_dtype = torch.float32
+
+    @classmethod
+    def from_config(cls, cfg, input_shape, backgroud):
+        in_features = cfg.MODEL.ROI_HEADS.IN_FEATURES
+        assert not cfg.MODEL.KEYPOINT_ON and len(in_features) == 1
+        text_encoder = build_text_encoder(cfg, backgroud)
+        pooling_type = cfg.MODEL.ROI_HEADS.POOLING_TYPE
+        res5_ch = input_shape[in_features[0]].channels * 2
+        ch = res5_ch if pooling_type != "attnpool" else TEXT_DIMS[cfg.MODEL.TEACHER_OFFLINE.TYPE]
+        return cls(
+            in_features=in_features,
+            pooler=ROIPooler(cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION, (1.0 / input_shape[in_features[0]].stride,),
+                             cfg.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO, cfg.MODEL.ROI_BOX_HEAD.POOLER_TYPE),
+            box_predictor=FastRCNNOutputLayers.from_config(cfg, text_encoder, ShapeSpec(channels=ch, height=1, width=1)),
+            pooling_type=pooling_type,
+            num_classes=len(text_encoder.classes) - 1 if backgroud else len(text_encoder.classes),
+            batch_size_per_image=cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE, positive_fraction=cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION,
+            proposal_matcher=Matcher(cfg.MODEL.ROI_HEADS.IOU_THRESHOLDS, cfg.MODEL.ROI_HEADS.IOU_LABELS, allow_low_quality_matches=False),
+            proposal_append_gt=cfg.MODEL.ROI_HEADS.PROPOSAL_APPEND_GT, BG_TRAIN=cfg.CLOUD.BG_TRAIN)
+
+    def _shared_roi_transform(self, features, boxes, backbone_res5):
+        return backbone_res5(self.pooler(features, boxes))
+
+    def _pooled(self, features, boxes, res5, attnpool):
+        x = self._shared_roi_transform([features[f] for f in self.in_features], boxes, res5)
+        if self.pooling_type == "meanpool":
+            return x.mean(dim=[2, 3]).to(self.compute_dtype)
+        if self.pooling_type == "attnpool":
+            return attnpool(x).to(self.compute_dtype)
+        raise NotImplementedError
+
+    def forward(self, images, features, proposals, res5, attnpool, branch, merge_module=None, targets=None, update_prototype=False):
+        train = self.training and branch != "test"
+        if train:
+            assert targets
+            if branch == "pre_train":
+                proposals = self.label_and_sample_proposals(proposals, targets, branch=branch)
+                boxes = [Boxes.cat([p[0].proposal_boxes, p[1].proposal_boxes]) for p in proposals]
+            elif branch in ("step_one", "step_two"):
+                ta, tb, tc = [t[0] for t in targets], [t[1] for t in targets], [t[2] for t in targets]
+                proposals = self.label_and_sample_proposals(proposals, [ta, tb, tc], branch=branch)
+                boxes = [Boxes.cat([p[0].proposal_boxes, p[1].proposal_boxes, p[2].proposal_boxes]) for p in proposals]
+            else:
+                raise NotImplementedError
+        else:
+            boxes = [p.proposal_boxes for p in proposals]
+        predictions = self.box_predictor(self._pooled(features, boxes, res5, attnpool), branch=branch)
+        if not train:
+            pred_instances, _ = self.box_predictor.inference(predictions, proposals)
+            return pred_instances, {}
+        if branch != "pre_train":
+            if sum(len(c) for c in tc) != 0:
+                cpred = self.box_predictor(self._pooled(features, [c.gt_boxes for c in tc], res5, attnpool), branch=branch, return_feats=False)
+                predictions, proposals = (predictions, cpred), (proposals, tc)
+            else:
+                predictions, proposals = (predictions, ((None, None), None)), (proposals, None)
+        return [], self.box_predictor.losses(predictions, proposals, merge_module, branch=branch, update_prototype=update_prototype)
+
+    def _sample_proposals(self, matched_idxs, matched_labels, gt_classes):
+        if gt_classes.numel() > 0:
+            gt_classes = gt_classes[matched_idxs]
+            gt_classes[matched_labels == 0] = self.num_classes
+            gt_classes[matched_labels == -1] = -1
+        else:
+            gt_classes = torch.zeros_like(matched_idxs) + self.num_classes
+        fg, bg = subsample_labels(gt_classes, self.batch_size_per_image, self.positive_fraction, self.num_classes)
+        sampled = torch.cat([fg, bg], dim=0)
+        return sampled, gt_classes[sampled]
+
+    @torch.no_grad()
+    def label_and_sample_proposals(self, proposals, targets, branch):
+        """clip_roi_heads.py:282-399 (the `no_thresh_boxes` variant is never produced by the trainers, base.py:119-121)."""
+        out = []
+        if branch == "pre_train":
+            if self.proposal_append_gt:
+                proposals = add_ground_truth_to_proposals(targets, proposals)
+            for p, t in zip(proposals, targets):
+                idx, lab = self.proposal_matcher(pairwise_iou(t.gt_boxes, p.proposal_boxes))
+                sampled, cls = self._sample_proposals(idx, lab, t.gt_classes_offline)
+                idx = idx[sampled]
+                is_bg = cls == self.num_classes
+                fg, bg = p[sampled[~is_bg]], p[sampled[is_bg]]
+                bg.gt_classes = cls[is_bg]
+                for name, val in t.get_fields().items():
+                    if name.startswith("gt_") and not fg.has(name):
+                        fg.set(name, val[idx[~is_bg]])
+                out.append((fg, bg))
+            return out
+        ta, tb, tc = targets
+        if self.proposal_append_gt:
+            proposals = add_ground_truth_to_proposals(ta, proposals)
+            proposals = add_ground_truth_to_proposals(tb, proposals)
+        for p, a, b, c in zip(proposals, ta, tb, tc):
+            la, lb, lc = len(a), len(b), len(c)
+            idx, lab = self.proposal_matcher(pairwise_iou(Boxes.cat([a.gt_boxes, b.gt_boxes, c.gt_boxes]), p.proposal_boxes))
+            in_c = (idx >= la + lb) & (idx < la + lb + lc)
+            lab[in_c & (lab != 0)] = -1
+            sampled, cls = self._sample_proposals(idx, lab, torch.cat([a.gt_classes, b.gt_classes_online, c.gt_classes]))
+            idx = idx[sampled]
+            is_bg = cls == self.num_classes
+            m_a = (idx >= 0) & (idx < la) & ~is_bg
+            m_b = (idx >= la) & (idx < la + lb) & ~is_bg
+            pa, pb, pg = p[sampled[m_a]], p[sampled[m_b]], p[sampled[is_bg]]
+            pg.gt_classes = cls[is_bg]
+            if not self.BG_TRAIN:
+                pg = pg[0:0]
+            for name, val in a.get_fields().items():
+                if name.startswith("gt_") and not pa.has(name):
+                    pa.set(name, val[idx[m_a]])
+            for name, val in b.get_fields().items():
+                if name.startswith("gt_") and not pb.has(name):
+                    pb.set(name, val[idx[m_b] - la])
+            out.append((pa, pb, pg))
+        return out
+
+
+def build_roi_heads(cfg, input_shape, backgroud=False, name=None):
+    return ROI_HEADS_REGISTRY.get(name or cfg.MODEL.ROI_HEADS.NAME).from_config(cfg, input_shape, backgroud)

@@ -1,0 +1,216 @@
+"""DualTeacherRPN on the device (registered under the reference's name).
+
+Mirrors coin/modeling/proposal_generator/rpn.py:16-345 on top of a restated detectron2 RPN
+(StandardRPNHead, DefaultAnchorGenerator, Matcher, find_top_rpn_proposals).  The 3x3 / 1x1 head
+convolutions go through torch (MIOpen); the BCE + L1 losses over all N x 62 250 anchors and their
+gradients are ONE fused HIP launch (``coin_rpn_losses_fwd_bwd``), the objectness distillation KL another
+(``coin_kl_div_fwd_bwd`` mode 2), proposal NMS is ``coin_nms_batched``.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import layers as L
+from ..box_ops import Box2BoxTransform, Matcher, cell_anchors, find_top_rpn_proposals, grid_anchors, subsample_labels
+from ..registry import PROPOSAL_GENERATOR_REGISTRY
+from ..structures import Boxes, ImageList, Instances, pairwise_iou
+
+
+class StandardRPNHead(nn.Module):
+    def __init__(self, in_channels: int, num_anchors: int, box_dim: int = 4):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, in_channels, 3, stride=1, padding=1)
+        self.objectness_logits = nn.Conv2d(in_channels, num_anchors, 1)
+        self.anchor_deltas = nn.Conv2d(in_channels, num_anchors * box_dim, 1)
+        for l in (self.conv, self.objectness_logits, self.anchor_deltas):
+            nn.init.normal_(l.weight, std=0.01)
+            nn.init.constant_(l.bias, 0)
+
+    def forward(self, features: List[torch.Tensor]):
+        lg, dl = [], []
+        for x in features:
+            t = F.relu(self.conv(x))
+            lg.append(self.objectness_logits(t))
+            dl.append(self.anchor_deltas(t))
+        return lg, dl
+
+
+class DefaultAnchorGenerator(nn.Module):
+    box_dim = 4
+
+    def __init__(self, sizes, aspect_ratios, strides, offset: float = 0.0):
+        super().__init__()
+        self.strides, self.offset = list(strides), offset
+        self.register_buffer("cell_anchors_0", cell_anchors(sizes[0], aspect_ratios[0]), persistent=False)
+        self._cache: Dict[Tuple, torch.Tensor] = {}
+
+    @property
+    def num_anchors(self):
+        return [self.cell_anchors_0.shape[0]]
+
+    def forward(self, features: List[torch.Tensor]) -> List[Boxes]:
+        f = features[0]
+        key = (tuple(f.shape[-2:]), str(f.device))
+        if key not in self._cache:
+            self._cache[key] = grid_anchors(self.cell_anchors_0, f.shape[-2:], self.strides[0], self.offset, f.device)
+        return [Boxes(self._cache[key])]
+
+
+@PROPOSAL_GENERATOR_REGISTRY.register()
+class DualTeacherRPN(nn.Module):
+    def __init__(self, *, in_features, head, anchor_generator, anchor_matcher, box2box_transform, batch_size_per_image,
+                 positive_fraction, pre_nms_topk, post_nms_topk, nms_thresh=0.7, min_box_size=0.0, anchor_boundary_thresh=-1.0,
+                 loss_weight=None, BG_TRAIN=True):
+        super().__init__()
+        self.in_features, self.rpn_head, self.anchor_generator = in_features, head, anchor_generator
+        self.anchor_matcher, self.box2box_transform = anchor_matcher, box2box_transform
+        self.batch_size_per_image, self.positive_fraction = batch_size_per_image, positive_fraction
+        self.pre_nms_topk = {True: pre_nms_topk[0], False: pre_nms_topk[1]}
+        self.post_nms_topk = {True: post_nms_topk[0], False: post_nms_topk[1]}
+        self.nms_thresh, self.min_box_size, self.anchor_boundary_thresh = nms_thresh, float(min_box_size), anchor_boundary_thresh
+        self.loss_weight = loss_weight or {"loss_rpn_cls": 1.0, "loss_rpn_loc": 1.0, "loss_rpn_distillation": 0.1}
+        self.BG_TRAIN = BG_TRAIN
+
+    @classmethod
+    def from_config(cls, cfg, input_shape):
+        in_features = cfg.MODEL.RPN.IN_FEATURES
+        ch = input_shape[in_features[0]].channels
+        ag = DefaultAnchorGenerator(cfg.MODEL.ANCHOR_GENERATOR.SIZES, cfg.MODEL.ANCHOR_GENERATOR.ASPECT_RATIOS,
+                                    [input_shape[f].stride for f in in_features], cfg.MODEL.ANCHOR_GENERATOR.OFFSET)
+        assert tuple(cfg.MODEL.RPN.BBOX_REG_WEIGHTS) == (1.0, 1.0, 1.0, 1.0), "the fused RPN loss kernel uses unit box weights"
+        return cls(
+            in_features=in_features, head=StandardRPNHead(ch, ag.num_anchors[0]), anchor_generator=ag,
+            anchor_matcher=Matcher(cfg.MODEL.RPN.IOU_THRESHOLDS, cfg.MODEL.RPN.IOU_LABELS, allow_low_quality_matches=True),
+            box2box_transform=Box2BoxTransform(cfg.MODEL.RPN.BBOX_REG_WEIGHTS), batch_size_per_image=cfg.MODEL.RPN.BATCH_SIZE_PER_IMAGE,
+            positive_fraction=cfg.MODEL.RPN.POSITIVE_FRACTION,
+            pre_nms_topk=(cfg.MODEL.RPN.PRE_NMS_TOPK_TRAIN, cfg.MODEL.RPN.PRE_NMS_TOPK_TEST),
+            post_nms_topk=(cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN, cfg.MODEL.RPN.POST_NMS_TOPK_TEST),
+            nms_thresh=cfg.MODEL.RPN.NMS_THRESH, min_box_size=cfg.MODEL.PROPOSAL_GENERATOR.MIN_SIZE,
+            anchor_boundary_thresh=cfg.MODEL.RPN.BOUNDARY_THRESH,
+            loss_weight={"loss_rpn_cls": cfg.MODEL.RPN.LOSS_WEIGHT,
+                         "loss_rpn_loc": cfg.MODEL.RPN.BBOX_REG_LOSS_WEIGHT * cfg.MODEL.RPN.LOSS_WEIGHT,
+                         "loss_rpn_distillation": cfg.CLOUD.LOSS_DISTILLATION_WEIGHT},
+            BG_TRAIN=cfg.CLOUD.BG_TRAIN)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, images: ImageList, features: Dict[str, torch.Tensor], gt_instances=None, branch=None):
+        feats = [features[f] for f in self.in_features]
+        anchors = self.anchor_generator(feats)
+        lg, dl = self.rpn_head(feats)
+        # (N, A, H, W) -> (N, H*W*A) ; (N, A*4, H, W) -> (N, H*W*A, 4).  With channels-last activations both are views.
+        logits = [s.permute(0, 2, 3, 1).flatten(1) for s in lg]
+        deltas = [x.view(x.shape[0], -1, 4, x.shape[-2], x.shape[-1]).permute(0, 3, 4, 1, 2).flatten(1, -2) for x in dl]
+        losses = {}
+        if self.training and branch != "test":
+            assert gt_instances is not None, "RPN requires gt_instances in training!"
+            if branch == "pre_train":
+                labels, gt_boxes = self.label_and_sample_anchors(anchors, gt_instances, branch)
+                losses = self.losses(anchors, logits, labels, deltas, gt_boxes)
+            elif branch in ("step_one", "step_two"):
+                ia, ic = [g[0] for g in gt_instances], [g[2] for g in gt_instances]
+                labels, gt_boxes, midx, dlabels = self.label_and_sample_anchors(anchors, [ia, ic], branch)
+                teacher = [c.gt_probs[:, :-1].sum(1)[m] if len(c) != 0 else torch.zeros_like(m, dtype=torch.float32)
+                           for c, m in zip(ic, midx)]
+                losses = self.losses(anchors, logits, labels, deltas, gt_boxes, calc_bg=self.BG_TRAIN)
+                losses.update(self.losses(anchors, logits, dlabels, None, None, teacher_probs=teacher, only_distillation=True))
+            else:
+                raise NotImplementedError
+        proposals = self.predict_proposals(anchors, logits, deltas, images.image_sizes)
+        return proposals, losses
+
+    # ------------------------------------------------------------------ labels
+    def _subsample_labels(self, label: torch.Tensor) -> torch.Tensor:
+        pos, neg = subsample_labels(label, self.batch_size_per_image, self.positive_fraction, 0)
+        label.fill_(-1)
+        label.scatter_(0, pos, 1)
+        label.scatter_(0, neg, 0)
+        return label
+
+    @torch.no_grad()
+    def label_and_sample_anchors(self, anchors: List[Boxes], gt_instances, branch):
+        anchors = Boxes.cat(anchors)
+        labels_out, boxes_out = [], []
+        if branch == "pre_train":
+            for g in gt_instances:
+                gb = g.gt_boxes
+                idx, lab = self.anchor_matcher(pairwise_iou(gb, anchors))
+                lab = self._subsample_labels(lab)
+                if len(gb) == 0:
+                    mb = torch.zeros_like(anchors.tensor)
+                    lab[:] = -1
+                else:
+                    mb = gb.tensor[idx]
+                labels_out.append(lab)
+                boxes_out.append(mb)
+            return labels_out, boxes_out
+        ga, gc = gt_instances
+        midx_out, dist_out = [], []
+        for a, c in zip(ga, gc):
+            ba, bc = a.gt_boxes, c.gt_boxes
+            both = Boxes.cat([ba, bc])
+            idx, lab = self.anchor_matcher(pairwise_iou(both, anchors))
+            in_c = (idx >= len(ba)) & (idx < len(both))
+            is_bg = lab == 0
+            fg_c = in_c & ~is_bg
+            didx = idx - len(ba)
+            didx[~fg_c] = 0
+            lab[fg_c] = -1
+            idx = idx.clone()
+            idx[in_c] = 0
+            dlab = torch.zeros_like(lab)
+            dlab[fg_c] = 1
+            lab = self._subsample_labels(lab)
+            if len(ba) == 0:
+                mb = torch.zeros_like(anchors.tensor)
+                lab[~(in_c & is_bg)] = -1
+            else:
+                mb = ba.tensor[idx]
+            labels_out.append(lab)
+            boxes_out.append(mb)
+            midx_out.append(didx)
+            dist_out.append(dlab)
+        return labels_out, boxes_out, midx_out, dist_out
+
+    # ------------------------------------------------------------------ losses
+    def losses(self, anchors, logits, gt_labels, deltas, gt_boxes, teacher_probs=None, only_distillation=False, calc_bg=True):
+        num_images = len(gt_labels)
+        labels = torch.stack(gt_labels)
+        lg = logits[0] if len(logits) == 1 else torch.cat(logits, dim=1)
+        if not only_distillation:
+            a = Boxes.cat(anchors).tensor
+            dl = deltas[0] if len(deltas) == 1 else torch.cat(deltas, dim=1)
+            cls_sum, loc_sum = L.rpn_losses(lg, dl, labels, a, torch.stack(gt_boxes), min_label=0 if calc_bg else 1)
+            normalizer = self.batch_size_per_image * num_images
+            if calc_bg:
+                cls = cls_sum / normalizer
+            else:
+                cls = cls_sum / (labels >= 1).sum().clamp(min=1).float()
+            out = {"loss_rpn_cls": cls, "loss_rpn_loc": loc_sum / normalizer}
+        else:
+            assert teacher_probs is not None, "distillation need teacher probs"
+            valid = labels > 0
+            out = {}
+            if bool(valid.any()):  # rpn.py:336-340: the term is dropped when no anchor matches a private box
+                out["loss_rpn_distillation"] = L.kl_div_binary(lg.reshape(-1), torch.stack(teacher_probs).reshape(-1), valid.reshape(-1))
+        return {k: v * self.loss_weight.get(k, 1.0) for k, v in out.items()}
+
+    # ------------------------------------------------------------------ proposals
+    @torch.no_grad()
+    def predict_proposals(self, anchors, logits, deltas, image_sizes):
+        n = deltas[0].shape[0]
+        a = anchors[0].tensor
+        d = deltas[0].detach().reshape(-1, 4)
+        boxes = self.box2box_transform.apply_deltas(d, a.unsqueeze(0).expand(n, -1, -1).reshape(-1, 4)).view(n, -1, 4)
+        return find_top_rpn_proposals(boxes, logits[0].detach(), image_sizes, self.nms_thresh, self.pre_nms_topk[self.training],
+                                      self.post_nms_topk[self.training], self.min_box_size, self.training)
+
+
+def build_proposal_generator(cfg, input_shape):
+    name = cfg.MODEL.PROPOSAL_GENERATOR.NAME
+    if name == "PrecomputedProposals":
+        return None
+    return PROPOSAL_GENERATOR_REGISTRY.get(name).from_config(cfg, input_shape)

@@ -162,6 +162,7 @@ int coin_l1_mean_fwd_bwd(const float* a, const float* b, int64_t n, float* loss,
 /* RPN objectness BCE-with-logits, sum over anchors with labels >= min_label, and the anchor
  * L1 localisation loss over labels == 1 (DualTeacherRPN.losses, rpn.py:300-324):
  *   loss_cls = sum_{label>=min_label} bce(logit, label) ; loss_loc = sum_{label==1} |d - get_deltas(anchor, gt)|_1
+ * Box2BoxTransform weights (1,1,1,1) (detectron2 MODEL.RPN.BBOX_REG_WEIGHTS default).
  * logits [A_total] float32, labels [A_total] int8 (-1 ignore, 0 neg, 1 pos), deltas [A_total,4],
  * anchors [A_per_image,4] (broadcast over images), matched_gt [A_total,4].
  * Outputs are SUMS (caller divides by batch_size_per_image * num_images).
@@ -172,9 +173,25 @@ int coin_rpn_losses_fwd_bwd(const float* logits, const int8_t* labels, const flo
                             float* grad_logits, float* grad_deltas, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Batched greedy NMS  (replaces torchvision.ops.nms / batched_nms under detectron2
+ *                      find_top_rpn_proposals, coin/modeling/proposal_generator/rpn.py:113-115, and
+ *                      fast_rcnn_inference_single_image, coin/modeling/roi_heads/fast_rcnn.py:164)
+ * boxes   : [B, n_max, 4] float32 xyxy, each image's first counts[b] rows sorted by DESCENDING score
+ * counts  : [B] int32 (device)
+ * keep    : [B, n_max] int32: the first num_keep[b] entries are the surviving row indices, in score
+ *           order, truncated to max_keep;  num_keep: [B] int32.
+ * A box is suppressed when IoU > iou_threshold with an earlier surviving box.
+ * workspace: coin_nms_workspace_bytes(B, n_max) bytes of device memory (contents undefined).
+ * n_max <= 16384.  Everything stays on the device (no host round trip).
+ * ---------------------------------------------------------------------------------------- */
+size_t coin_nms_workspace_bytes(int B, int n_max);
+int coin_nms_batched(const float* boxes, const int* counts, int B, int n_max, float iou_threshold,
+                     int max_keep, void* workspace, int* keep, int* num_keep, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Input normalisation  (replaces OpenVocabularyRCNN.preprocess_image, clip_rcnn.py:287-298:
  *                       ToTensor + Normalize + ImageList.from_tensors zero padding)
- * img   : [3,h,w] uint8 (CHW, as the dataset mapper emits)
+ * img   : [3,h,w] uint8 (CHW, as the dataset mapper emits); mean/std_ are HOST arrays of 3 floats
  * out   : image `n` of a batch [Nb,3,Hp,Wp] (COIN_NCHW) or [Nb,Hp,Wp,3] (COIN_NHWC), dtype
  *         `dtype`; pixels outside h x w are written as 0.
  * ---------------------------------------------------------------------------------------- */

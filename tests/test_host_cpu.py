@@ -1,0 +1,211 @@
+"""Host logic of the product (coin_amd.modeling / engine / solver / config) on CPU.
+
+The HIP kernels are replaced by oracle functions through tests/cpu_shim.py (TEST-ONLY monkey patch), so
+what is checked here is everything around them: state-dict compatibility with the reference's keys, anchor
+labelling and RoI sampling (same RNG stream as the reference), row bookkeeping of the losses, target
+preparation, parameter groups and schedule - against the golden vectors captured from the reference.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cpu_shim import cpu_kernels
+from golden_util import GOLDEN, K, LOSS_W, T, close, load, load_weights
+
+torch.set_num_threads(4)
+
+
+def _inst(z, prefix, size):
+    from coin_amd.structures import Boxes, Instances
+
+    inst = Instances(tuple(size))
+    for k in z.files:
+        if k.startswith(prefix + "."):
+            name = k[len(prefix) + 1:]
+            if "." in name:
+                continue
+            v = T(z[k])
+            inst.set(name, Boxes(v) if name.endswith("boxes") else v, check_len=False)
+    return inst
+
+
+def tiny_product_detector():
+    from coin_amd.box_ops import Box2BoxTransform, Matcher
+    from coin_amd.modeling.backbone import CLIP_IMAGE
+    from coin_amd.modeling.fast_rcnn import FastRCNNOutputLayers
+    from coin_amd.modeling.meta_arch import OpenVocabularyRCNN
+    from coin_amd.modeling.roi_heads import OpenVocabularyRes5ROIHeads, ROIPooler
+    from coin_amd.modeling.rpn import DefaultAnchorGenerator, DualTeacherRPN, StandardRPNHead
+    from coin_amd.modeling.text_encoder import CLIP_TEXT, prompt_tokens
+    from coin_amd.structures import ShapeSpec
+
+    toks = torch.zeros(K + 1, 16, dtype=torch.int)
+    for i in range(K + 1):
+        seq = [62, 1, 2, 3, 1, 6, 6, 6, 6, 10 + i, 5, 63]
+        toks[i, : len(seq)] = torch.tensor(seq)
+    te = CLIP_TEXT("RN50", ["car", "person", "bus", "backgroud"], embed_dim=32, context_length=16, vocab_size=64, width=32, heads=2,
+                   layers=2, tokenized_prompts=toks, n_templates=2)
+    bp = FastRCNNOutputLayers(ShapeSpec(channels=256, height=1, width=1), text_encoder=te, pooling_type="meanpool",
+                              box2box_transform=Box2BoxTransform((10.0, 10.0, 5.0, 5.0)), text_dim=32, classes_weight=[1.0] * K + [0.9],
+                              loss_type="MILCrossEntropy", test_score_thresh=0.05, test_nms_thresh=0.5, test_topk_per_image=100,
+                              cls_agnostic_bbox_reg=True, loss_weight=LOSS_W, batch_size_per_image=32, cls_b_thresh=0.3,
+                              dataset=("foggytrain_0.02",), prototype_update_rate=0.9996)
+    rh = OpenVocabularyRes5ROIHeads(in_features=["res4"], pooler=ROIPooler(14, (1.0 / 16,), 0, "ROIAlignV2"), box_predictor=bp,
+                                    pooling_type="meanpool", num_classes=K, batch_size_per_image=32, positive_fraction=0.25,
+                                    proposal_matcher=Matcher([0.5], [0, 1], False))
+    ag = DefaultAnchorGenerator([[32, 64, 128]], [[0.5, 1.0, 2.0]], [16])
+    pg = DualTeacherRPN(in_features=["res4"], head=StandardRPNHead(128, 9), anchor_generator=ag,
+                        anchor_matcher=Matcher([0.3, 0.7], [0, -1, 1], True), box2box_transform=Box2BoxTransform((1.0, 1.0, 1.0, 1.0)),
+                        batch_size_per_image=64, positive_fraction=0.5, pre_nms_topk=(200, 120), post_nms_topk=(60, 40))
+    bb = CLIP_IMAGE("RN50", freeze_at=2, layers=(1, 1, 2, 2), width=8)
+    return OpenVocabularyRCNN(backbone=bb, proposal_generator=pg, roi_heads=rh, pixel_mean=[0.48145466, 0.4578275, 0.40821073],
+                              pixel_std=[0.26862954, 0.26130258, 0.27577711], device="cpu", compute_dtype=torch.float32)
+
+
+def test_state_dict_keys_match_the_reference():
+    z = load("e2e_pretrain")
+    model = tiny_product_detector()
+    ref_keys = {k[3:] for k in z.files if k.startswith("w::")}
+    assert set(model.state_dict().keys()) == ref_keys
+    for k, v in model.state_dict().items():
+        assert tuple(v.shape) == tuple(z["w::" + k].shape), k
+
+
+def test_e2e_pretrain_host_logic_vs_golden():
+    z = load("e2e_pretrain")
+    with cpu_kernels():
+        model = tiny_product_detector()
+        load_weights(model, z)
+        model.train()
+        batch = []
+        for i in range(2):
+            img = T(z[f"img{i}"])
+            size = (img.shape[1], img.shape[2])
+            batch.append({"image": img, "height": size[0], "width": size[1], "RCNN": _inst(z, f"rcnn{i}", size), "RPN": _inst(z, f"rpn{i}", size)})
+        torch.manual_seed(123)
+        losses = model(batch, branch="pre_train", update_prototype=True)
+        ref = {k[6:]: float(z[k]) for k in z.files if k.startswith("loss::")}
+        assert set(losses) == set(ref)
+        for k, v in ref.items():
+            assert abs(float(losses[k]) - v) < 1e-4, (k, float(losses[k]), v)
+        sum(losses.values()).backward()
+        params = dict(model.named_parameters())
+        for k in z.files:
+            if k.startswith("g::"):
+                close(params[k[3:]].grad, z[k], 1e-4, k)
+        close(model.roi_heads.box_predictor.text_encoder.per_class_feat, z["prototype_after"], 1e-6)
+        close(model.backbone.layer4[0].bn1.running_mean, z["after::layer4.0.bn1.running_mean"], 1e-6)
+
+
+def test_e2e_step_two_host_logic_vs_golden():
+    from coin_amd.modeling.text_encoder import CKGNet
+
+    z = load("e2e_step_two")
+    with cpu_kernels():
+        model = tiny_product_detector()
+        load_weights(model, z)
+        model.train()
+        merge = CKGNet(32, 32, K + 1, head_num=4)
+        load_weights(merge, z, "m::")
+        batch, rc, rp = [], [], []
+        for i in range(2):
+            img = T(z[f"img{i}"])
+            size = (img.shape[1], img.shape[2])
+            batch.append({"image": img, "height": size[0], "width": size[1]})
+            rc.append((_inst(z, f"a{i}", size), _inst(z, f"b{i}", size), _inst(z, f"c{i}", size)))
+            rp.append((_inst(z, f"rpn_a{i}", size), None, _inst(z, f"rpn_c{i}", size)))
+        torch.manual_seed(135)
+        losses = model(batch, merge, (rc, rp), branch="step_two", update_prototype=True)
+        ref = {k[6:]: float(z[k]) for k in z.files if k.startswith("loss::")}
+        assert set(losses) == set(ref)
+        for k, v in ref.items():
+            assert abs(float(losses[k]) - v) < 1e-4, (k, float(losses[k]), v)
+        skip = ["loss_merge_grad", "loss_merge_a", "loss_merge_b", "loss_merge_base"]
+        sum(v for k, v in losses.items() if k not in skip).backward()
+        params = dict(model.named_parameters())
+        for k in z.files:
+            if k.startswith("g::"):
+                close(params[k[3:]].grad, z[k], 1e-4, k)
+
+
+def test_inference_host_logic_vs_golden():
+    z = load("inference")
+    with cpu_kernels():
+        model = tiny_product_detector()
+        load_weights(model, z)
+        model.eval()
+        batch = [{"image": T(z[f"img{i}"]), "height": int(z[f"hw{i}"][0]), "width": int(z[f"hw{i}"][1])} for i in range(2)]
+        res = model(batch, branch="test")
+    for i, r in enumerate(res):
+        inst = r["instances"]
+        assert len(inst) == z[f"det{i}.scores"].shape[0]
+        close(torch.sort(inst.scores, descending=True).values, np.sort(z[f"det{i}.scores"])[::-1].copy(), 1e-5)
+        assert sorted(inst.pred_classes.tolist()) == sorted(z[f"det{i}.pred_classes"].tolist())
+
+
+def test_param_groups_and_schedule_match_reference():
+    from coin_amd.solver import FusedSGD, WarmupTwoStageMultiStepLR, get_default_optimizer_params
+
+    rows = json.load(open(os.path.join(GOLDEN, "optimizer_groups.json")))
+    model = tiny_product_detector()
+    overrides = [{"backbone.encoder.visual": 0.1, "backbone.encoder.visual.layer4": 0.1, "backbone.encoder.attnpool": 0.1,
+                  "embedding_tmp": 1.0, "add_in_embedding": 1.0, "logit_scale": 0.0, "anchor_generator": 1.0}]
+    groups = get_default_optimizer_params(model, 0.001, weight_decay_norm=0.0, bias_lr_factor=1.0, weight_decay_bias=1e-4, overrides=overrides)
+    assert [g["name"] for g in groups] == [r["name"] for r in rows]
+    for g, r in zip(groups, rows):
+        assert abs(g["lr"] - r["lr"]) < 1e-12 and g.get("weight_decay") == r["weight_decay"], g["name"]
+    z = load("lr_fusion_process")
+    p = [torch.nn.Parameter(torch.zeros(1)), torch.nn.Parameter(torch.zeros(1))]
+    for name, steps, factors in (("lr_pretrain", (40,), (1, 0.1)), ("lr_final", (40, 45, 60), (1, 0.1, 0.5, 0.1))):
+        opt = FusedSGD([{"params": [p[0]], "lr": 0.001}, {"params": [p[1]], "lr": 0.0001}], lr=0.001)
+        s = WarmupTwoStageMultiStepLR(opt, list(steps), factor_list=list(factors), warmup_factor=0.001, warmup_iters=8)
+        for it in range(z[name].shape[0]):
+            assert np.allclose([g["lr"] for g in opt.param_groups], z[name][it], rtol=1e-12, atol=0)
+            s.step()
+
+
+def test_trainer_target_preparation_matches_reference():
+    from coin_amd.engine import BASE_Trainer
+    from coin_amd.structures import Boxes, Instances
+
+    z = load("lr_fusion_process")
+    tr = BASE_Trainer()
+    for flip in ("no", "horizontal", "vertical"):
+        inst = Instances((200, 300))
+        inst.pred_boxes = Boxes(T(z["box_a"]).clone())
+        inst.scores = T(z["proc_scores"]).clone()
+        inst.pred_classes = torch.arange(6) % 3
+        inst.probs = torch.rand(6, 4)
+        out = tr.process(inst, (200, 300), (160, 270), flip)
+        close(out.gt_boxes.tensor, z["proc_" + flip], 1e-6)
+        assert out.has("gt_classes") and not out.has("pred_classes") and out.image_size == (160, 270)
+        out_t = tr.process(inst, (200, 300), (160, 270), flip, thresh=0.5)
+        close(out_t.gt_boxes.tensor, z["proc_thresh_" + flip], 1e-6)
+
+
+def test_pretrainer_run_step_on_cpu_with_shimmed_kernels():
+    """Whole PRETrainer.run_step (synthetic loader, set_boxes, forward, backward, fused-SGD table, scheduler)."""
+    from coin_amd.config import get_cfg
+    from coin_amd.engine import PRETrainer
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(os.path.dirname(GOLDEN), "..", "configs", "coin", "PRETRAINS", "CLIPDET_synthetic.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu", "AMD.COMPUTE_DTYPE", "fp32", "AMD.SYNTHETIC.HEIGHT", 96, "AMD.SYNTHETIC.WIDTH", 128,
+                         "AMD.SYNTHETIC.BOXES_PER_IMAGE", 4, "SOLVER.IMG_PER_BATCH_UNLABEL", 1, "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 16,
+                         "MODEL.RPN.PRE_NMS_TOPK_TRAIN", 100, "MODEL.RPN.POST_NMS_TOPK_TRAIN", 30, "AMD.TEXT_TEMPLATES", 1,
+                         "AMD.ARCH.LAYERS", [1, 1, 1, 1], "AMD.ARCH.WIDTH", 8, "AMD.ARCH.TEXT_WIDTH", 32, "AMD.ARCH.TEXT_LAYERS", 2,
+                         "AMD.ARCH.TEXT_HEADS", 2, "AMD.ARCH.TEXT_DIM", 32, "AMD.ARCH.CONTEXT_LENGTH", 16, "AMD.ARCH.VOCAB_SIZE", 64])
+    with cpu_kernels():
+        torch.manual_seed(0)
+        tr = PRETrainer(cfg)
+        before = [p.detach().clone() for p in tr.optimizer.params]
+        rec1 = tr.run_step()
+        rec2 = tr.run_step()
+    assert set(rec1) == {"loss_text_align", "loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc"}
+    assert all(torch.isfinite(v) for v in rec1.values()) and all(torch.isfinite(v) for v in rec2.values())
+    changed = sum(int(not torch.equal(a, b)) for a, b in zip(before, tr.optimizer.params))
+    assert changed > 0.5 * len(before)  # zero-init bn3.weight (CLIP init) leaves the inner BN affine params of each block without gradient at step 0
+    assert tr.iter == 2 and tr.scheduler.last_epoch == 2
