@@ -45,6 +45,44 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ---- optional per-entry-point device timing (HIP events on the launch stream); used by bench.py's roofline line
+_TIMING = None
+
+
+def timing_begin(names: Sequence[str]) -> None:
+    global _TIMING
+    _TIMING = {n: [] for n in names}
+
+
+def timing_end() -> dict:
+    """-> {name: (launches, mean_ms, algorithmic_bytes_per_launch)}; call after a device synchronize."""
+    global _TIMING
+    out = {}
+    for n, evs in (_TIMING or {}).items():
+        if evs:
+            ms = [s.elapsed_time(e) for s, e, _ in evs]
+            out[n] = (len(ms), sum(ms) / len(ms), sum(b for _, _, b in evs) / len(evs))
+    _TIMING = None
+    return out
+
+
+class _timed:
+    def __init__(self, name: str, alg_bytes: int = 0):
+        self.on = _TIMING is not None and name in _TIMING
+        self.name, self.bytes = name, alg_bytes
+
+    def __enter__(self):
+        if self.on:
+            self.s, self.e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.s.record(torch.cuda.current_stream())
+
+    def __exit__(self, *a):
+        if self.on:
+            self.e.record(torch.cuda.current_stream())
+            _TIMING[self.name].append((self.s, self.e, self.bytes))
+        return False
+
+
 def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
     if t.dtype != torch.float32 or not t.is_contiguous():
         raise CoinHipError(f"{name} must be contiguous float32")
@@ -72,9 +110,11 @@ def roi_align_fwd(feat: torch.Tensor, rois: torch.Tensor, output_size: Tuple[int
     r = rois.shape[0]
     shape = (r, c, ph, pw) if layout == COIN_NCHW else (r, ph, pw, c)
     out = torch.empty(shape, dtype=feat.dtype, device=feat.device)
-    check(_lib.lib().coin_roi_align_fwd(_p(feat), n, c, h, w, layout, _p(rois), r, ph, pw, float(spatial_scale),
-                                        int(sampling_ratio), int(aligned), _p(out), _dt(feat), _stream()),
-          "coin_roi_align_fwd")
+    # algorithmic bytes: read the map once + rois + write the pooled tiles
+    with _timed("coin_roi_align_fwd", feat.numel() * feat.element_size() + rois.numel() * 4 + out.numel() * out.element_size()):
+        check(_lib.lib().coin_roi_align_fwd(_p(feat), n, c, h, w, layout, _p(rois), r, ph, pw, float(spatial_scale),
+                                            int(sampling_ratio), int(aligned), _p(out), _dt(feat), _stream()),
+              "coin_roi_align_fwd")
     return out
 
 
@@ -97,9 +137,10 @@ def roi_align_bwd(grad_out: torch.Tensor, rois: torch.Tensor, feat_shape: Sequen
         n, h, w, c = feat_shape
         ph, pw = grad_out.shape[1:3]
     r = rois.shape[0]
-    check(_lib.lib().coin_roi_align_bwd(_p(grad_out), n, c, h, w, layout, _p(rois), r, ph, pw, float(spatial_scale),
-                                        int(sampling_ratio), int(aligned), _p(grad_feat), _dt(grad_out), _stream()),
-          "coin_roi_align_bwd")
+    with _timed("coin_roi_align_bwd", grad_out.numel() * grad_out.element_size() + rois.numel() * 4 + grad_feat.numel() * 4):
+        check(_lib.lib().coin_roi_align_bwd(_p(grad_out), n, c, h, w, layout, _p(rois), r, ph, pw, float(spatial_scale),
+                                            int(sampling_ratio), int(aligned), _p(grad_feat), _dt(grad_out), _stream()),
+              "coin_roi_align_bwd")
     return grad_feat
 
 
@@ -122,8 +163,9 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
         raise CoinHipError("gemm_nt: bad `out`")
     if bias is not None:
         _f32c(bias, "bias")
-    check(_lib.lib().coin_gemm_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), m, n, k, _p(bias),
-                                  act, float(act_alpha), _dt(a), _dt(out), _stream()), "coin_gemm_nt")
+    with _timed("coin_gemm_nt", 2 * m * n * k):  # "bytes" slot carries FLOPs for the MFMA-bound entry point
+        check(_lib.lib().coin_gemm_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), m, n, k, _p(bias),
+                                      act, float(act_alpha), _dt(a), _dt(out), _stream()), "coin_gemm_nt")
     return out
 
 

@@ -1,0 +1,84 @@
+"""The C-ABI library loads, exports every symbol include/coin_hip.h declares, and the Python binding table
+mirrors the header.  No compute calls (no GPU here).  Also: the product has no CPU fallback."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from coin_amd import _lib
+
+HEADER = open(_lib.HEADER_PATH).read()
+
+
+def declared_functions():
+    body = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
+    body = re.sub(r"typedef struct.*?}\s*\w+;", "", body, flags=re.S)
+    out = {}
+    for m in re.finditer(r"^\s*(?:const\s+)?(int|size_t|char\s*\*|const char\s*\*)\s*\*?\s*(coin_\w+)\s*\(([^;]*?)\)\s*;", body, flags=re.M | re.S):
+        args = [a.strip() for a in m.group(3).replace("\n", " ").split(",")]
+        out[m.group(2)] = [] if args == ["void"] else args
+    return out
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.lib()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    decl = declared_functions()
+    assert len(decl) >= 19, decl.keys()
+    for name in decl:
+        assert hasattr(lib, name), f"{name} declared in coin_hip.h but not exported by libcoin_hip.so"
+
+
+def test_binding_table_matches_header(lib):
+    decl = declared_functions()
+    for name, argtypes in _lib.SIGNATURES.items():
+        assert name in decl, f"{name} bound in _lib.py but not declared in coin_hip.h"
+        assert len(argtypes) == len(decl[name]), f"{name}: {len(argtypes)} bound args vs {len(decl[name])} declared"
+        for ct, d in zip(argtypes, decl[name]):
+            is_ptr = "*" in d or "[" in d
+            assert is_ptr == (ct in (ctypes.c_void_p,) or hasattr(ct, "contents") or ct is ctypes.POINTER(ctypes.c_float)), (name, d, ct)
+            if not is_ptr:
+                want = {"int": ctypes.c_int, "float": ctypes.c_float, "int64_t": ctypes.c_int64}[d.split()[-2] if len(d.split()) > 1 else d]
+                assert ct is want, (name, d, ct)
+    unbound = set(decl) - set(_lib.SIGNATURES) - {"coin_abi_version", "coin_build_arch", "coin_nms_workspace_bytes"}
+    assert not unbound, unbound
+
+
+def test_version_arch_and_workspace_query(lib):
+    assert lib.coin_abi_version() == 1
+    assert lib.coin_build_arch() == b"gfx950"
+    assert lib.coin_nms_workspace_bytes(2, 12000) == 2 * 12000 * 188 * 8
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(_lib.SgdTensor) == 48 and ctypes.sizeof(_lib.EmaTensor) == 24
+
+
+def test_argument_validation_without_gpu(lib):
+    """Bad arguments are rejected before any launch (safe to call without a device)."""
+    assert lib.coin_roi_align_fwd(None, 1, 8, 4, 4, 1, None, 1, 2, 2, 1.0, 0, 1, None, 0, None) == -1
+    assert lib.coin_gemm_nt(None, 8, None, 8, None, 8, 1, 1, 8, None, 0, 0.0, 0, 0, None) == -1
+    assert lib.coin_mil_ce_fwd_bwd(None, 9, None, None, None, 4, 9, 1, 1, None, None, None) == -1
+    assert lib.coin_nms_batched(None, None, 1, 20000, 0.5, 10, None, None, None, None) == -1
+
+
+def test_product_has_no_cpu_fallback():
+    from coin_amd import kernels as K
+    from coin_amd import layers as L
+    from coin_amd._lib import CoinHipError
+
+    with pytest.raises(CoinHipError):
+        K.roi_align_fwd(torch.zeros(1, 4, 4, 8), torch.zeros(1, 5), (2, 2), 1.0)
+    with pytest.raises(CoinHipError):
+        K.gemm_nt(torch.zeros(4, 16), torch.zeros(4, 16))
+    with pytest.raises(CoinHipError):
+        L.mil_cross_entropy(torch.zeros(4, 9), labels=torch.zeros(4, dtype=torch.int64))
+    with pytest.raises(CoinHipError):
+        L.roi_align(torch.zeros(1, 8, 4, 4), torch.zeros(1, 5), (2, 2), 1.0)

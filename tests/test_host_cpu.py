@@ -18,51 +18,7 @@ from golden_util import GOLDEN, K, LOSS_W, T, close, load, load_weights
 torch.set_num_threads(4)
 
 
-def _inst(z, prefix, size):
-    from coin_amd.structures import Boxes, Instances
-
-    inst = Instances(tuple(size))
-    for k in z.files:
-        if k.startswith(prefix + "."):
-            name = k[len(prefix) + 1:]
-            if "." in name:
-                continue
-            v = T(z[k])
-            inst.set(name, Boxes(v) if name.endswith("boxes") else v, check_len=False)
-    return inst
-
-
-def tiny_product_detector():
-    from coin_amd.box_ops import Box2BoxTransform, Matcher
-    from coin_amd.modeling.backbone import CLIP_IMAGE
-    from coin_amd.modeling.fast_rcnn import FastRCNNOutputLayers
-    from coin_amd.modeling.meta_arch import OpenVocabularyRCNN
-    from coin_amd.modeling.roi_heads import OpenVocabularyRes5ROIHeads, ROIPooler
-    from coin_amd.modeling.rpn import DefaultAnchorGenerator, DualTeacherRPN, StandardRPNHead
-    from coin_amd.modeling.text_encoder import CLIP_TEXT, prompt_tokens
-    from coin_amd.structures import ShapeSpec
-
-    toks = torch.zeros(K + 1, 16, dtype=torch.int)
-    for i in range(K + 1):
-        seq = [62, 1, 2, 3, 1, 6, 6, 6, 6, 10 + i, 5, 63]
-        toks[i, : len(seq)] = torch.tensor(seq)
-    te = CLIP_TEXT("RN50", ["car", "person", "bus", "backgroud"], embed_dim=32, context_length=16, vocab_size=64, width=32, heads=2,
-                   layers=2, tokenized_prompts=toks, n_templates=2)
-    bp = FastRCNNOutputLayers(ShapeSpec(channels=256, height=1, width=1), text_encoder=te, pooling_type="meanpool",
-                              box2box_transform=Box2BoxTransform((10.0, 10.0, 5.0, 5.0)), text_dim=32, classes_weight=[1.0] * K + [0.9],
-                              loss_type="MILCrossEntropy", test_score_thresh=0.05, test_nms_thresh=0.5, test_topk_per_image=100,
-                              cls_agnostic_bbox_reg=True, loss_weight=LOSS_W, batch_size_per_image=32, cls_b_thresh=0.3,
-                              dataset=("foggytrain_0.02",), prototype_update_rate=0.9996)
-    rh = OpenVocabularyRes5ROIHeads(in_features=["res4"], pooler=ROIPooler(14, (1.0 / 16,), 0, "ROIAlignV2"), box_predictor=bp,
-                                    pooling_type="meanpool", num_classes=K, batch_size_per_image=32, positive_fraction=0.25,
-                                    proposal_matcher=Matcher([0.5], [0, 1], False))
-    ag = DefaultAnchorGenerator([[32, 64, 128]], [[0.5, 1.0, 2.0]], [16])
-    pg = DualTeacherRPN(in_features=["res4"], head=StandardRPNHead(128, 9), anchor_generator=ag,
-                        anchor_matcher=Matcher([0.3, 0.7], [0, -1, 1], True), box2box_transform=Box2BoxTransform((1.0, 1.0, 1.0, 1.0)),
-                        batch_size_per_image=64, positive_fraction=0.5, pre_nms_topk=(200, 120), post_nms_topk=(60, 40))
-    bb = CLIP_IMAGE("RN50", freeze_at=2, layers=(1, 1, 2, 2), width=8)
-    return OpenVocabularyRCNN(backbone=bb, proposal_generator=pg, roi_heads=rh, pixel_mean=[0.48145466, 0.4578275, 0.40821073],
-                              pixel_std=[0.26862954, 0.26130258, 0.27577711], device="cpu", compute_dtype=torch.float32)
+from e2e_util import _inst, tiny_product_detector  # noqa: E402
 
 
 def test_state_dict_keys_match_the_reference():
@@ -209,3 +165,15 @@ def test_pretrainer_run_step_on_cpu_with_shimmed_kernels():
     changed = sum(int(not torch.equal(a, b)) for a, b in zip(before, tr.optimizer.params))
     assert changed > 0.5 * len(before)  # zero-init bn3.weight (CLIP init) leaves the inner BN affine params of each block without gradient at step 0
     assert tr.iter == 2 and tr.scheduler.last_epoch == 2
+
+
+def test_oracle_reproduces_golden_at_parity_boundary():
+    """The boundary-P harness itself (samplers replaced by the stored reference samples) on the CPU oracle."""
+    from e2e_util import golden_pretrain_case, run_oracle_pretrain
+
+    case = golden_pretrain_case()
+    losses, grads = run_oracle_pretrain(case)
+    for k, ref in case["ref_losses"].items():
+        assert abs(float(losses[k]) - ref) < 1e-5, k
+    for k, ref in case["ref_grads"].items():
+        close(grads[k], ref, 1e-4, k)
