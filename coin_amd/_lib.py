@@ -81,6 +81,11 @@ def lib() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch owns the device memory and streams these kernels run on: make sure ITS HIP runtime (the libamdhip64 bundled
+    # with the wheel) is the one already mapped before libcoin_hip.so resolves its libamdhip64 dependency, otherwise a
+    # second runtime instance from /opt/rocm is loaded and every launch fails with hipErrorNoDevice.
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise CoinHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
