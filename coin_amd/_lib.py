@@ -56,6 +56,11 @@ SIGNATURES = {
     "coin_l1_mean_fwd_bwd": [_P, _P, _L, _P, _P, _P],
     "coin_rpn_losses_fwd_bwd": [_P, _P, _P, _P, _P, _L, _L, _I, _P, _P, _P, _P, _P],
     "coin_normalize_pad": [_P, _I, _I, ctypes.POINTER(c_float), ctypes.POINTER(c_float), _P, _I, _I, _I, _I, _I, _P],
+    "coin_bn_stats": [_P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _I, _P],
+    "coin_bn_apply_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "coin_bn_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P],
+    "coin_avgpool2_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "coin_avgpool2_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "coin_nms_batched": [_P, _P, _I, _I, _F, _I, _P, _P, _P, _P],
     "coin_sgd_step": [_P, _I, _L, _F, _F, _I, _P],
     "coin_ema_update": [_P, _I, _L, _F, _P],

@@ -1,0 +1,486 @@
+// Fused train-mode BatchNorm (+ residual add) (+ ReLU) (+ 2x2 average pool) for channels-last activations, gfx950.
+//
+// Replaces the nn.BatchNorm2d -> (+= identity) -> ReLU -> nn.AvgPool2d chains of the CLIP Bottleneck
+// (coin/modeling/utils.py:77-90) for the trainable stages (layer2, layer3 and res5 = layer4 on the RoI tiles,
+// clip_roi_heads.py:172-176).  On the RoI head these chains stream ~3 GB of bf16 activations per step; done as
+// separate library launches (statistics, normalise, add, relu, pool and their five backward kernels) they cost more
+// device time than the res5 convolutions.  Here:
+//   forward  = 1 statistics pass (read x) + 1 apply pass (read x [, residual], write y; y already pooled if pool=2)
+//   backward = 1 reduction pass (read x, dy [, y]) + 1 dx pass (read x, dy [, y], write dx [, d_residual])
+// All four are pure HBM streams: lane = 8 (bf16) or 4 (f32) consecutive channels = one 16-byte access, rows are
+// grid-strided, per-channel sums are kept in registers, combined through LDS and flushed with one float atomic per
+// (block, channel).  Statistics are accumulated in fp32 around a per-channel pivot (the first row) so that
+// E[x^2]-E[x]^2 does not cancel; running_mean / running_var follow nn.BatchNorm2d (momentum, unbiased variance).
+#include "common.h"
+
+namespace {
+
+constexpr int BN_THREADS = 256;
+
+template <typename T>
+struct Ld {
+  static constexpr int V = Vec16<T>::N;
+  typedef typename Vec16<T>::type vec;
+  static __device__ __forceinline__ void load(const T* p, float (&o)[V]) {
+    const vec v = *reinterpret_cast<const vec*>(p);
+#pragma unroll
+    for (int i = 0; i < V; ++i) o[i] = (float)v[i];
+  }
+  static __device__ __forceinline__ void store(T* p, const float (&o)[V]) {
+    vec v;
+#pragma unroll
+    for (int i = 0; i < V; ++i) v[i] = (T)o[i];
+    *reinterpret_cast<vec*>(p) = v;
+  }
+};
+
+// Thread -> (channel group, row slot).  tpr = threads per row = C / V (<= 256 here; larger C loops over groups).
+struct Map {
+  int cg, slot, rows_per_iter, ngroups_iter;
+};
+
+// ------------------------------------------------------------------------------------------ statistics
+// sums[0..C) = sum(x - pivot), sums[C..2C) = sum((x - pivot)^2), pivot[c] = x[0][c]
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restrict__ x, int64_t M, int C,
+                                                               float* __restrict__ sums) {
+  constexpr int V = Ld<T>::V;
+  extern __shared__ float red[];  // [BN_THREADS][2*V]
+  const int ncg = C / V;
+  const int tpr = ncg < BN_THREADS ? ncg : BN_THREADS;
+  const int rpi = BN_THREADS / tpr;
+  const int slot = threadIdx.x / tpr, cg0 = threadIdx.x - slot * tpr;
+  const bool active = slot < rpi;
+  for (int cg = cg0; cg < ncg; cg += tpr) {
+    float s1[V], s2[V], piv[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) s1[i] = s2[i] = 0.f;
+    Ld<T>::load(x + (size_t)cg * V, piv);
+    if (active) {
+      for (int64_t r = (int64_t)blockIdx.x * rpi + slot; r < M; r += (int64_t)gridDim.x * rpi) {
+        float v[V];
+        Ld<T>::load(x + (size_t)r * C + (size_t)cg * V, v);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const float d = v[i] - piv[i];
+          s1[i] += d;
+          s2[i] += d * d;
+        }
+      }
+    }
+    // combine the row slots that share this channel group
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      red[threadIdx.x * 2 * V + i] = s1[i];
+      red[threadIdx.x * 2 * V + V + i] = s2[i];
+    }
+    __syncthreads();
+    if (slot == 0) {
+      for (int s = 1; s < rpi; ++s) {
+        const float* o = red + (size_t)(s * tpr + cg0) * 2 * V;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          s1[i] += o[i];
+          s2[i] += o[V + i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        atomicAdd(sums + cg * V + i, s1[i]);
+        atomicAdd(sums + C + cg * V + i, s2[i]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// mean / rstd from the pivoted sums; also the running-statistics update (one thread per channel)
+template <typename T>
+__global__ void bn_finalize_kernel(const T* __restrict__ x, const float* __restrict__ sums, int64_t M, int C, float eps,
+                                   float momentum, float* __restrict__ mean, float* __restrict__ rstd,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float piv = (float)x[c];
+  const float m1 = sums[c] / (float)M;
+  const float var = fmaxf(sums[C + c] / (float)M - m1 * m1, 0.f);
+  const float mu = piv + m1;
+  mean[c] = mu;
+  rstd[c] = 1.0f / sqrtf(var + eps);
+  if (running_mean) {
+    const float unbiased = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ apply (forward)
+// x: [N, H, W, C]; y: [N, H/pool, W/pool, C] (floor); residual (pool == 1 only): same shape as y
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const T* __restrict__ residual,
+                                                               T* __restrict__ y, int N, int H, int W, int C, int relu, int pool) {
+  constexpr int V = Ld<T>::V;
+  const int ncg = C / V;
+  const int OH = H / pool, OW = W / pool;
+  const int64_t rows = (int64_t)N * OH * OW;
+  const int64_t total = rows * ncg;
+  for (int64_t idx = (int64_t)blockIdx.x * BN_THREADS + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BN_THREADS) {
+    const int cg = (int)(idx % ncg);
+    const int64_t orow = idx / ncg;
+    float sc[V], sh[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = cg * V + i;
+      sc[i] = rstd[c] * gamma[c];
+      sh[i] = beta[c] - mean[c] * sc[i];
+    }
+    float o[V];
+    if (pool == 1) {
+      float v[V];
+      Ld<T>::load(x + (size_t)orow * C + (size_t)cg * V, v);
+      if (residual) {
+        float rr[V];
+        Ld<T>::load(residual + (size_t)orow * C + (size_t)cg * V, rr);
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[i] = v[i] * sc[i] + sh[i] + rr[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[i] = v[i] * sc[i] + sh[i];
+      }
+      if (relu) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[i] = fmaxf(o[i], 0.f);
+      }
+    } else {
+      const int ow = (int)(orow % OW);
+      const int oh = (int)((orow / OW) % OH);
+      const int n = (int)(orow / ((int64_t)OW * OH));
+#pragma unroll
+      for (int i = 0; i < V; ++i) o[i] = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          float v[V];
+          Ld<T>::load(x + (((size_t)n * H + (2 * oh + dy)) * W + (2 * ow + dx)) * C + (size_t)cg * V, v);
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            float t = v[i] * sc[i] + sh[i];
+            if (relu) t = fmaxf(t, 0.f);
+            // the un-pooled activation is rounded to the storage type before pooling, as nn.AvgPool2d sees it
+            o[i] += (float)(T)t;
+          }
+        }
+#pragma unroll
+      for (int i = 0; i < V; ++i) o[i] *= 0.25f;
+    }
+    Ld<T>::store(y + (size_t)orow * C + (size_t)cg * V, o);
+  }
+}
+
+// Upstream gradient of the pre-activation at input pixel (n,h,w): dy (through pool / relu mask).
+template <typename T>
+__device__ __forceinline__ void upstream(const T* __restrict__ dy, const T* __restrict__ yout, const float (&xv)[Ld<T>::V],
+                                         const float (&sc)[Ld<T>::V], const float (&sh)[Ld<T>::V], int n, int h, int w, int H, int W,
+                                         int C, int cg, int relu, int pool, float (&g)[Ld<T>::V]) {
+  constexpr int V = Ld<T>::V;
+  if (pool == 1) {
+    const size_t off = (((size_t)n * H + h) * W + w) * C + (size_t)cg * V;
+    Ld<T>::load(dy + off, g);
+    if (relu) {
+      float yv[V];
+      Ld<T>::load(yout + off, yv);
+#pragma unroll
+      for (int i = 0; i < V; ++i) g[i] = yv[i] > 0.f ? g[i] : 0.f;
+    }
+  } else {
+    const int OH = H / 2, OW = W / 2;
+    if ((h >> 1) >= OH || (w >> 1) >= OW) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) g[i] = 0.f;
+      return;
+    }
+    Ld<T>::load(dy + (((size_t)n * OH + (h >> 1)) * OW + (w >> 1)) * C + (size_t)cg * V, g);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      g[i] *= 0.25f;
+      if (relu && !(xv[i] * sc[i] + sh[i] > 0.f)) g[i] = 0.f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ backward reductions
+// dsums[0..C) = sum g (= dbeta), dsums[C..2C) = sum g * xhat (= dgamma)
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                    const T* __restrict__ yout, const float* __restrict__ mean,
+                                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, int N, int H, int W, int C,
+                                                                    int relu, int pool, float* __restrict__ dsums) {
+  constexpr int V = Ld<T>::V;
+  extern __shared__ float red[];
+  const int ncg = C / V;
+  const int tpr = ncg < BN_THREADS ? ncg : BN_THREADS;
+  const int rpi = BN_THREADS / tpr;
+  const int slot = threadIdx.x / tpr, cg0 = threadIdx.x - slot * tpr;
+  const bool active = slot < rpi;
+  const int64_t M = (int64_t)N * H * W;
+  for (int cg = cg0; cg < ncg; cg += tpr) {
+    float sc[V], sh[V], mu[V], rs[V], db[V], dg[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = cg * V + i;
+      mu[i] = mean[c];
+      rs[i] = rstd[c];
+      sc[i] = rs[i] * gamma[c];
+      sh[i] = beta[c] - mu[i] * sc[i];
+      db[i] = dg[i] = 0.f;
+    }
+    if (active) {
+      for (int64_t r = (int64_t)blockIdx.x * rpi + slot; r < M; r += (int64_t)gridDim.x * rpi) {
+        const int w = (int)(r % W);
+        const int h = (int)((r / W) % H);
+        const int n = (int)(r / ((int64_t)W * H));
+        float xv[V], g[V];
+        Ld<T>::load(x + (size_t)r * C + (size_t)cg * V, xv);
+        upstream<T>(dy, yout, xv, sc, sh, n, h, w, H, W, C, cg, relu, pool, g);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          db[i] += g[i];
+          dg[i] += g[i] * (xv[i] - mu[i]) * rs[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      red[threadIdx.x * 2 * V + i] = db[i];
+      red[threadIdx.x * 2 * V + V + i] = dg[i];
+    }
+    __syncthreads();
+    if (slot == 0) {
+      for (int s = 1; s < rpi; ++s) {
+        const float* o = red + (size_t)(s * tpr + cg0) * 2 * V;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          db[i] += o[i];
+          dg[i] += o[V + i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        atomicAdd(dsums + cg * V + i, db[i]);
+        atomicAdd(dsums + C + cg * V + i, dg[i]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// dx = gamma * rstd * (g - dbeta/M - xhat * dgamma/M);  d_residual = g (pool == 1 with residual)
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                const T* __restrict__ yout, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ dsums,
+                                                                int N, int H, int W, int C, int relu, int pool, T* __restrict__ dx,
+                                                                T* __restrict__ dres) {
+  constexpr int V = Ld<T>::V;
+  const int ncg = C / V;
+  const int64_t M = (int64_t)N * H * W;
+  const int64_t total = M * ncg;
+  const float invM = 1.0f / (float)M;
+  for (int64_t idx = (int64_t)blockIdx.x * BN_THREADS + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BN_THREADS) {
+    const int cg = (int)(idx % ncg);
+    const int64_t r = idx / ncg;
+    const int w = (int)(r % W);
+    const int h = (int)((r / W) % H);
+    const int n = (int)(r / ((int64_t)W * H));
+    float sc[V], sh[V], xv[V], g[V], o[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = cg * V + i;
+      sc[i] = rstd[c] * gamma[c];
+      sh[i] = beta[c] - mean[c] * sc[i];
+    }
+    Ld<T>::load(x + (size_t)r * C + (size_t)cg * V, xv);
+    upstream<T>(dy, yout, xv, sc, sh, n, h, w, H, W, C, cg, relu, pool, g);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = cg * V + i;
+      const float xhat = (xv[i] - mean[c]) * rstd[c];
+      o[i] = sc[i] * (g[i] - dsums[c] * invM - xhat * dsums[C + c] * invM);
+    }
+    Ld<T>::store(dx + (size_t)r * C + (size_t)cg * V, o);
+    if (dres) Ld<T>::store(dres + (size_t)r * C + (size_t)cg * V, g);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ plain 2x2 average pool
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void avgpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W,
+                                                                   int C) {
+  constexpr int V = Ld<T>::V;
+  const int ncg = C / V, OH = H / 2, OW = W / 2;
+  const int64_t total = (int64_t)N * OH * OW * ncg;
+  for (int64_t idx = (int64_t)blockIdx.x * BN_THREADS + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BN_THREADS) {
+    const int cg = (int)(idx % ncg);
+    const int64_t orow = idx / ncg;
+    const int ow = (int)(orow % OW), oh = (int)((orow / OW) % OH), n = (int)(orow / ((int64_t)OW * OH));
+    float o[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) o[i] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        float v[V];
+        Ld<T>::load(x + (((size_t)n * H + (2 * oh + dy)) * W + (2 * ow + dx)) * C + (size_t)cg * V, v);
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[i] += v[i];
+      }
+#pragma unroll
+    for (int i = 0; i < V; ++i) o[i] *= 0.25f;
+    Ld<T>::store(y + (size_t)orow * C + (size_t)cg * V, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void avgpool2_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W,
+                                                                   int C) {
+  constexpr int V = Ld<T>::V;
+  const int ncg = C / V, OH = H / 2, OW = W / 2;
+  const int64_t total = (int64_t)N * H * W * ncg;
+  for (int64_t idx = (int64_t)blockIdx.x * BN_THREADS + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BN_THREADS) {
+    const int cg = (int)(idx % ncg);
+    const int64_t r = idx / ncg;
+    const int w = (int)(r % W), h = (int)((r / W) % H), n = (int)(r / ((int64_t)W * H));
+    float g[V];
+    if ((h >> 1) < OH && (w >> 1) < OW) {
+      Ld<T>::load(dy + (((size_t)n * OH + (h >> 1)) * OW + (w >> 1)) * C + (size_t)cg * V, g);
+#pragma unroll
+      for (int i = 0; i < V; ++i) g[i] *= 0.25f;
+    } else {
+#pragma unroll
+      for (int i = 0; i < V; ++i) g[i] = 0.f;
+    }
+    Ld<T>::store(dx + (size_t)r * C + (size_t)cg * V, g);
+  }
+}
+
+int bn_check(const void* x, int N, int H, int W, int C, int pool, int dtype) {
+  if (!x || N <= 0 || H <= 0 || W <= 0 || C <= 0) return COIN_EINVAL;
+  if (dtype != COIN_F32 && dtype != COIN_BF16) return COIN_EINVAL;
+  if (pool != 1 && pool != 2) return COIN_EINVAL;
+  const int v = dtype == COIN_F32 ? 4 : 8;
+  if (C % v) return COIN_ESHAPE;
+  if (C / v > BN_THREADS && (C / v) % BN_THREADS) return COIN_ESHAPE;  // uniform trip count of the channel-group loops
+  if ((uintptr_t)x & 15) return COIN_EALIGN;
+  return COIN_OK;
+}
+
+int stream_grid(int64_t work_items) {
+  int64_t g = (work_items + BN_THREADS - 1) / BN_THREADS;
+  if (g > 256 * 16) g = 256 * 16;
+  return (int)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+#define BN_DISPATCH(dtype, EXPR_F32, EXPR_BF16) \
+  do {                                          \
+    if ((dtype) == COIN_F32) {                  \
+      typedef float T;                          \
+      EXPR_F32;                                 \
+    } else {                                    \
+      typedef bf16_t T;                         \
+      EXPR_BF16;                                \
+    }                                           \
+  } while (0)
+
+extern "C" int coin_bn_stats(const void* x, int N, int H, int W, int C, float eps, float momentum, float* sums_workspace,
+                             float* mean, float* rstd, float* running_mean, float* running_var, int dtype, void* stream) {
+  int rc = bn_check(x, N, H, W, C, 1, dtype);
+  if (rc) return rc;
+  if (!sums_workspace || !mean || !rstd) return COIN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t M = (int64_t)N * H * W;
+  hipError_t e = hipMemsetAsync(sums_workspace, 0, sizeof(float) * 2 * C, st);
+  if (e != hipSuccess) return (int)e;
+  const int v = dtype == COIN_F32 ? 4 : 8;
+  const int ncg = C / v, tpr = ncg < BN_THREADS ? ncg : BN_THREADS, rpi = BN_THREADS / tpr;
+  int64_t g = (M + rpi - 1) / rpi;
+  if (g > 2048) g = 2048;
+  const size_t lds = sizeof(float) * BN_THREADS * 2 * v;
+#define GO(T) bn_stats_kernel<T><<<(int)g, BN_THREADS, lds, st>>>((const T*)x, M, C, sums_workspace); \
+  bn_finalize_kernel<T><<<(C + 255) / 256, 256, 0, st>>>((const T*)x, sums_workspace, M, C, eps, momentum, mean, rstd, running_mean, running_var)
+  BN_DISPATCH(dtype, GO(float), GO(bf16_t));
+#undef GO
+  return coin_launch_status();
+}
+
+extern "C" int coin_bn_apply_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                 const void* residual, void* y, int N, int H, int W, int C, int relu, int pool, int dtype,
+                                 void* stream) {
+  int rc = bn_check(x, N, H, W, C, pool, dtype);
+  if (rc) return rc;
+  if (!mean || !rstd || !gamma || !beta || !y) return COIN_EINVAL;
+  if (pool == 2 && residual) return COIN_ESHAPE;
+  if (pool == 2 && (H < 2 || W < 2)) return COIN_ESHAPE;
+  const int v = dtype == COIN_F32 ? 4 : 8;
+  const int64_t items = (int64_t)N * (H / pool) * (W / pool) * (C / v);
+  hipStream_t st = (hipStream_t)stream;
+#define GO(T) bn_apply_kernel<T><<<stream_grid(items), BN_THREADS, 0, st>>>((const T*)x, mean, rstd, gamma, beta, (const T*)residual, (T*)y, N, H, W, C, relu, pool)
+  BN_DISPATCH(dtype, GO(float), GO(bf16_t));
+#undef GO
+  return coin_launch_status();
+}
+
+extern "C" int coin_bn_bwd(const void* x, const void* dy, const void* y, const float* mean, const float* rstd, const float* gamma,
+                           const float* beta, int N, int H, int W, int C, int relu, int pool, float* dsums /* [2C]: dbeta, dgamma */,
+                           void* dx, void* d_residual, int dtype, void* stream) {
+  int rc = bn_check(x, N, H, W, C, pool, dtype);
+  if (rc) return rc;
+  if (!dy || !mean || !rstd || !gamma || !beta || !dsums || !dx) return COIN_EINVAL;
+  if (relu && pool == 1 && !y) return COIN_EINVAL;  // the ReLU mask is read from the saved output
+  if (pool == 2 && d_residual) return COIN_ESHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(dsums, 0, sizeof(float) * 2 * C, st);
+  if (e != hipSuccess) return (int)e;
+  const int v = dtype == COIN_F32 ? 4 : 8;
+  const int64_t M = (int64_t)N * H * W;
+  const int ncg = C / v, tpr = ncg < BN_THREADS ? ncg : BN_THREADS, rpi = BN_THREADS / tpr;
+  int64_t g = (M + rpi - 1) / rpi;
+  if (g > 2048) g = 2048;
+  const size_t lds = sizeof(float) * BN_THREADS * 2 * v;
+#define GO(T) bn_bwd_reduce_kernel<T><<<(int)g, BN_THREADS, lds, st>>>((const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, beta, N, H, W, C, relu, pool, dsums); \
+  bn_bwd_dx_kernel<T><<<stream_grid(M * ncg), BN_THREADS, 0, st>>>((const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, beta, dsums, N, H, W, C, relu, pool, (T*)dx, (T*)d_residual)
+  BN_DISPATCH(dtype, GO(float), GO(bf16_t));
+#undef GO
+  return coin_launch_status();
+}
+
+extern "C" int coin_avgpool2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream) {
+  int rc = bn_check(x, N, H, W, C, 2, dtype);
+  if (rc) return rc;
+  if (!y || H < 2 || W < 2) return COIN_EINVAL;
+  const int v = dtype == COIN_F32 ? 4 : 8;
+  hipStream_t st = (hipStream_t)stream;
+#define GO(T) avgpool2_fwd_kernel<T><<<stream_grid((int64_t)N * (H / 2) * (W / 2) * (C / v)), BN_THREADS, 0, st>>>((const T*)x, (T*)y, N, H, W, C)
+  BN_DISPATCH(dtype, GO(float), GO(bf16_t));
+#undef GO
+  return coin_launch_status();
+}
+
+extern "C" int coin_avgpool2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype, void* stream) {
+  int rc = bn_check(dy, N, H, W, C, 2, dtype);
+  if (rc) return rc;
+  if (!dx || H < 2 || W < 2) return COIN_EINVAL;
+  const int v = dtype == COIN_F32 ? 4 : 8;
+  hipStream_t st = (hipStream_t)stream;
+#define GO(T) avgpool2_bwd_kernel<T><<<stream_grid((int64_t)N * H * W * (C / v)), BN_THREADS, 0, st>>>((const T*)dy, (T*)dx, N, H, W, C)
+  BN_DISPATCH(dtype, GO(float), GO(bf16_t));
+#undef GO
+  return coin_launch_status();
+}

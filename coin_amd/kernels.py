@@ -16,7 +16,7 @@ from ._lib import ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, COIN_BF16, COIN_F32, COIN_
 
 __all__ = [
     "roi_align_fwd", "roi_align_bwd", "gemm_nt", "transpose2d", "bias_act_bwd", "cosine_logits_fwd",
-    "cosine_logits_bwd", "nms_batched", "mil_ce", "kl_div", "box_reg_l1", "l1_mean", "rpn_losses", "normalize_pad",
+    "cosine_logits_bwd", "bn_stats", "bn_apply_fwd", "bn_bwd", "avgpool2_fwd", "avgpool2_bwd", "nms_batched", "mil_ce", "kl_div", "box_reg_l1", "l1_mean", "rpn_losses", "normalize_pad",
     "SgdTable", "EmaTable",
 ]
 
@@ -316,6 +316,71 @@ def rpn_losses(logits: torch.Tensor, labels: torch.Tensor, deltas: torch.Tensor,
                                              ctypes.c_void_p(out.data_ptr() + 4), _p(g_logits), _p(g_deltas), _stream()),
           "coin_rpn_losses_fwd_bwd")
     return out[0], out[1], g_logits, g_deltas
+
+
+# --------------------------------------------------------------------------- fused BatchNorm / pooling (NHWC)
+def _nhwc(t: torch.Tensor, name: str):
+    if t.dim() != 4 or not t.is_contiguous():
+        raise CoinHipError(f"{name} must be a contiguous [N,H,W,C] tensor")
+    return t.shape
+
+
+def bn_stats(x: torch.Tensor, eps: float, momentum: float, running_mean: Optional[torch.Tensor] = None,
+             running_var: Optional[torch.Tensor] = None):
+    """Batch mean / rstd of x [N,H,W,C] (+ in-place running-statistics update)."""
+    _dev(x, running_mean, running_var)
+    n, h, w, c = _nhwc(x, "x")
+    ws = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(c, dtype=torch.float32, device=x.device)
+    check(_lib.lib().coin_bn_stats(_p(x), n, h, w, c, float(eps), float(momentum), _p(ws), _p(mean), _p(rstd), _p(running_mean),
+                                   _p(running_var), _dt(x), _stream()), "coin_bn_stats")
+    return mean, rstd
+
+
+def bn_apply_fwd(x: torch.Tensor, mean, rstd, gamma, beta, residual: Optional[torch.Tensor], relu: bool, pool: int) -> torch.Tensor:
+    _dev(x, mean, rstd, gamma, beta, residual)
+    n, h, w, c = _nhwc(x, "x")
+    y = torch.empty((n, h // pool, w // pool, c), dtype=x.dtype, device=x.device)
+    if residual is not None and (residual.shape != y.shape or residual.dtype != x.dtype or not residual.is_contiguous()):
+        raise CoinHipError("residual must match the output (contiguous NHWC, same dtype)")
+    check(_lib.lib().coin_bn_apply_fwd(_p(x), _p(_f32c(mean, "mean")), _p(_f32c(rstd, "rstd")), _p(_f32c(gamma, "gamma")),
+                                       _p(_f32c(beta, "beta")), _p(residual), _p(y), n, h, w, c, int(relu), int(pool), _dt(x), _stream()),
+          "coin_bn_apply_fwd")
+    return y
+
+
+def bn_bwd(x: torch.Tensor, dy: torch.Tensor, y: Optional[torch.Tensor], mean, rstd, gamma, beta, relu: bool, pool: int,
+           want_dres: bool):
+    """-> dx [N,H,W,C], dgamma [C], dbeta [C], d_residual (or None)."""
+    _dev(x, dy, y)
+    n, h, w, c = _nhwc(x, "x")
+    if not dy.is_contiguous() or dy.dtype != x.dtype:
+        raise CoinHipError("dy must be contiguous NHWC of x's dtype")
+    dsums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(dy) if want_dres else None
+    check(_lib.lib().coin_bn_bwd(_p(x), _p(dy), _p(y), _p(mean), _p(rstd), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")), n, h, w, c,
+                                 int(relu), int(pool), _p(dsums), _p(dx), _p(dres), _dt(x), _stream()), "coin_bn_bwd")
+    return dx, dsums[c:], dsums[:c], dres
+
+
+def avgpool2_fwd(x: torch.Tensor) -> torch.Tensor:
+    _dev(x)
+    n, h, w, c = _nhwc(x, "x")
+    y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
+    check(_lib.lib().coin_avgpool2_fwd(_p(x), _p(y), n, h, w, c, _dt(x), _stream()), "coin_avgpool2_fwd")
+    return y
+
+
+def avgpool2_bwd(dy: torch.Tensor, in_shape) -> torch.Tensor:
+    _dev(dy)
+    n, h, w, c = in_shape
+    if not dy.is_contiguous():
+        raise CoinHipError("dy must be contiguous NHWC")
+    dx = torch.empty(tuple(in_shape), dtype=dy.dtype, device=dy.device)
+    check(_lib.lib().coin_avgpool2_bwd(_p(dy), _p(dx), n, h, w, c, _dt(dy), _stream()), "coin_avgpool2_bwd")
+    return dx
 
 
 # --------------------------------------------------------------------------- NMS

@@ -56,6 +56,79 @@ def roi_align(feat: torch.Tensor, rois: torch.Tensor, output_size: Tuple[int, in
     return out.permute(0, 3, 1, 2)
 
 
+# --------------------------------------------------------------------------- fused BatchNorm(train) [+res] [+ReLU] [+pool]
+def _as_nhwc(t: torch.Tensor) -> torch.Tensor:
+    v = t.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+class _BNAct(Function):
+    """nn.BatchNorm2d(train) -> (+ identity) -> ReLU -> nn.AvgPool2d(2) of the CLIP Bottleneck (coin/modeling/utils.py:77-90)
+    as two HIP streams forward and two backward (coin_bn_stats / coin_bn_apply_fwd / coin_bn_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, pool):
+        xn = _as_nhwc(x)
+        rn = _as_nhwc(residual) if residual is not None else None
+        g, b = gamma.float().contiguous(), beta.float().contiguous()
+        mean, rstd = K.bn_stats(xn, eps, momentum, running_mean, running_var)
+        y = K.bn_apply_fwd(xn, mean, rstd, g, b, rn, relu, pool)
+        ctx.relu, ctx.pool, ctx.has_res = relu, pool, residual is not None
+        ctx.save_for_backward(xn, y if (relu and pool == 1) else None, mean, rstd, g, b)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        xn, y, mean, rstd, g, b = ctx.saved_tensors
+        dyn = _as_nhwc(dy)
+        if dyn.dtype != xn.dtype:
+            dyn = dyn.to(xn.dtype)
+        dx, dgamma, dbeta, dres = K.bn_bwd(xn, dyn, y, mean, rstd, g, b, ctx.relu, ctx.pool, ctx.has_res and ctx.needs_input_grad[3])
+        return (dx.permute(0, 3, 1, 2), dgamma, dbeta, dres.permute(0, 3, 1, 2) if dres is not None else None,
+                None, None, None, None, None, None)
+
+
+def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm2d, relu: bool, residual: Optional[torch.Tensor] = None, pool: int = 1) -> torch.Tensor:
+    """Train-mode BatchNorm with batch statistics (per GPU, as the reference) fused with the elementwise tail.
+    x / residual / result: logical [N,C,H,W] in channels-last memory format."""
+    if bn.training:
+        if bn.momentum is None:
+            raise CoinHipError("cumulative-average BatchNorm (momentum=None) is not used by the reference")
+        if bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        rm = bn.running_mean if bn.track_running_stats else None
+        rv = bn.running_var if bn.track_running_stats else None
+        return _BNAct.apply(x, bn.weight, bn.bias, residual, rm, rv, float(bn.momentum), float(bn.eps), bool(relu), int(pool))
+    # eval mode (teacher inference): a per-channel affine map with the running statistics
+    scale = bn.weight * (bn.running_var + bn.eps).rsqrt()
+    shift = bn.bias - bn.running_mean * scale
+    y = x * scale.view(1, -1, 1, 1).to(x.dtype) + shift.view(1, -1, 1, 1).to(x.dtype)
+    if residual is not None:
+        y = y + residual
+    if relu:
+        y = torch.relu(y)
+    return avg_pool2(y) if pool == 2 else y
+
+
+class _AvgPool2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        xn = _as_nhwc(x)
+        ctx.shape = tuple(xn.shape)
+        return K.avgpool2_fwd(xn).permute(0, 3, 1, 2)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        return K.avgpool2_bwd(_as_nhwc(dy), ctx.shape).permute(0, 3, 1, 2)
+
+
+def avg_pool2(x: torch.Tensor) -> torch.Tensor:
+    """nn.AvgPool2d(2) on a channels-last tensor."""
+    return _AvgPool2.apply(x)
+
+
 # --------------------------------------------------------------------------- box-head linear
 class _LinearAct(Function):
     """nn.Linear (+ LeakyReLU) of FastRCNNOutputLayers (fast_rcnn.py:237-251,331-337) on the MFMA GEMM."""

@@ -22,6 +22,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import layers as L
 from ..registry import BACKBONE_REGISTRY
 from ..structures import ShapeSpec
 
@@ -94,12 +95,24 @@ class Bottleneck(nn.Module):
                 ("-1", nn.AvgPool2d(stride)), ("0", nn.Conv2d(inplanes, out, 1, stride=1, bias=False)), ("1", nn.BatchNorm2d(out))]))
 
     def forward(self, x):
-        y = _conv_bn(x, self.conv1, self.bn1, True)
-        y = _conv_bn(y, self.conv2, self.bn2, True)
-        y = _conv_bn(self.avgpool(y), self.conv3, self.bn3, False)
+        if isinstance(self.bn1, FrozenBatchNorm2d):  # frozen stage (layer1 at FREEZE_AT=2): plain inference ops
+            y = _conv_bn(x, self.conv1, self.bn1, True)
+            y = _conv_bn(y, self.conv2, self.bn2, True)
+            y = _conv_bn(self.avgpool(y), self.conv3, self.bn3, False)
+            if self.downsample is not None:
+                x = _conv_bn(self.downsample[0](x), self.downsample[1], self.downsample[2], False)
+            return F.relu(y + x)
+        # trainable stage: every BatchNorm + elementwise tail is a fused HIP stream (coin_amd.layers.bn_act)
+        pool = 2 if self.stride > 1 else 1
+        assert self.stride in (1, 2)
+        y = L.bn_act(self.conv1(x), self.bn1, relu=True)
+        y = L.bn_act(self.conv2(y), self.bn2, relu=True, pool=pool)          # ReLU and the anti-aliasing avg-pool fused in
         if self.downsample is not None:
-            x = _conv_bn(self.downsample[0](x), self.downsample[1], self.downsample[2], False)
-        return F.relu(y + x)
+            sx = L.avg_pool2(x) if pool == 2 else x
+            sx = L.bn_act(self.downsample[1](sx), self.downsample[2], relu=False)
+        else:
+            sx = x
+        return L.bn_act(self.conv3(y), self.bn3, relu=True, residual=sx)      # bn3 + identity add + ReLU
 
 
 class ModifiedResNet(nn.Module):

@@ -100,6 +100,36 @@ int coin_bias_act_bwd(const void* dC, const void* C, void* dZ, int ld, int M, in
                       float* dbias, int act, float act_alpha, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused train-mode BatchNorm (+ residual) (+ ReLU) (+ 2x2 average pool), channels-last
+ *   (replaces the nn.BatchNorm2d / `out += identity` / ReLU / nn.AvgPool2d chains of the CLIP Bottleneck,
+ *    coin/modeling/utils.py:77-90, for the trainable stages incl. res5 on the RoI tiles)
+ *
+ * x [N,H,W,C] dtype `dtype`; per-channel float32 vectors of length C; C % 8 == 0 (bf16) / % 4 (f32), and
+ * C/8 (resp. C/4) <= 256 or a multiple of 256.
+ *
+ * coin_bn_stats     : batch mean and 1/sqrt(biased var + eps) over N*H*W (fp32, pivoted sums), and the
+ *                     nn.BatchNorm2d running-statistics update (momentum, unbiased variance) when
+ *                     running_mean/var are non-NULL.  sums_workspace: 2*C floats (contents undefined).
+ * coin_bn_apply_fwd : y = pool( relu?( (x-mean)*rstd*gamma + beta [+ residual] ) ); pool in {1,2};
+ *                     pool == 2 writes y [N,H/2,W/2,C] (floor, as nn.AvgPool2d(2)); residual requires pool == 1.
+ * coin_bn_bwd       : given dy (shape of y) computes dsums[0..C) = dbeta, dsums[C..2C) = dgamma, dx (shape of x)
+ *                     and, if d_residual != NULL, d_residual = dy * relu'  (shape of y, pool == 1).
+ *                     `y` (the saved forward output) supplies the ReLU mask when relu && pool == 1.
+ * ---------------------------------------------------------------------------------------- */
+int coin_bn_stats(const void* x, int N, int H, int W, int C, float eps, float momentum, float* sums_workspace,
+                  float* mean, float* rstd, float* running_mean, float* running_var, int dtype, void* stream);
+int coin_bn_apply_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                      const void* residual, void* y, int N, int H, int W, int C, int relu, int pool, int dtype,
+                      void* stream);
+int coin_bn_bwd(const void* x, const void* dy, const void* y, const float* mean, const float* rstd,
+                const float* gamma, const float* beta, int N, int H, int W, int C, int relu, int pool,
+                float* dsums, void* dx, void* d_residual, int dtype, void* stream);
+
+/* nn.AvgPool2d(2) forward / backward on channels-last tensors (the anti-aliased shortcut of utils.py:71-75). */
+int coin_avgpool2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
+int coin_avgpool2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Cosine-similarity classifier  (replaces FastRCNNOutputLayers.do_classify,
  *                                fast_rcnn.py:343-346)
  *   scores[r,k] = <f_r/|f_r|, t_k/|t_k|> * inv_scale          (inv_scale = 1/logit_scale = 100)

@@ -75,6 +75,15 @@ def _roi_align(feat, rois, output_size, spatial_scale, sampling_ratio=0, aligned
     return d2.roi_align_torch(feat.float(), rois.float(), tuple(output_size), spatial_scale, sampling_ratio, aligned).to(feat.dtype)
 
 
+def _bn_act(x, bn, relu, residual=None, pool=1):
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    if relu:
+        y = F.relu(y)
+    return F.avg_pool2d(y, 2) if pool == 2 else y
+
+
 def _normalize_pad(images, mean, std, size_divisibility=0, layout=0, dtype=torch.float32):
     m, s = torch.tensor(mean).view(3, 1, 1), torch.tensor(std).view(3, 1, 1)
     imgs = [(im.float().div(255) - m) / s for im in images]
@@ -122,7 +131,7 @@ def cpu_kernels():
     patches = {
         L: dict(linear_act=_linear_act, cosine_logits=_cosine_logits, mil_cross_entropy=_mil, kl_div_from_logits=_kl_logits,
                 kl_div_from_probs=_kl_probs, kl_div_binary=_kl_binary, box_reg_l1=_box_reg, l1_mean=lambda a, b: F.l1_loss(a, b),
-                rpn_losses=_rpn_losses, roi_align=_roi_align),
+                rpn_losses=_rpn_losses, roi_align=_roi_align, bn_act=_bn_act, avg_pool2=lambda x: F.avg_pool2d(x, 2)),
         K: dict(normalize_pad=_normalize_pad, nms_batched=_nms_batched, SgdTable=_CpuSgdTable),
     }
     saved = {mod: {k: getattr(mod, k) for k in d} for mod, d in patches.items()}

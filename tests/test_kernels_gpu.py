@@ -364,3 +364,71 @@ def test_ema_golden(K):
     K.EmaTable(t, s).update(0.9996)
     for k, tt in zip(keys, t):
         np.testing.assert_allclose(tt.cpu().numpy(), z["after::" + k], rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------ fused BatchNorm
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("relu,res,pool,shape", [
+    (True, False, 1, (6, 16, 14, 14)), (True, False, 2, (5, 32, 14, 14)), (True, True, 1, (4, 64, 7, 7)),
+    (False, False, 1, (3, 2048, 7, 7)), (True, False, 2, (2, 8, 9, 11)), (True, True, 1, (2, 4096, 3, 3)),
+])
+def test_bn_act_vs_torch(dtype, relu, res, pool, shape):
+    from coin_amd import layers as L
+
+    g = torch.Generator().manual_seed(sum(shape) + pool)
+    n, c, h, w = shape
+    x = (torch.randn(shape, generator=g) * 2 + torch.randn(1, c, 1, 1, generator=g) * 3).to(dtype)
+    r = torch.randn(shape, generator=g).to(dtype) if res else None
+    bn = torch.nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5, generator=g)
+        bn.bias.normal_(0, 0.3, generator=g)
+        bn.running_mean.normal_(0, 1, generator=g)
+        bn.running_var.uniform_(0.5, 2, generator=g)
+    ref_bn = torch.nn.BatchNorm2d(c).double()
+    ref_bn.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+    xr = x.double().requires_grad_(True)
+    rr = r.double().requires_grad_(True) if res else None
+    y = ref_bn(xr)
+    if res:
+        y = y + rr
+    if relu:
+        y = F.relu(y)
+    if pool == 2:
+        y = F.avg_pool2d(y, 2)
+    dy = torch.randn(y.shape, generator=g).to(dtype)
+    y.backward(dy.double())
+    bn = bn.cuda()
+    xd = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rd = r.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True) if res else None
+    out = L.bn_act(xd, bn, relu, rd, pool)
+    out.backward(dy.cuda())
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    torch.testing.assert_close(out.detach().cpu().double(), y.detach(), rtol=tol, atol=tol)
+    gtol = 1e-3 if dtype == torch.float32 else 5e-2
+    scale = float(xr.grad.abs().max())
+    torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=gtol, atol=gtol * scale)
+    torch.testing.assert_close(bn.weight.grad.cpu().double(), ref_bn.weight.grad, rtol=gtol, atol=gtol * float(ref_bn.weight.grad.abs().max()))
+    torch.testing.assert_close(bn.bias.grad.cpu().double(), ref_bn.bias.grad, rtol=gtol, atol=gtol * float(ref_bn.bias.grad.abs().max()))
+    if res:
+        torch.testing.assert_close(rd.grad.cpu().double(), rr.grad, rtol=gtol, atol=gtol)
+    torch.testing.assert_close(bn.running_mean.cpu().double(), ref_bn.running_mean, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(bn.running_var.cpu().double(), ref_bn.running_var, rtol=2e-3, atol=2e-3)
+    assert int(bn.num_batches_tracked) == 1
+
+
+def test_avg_pool2_vs_torch():
+    from coin_amd import layers as L
+
+    g = torch.Generator().manual_seed(3)
+    for shape in [(2, 16, 14, 14), (3, 8, 9, 11), (1, 1024, 100, 167)]:
+        x = torch.randn(shape, generator=g)
+        xr = x.double().requires_grad_(True)
+        y = F.avg_pool2d(xr, 2)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy.double())
+        xd = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        out = L.avg_pool2(xd)
+        out.backward(dy.cuda())
+        torch.testing.assert_close(out.detach().cpu().double(), y.detach(), rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-6, atol=1e-6)

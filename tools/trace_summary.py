@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Summarise the steady-state tail of a rocprofv3 --kernel-trace CSV (per-dispatch rows) into a small per-kernel table.
+
+    python tools/trace_summary.py <kernel_trace.csv> <out.csv> [--window-ms 300]
+
+rocprofv3's own --stats aggregates the whole process, i.e. including MIOpen's one-off solver search and the warm-up
+steps; the bench's timed steps are the LAST thing the process does, so the last `window-ms` of device time are taken.
+"""
+import argparse
+import csv
+import collections
+
+ap = argparse.ArgumentParser()
+ap.add_argument("trace")
+ap.add_argument("out")
+ap.add_argument("--window-ms", type=float, default=300.0)
+a = ap.parse_args()
+rows = []
+with open(a.trace) as f:
+    r = csv.DictReader(f)
+    for row in r:
+        rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), row["Kernel_Name"]))
+end = max(e for _, e, _ in rows)
+lo = end - int(a.window_ms * 1e6)
+agg = collections.defaultdict(lambda: [0, 0])
+busy = 0
+for s, e, n in rows:
+    if s >= lo:
+        agg[n][0] += 1
+        agg[n][1] += e - s
+        busy += e - s
+items = sorted(agg.items(), key=lambda kv: -kv[1][1])
+with open(a.out, "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "PercentageOfBusy", f"window_ms={a.window_ms}", f"busy_ms={busy/1e6:.3f}"])
+    for n, (c, t) in items:
+        w.writerow([n[:160], c, t, t // c, f"{100.0*t/busy:.2f}"])
+print(f"window {a.window_ms} ms: busy {busy/1e6:.1f} ms over {len(items)} kernels")
+for n, (c, t) in items[:40]:
+    print(f"{t/1e6:8.2f} ms {100.0*t/busy:5.1f}% n={c:5d} avg={t/c/1e3:9.1f}us {n[:100]}")
