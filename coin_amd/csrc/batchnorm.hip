@@ -57,6 +57,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restric
     for (int i = 0; i < V; ++i) s1[i] = s2[i] = 0.f;
     Ld<T>::load(x + (size_t)cg * V, piv);
     if (active) {
+#pragma unroll 4
       for (int64_t r = (int64_t)blockIdx.x * rpi + slot; r < M; r += (int64_t)gridDim.x * rpi) {
         float v[V];
         Ld<T>::load(x + (size_t)r * C + (size_t)cg * V, v);
@@ -84,26 +85,44 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restric
           s2[i] += o[V + i];
         }
       }
+      float* __restrict__ part = sums + (size_t)blockIdx.x * 2 * C;  // per-block partials: no atomics, fixed order
 #pragma unroll
       for (int i = 0; i < V; ++i) {
-        atomicAdd(sums + cg * V + i, s1[i]);
-        atomicAdd(sums + C + cg * V + i, s2[i]);
+        part[cg * V + i] = s1[i];
+        part[C + cg * V + i] = s2[i];
       }
     }
     __syncthreads();
   }
 }
 
-// mean / rstd from the pivoted sums; also the running-statistics update (one thread per channel)
+// mean / rstd from the per-block pivoted partial sums (+ running statistics).  Block = 64 channels x 4 waves; each wave
+// sums every 4th partial with coalesced 256-byte reads, the four are combined through LDS in a fixed order.
 template <typename T>
-__global__ void bn_finalize_kernel(const T* __restrict__ x, const float* __restrict__ sums, int64_t M, int C, float eps,
-                                   float momentum, float* __restrict__ mean, float* __restrict__ rstd,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const T* __restrict__ x, const float* __restrict__ sums, int nparts, int64_t M,
+                                                           int C, float eps, float momentum, float* __restrict__ mean,
+                                                           float* __restrict__ rstd, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var) {
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float a1 = 0.f, a2 = 0.f;
+  if (c < C) {
+#pragma unroll 4
+    for (int p = wave; p < nparts; p += 4) {
+      a1 += sums[(size_t)p * 2 * C + c];
+      a2 += sums[(size_t)p * 2 * C + C + c];
+    }
+  }
+  red[0][wave][lane] = a1;
+  red[1][wave][lane] = a2;
+  __syncthreads();
+  if (wave != 0 || c >= C) return;
+  a1 = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+  a2 = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
   const float piv = (float)x[c];
-  const float m1 = sums[c] / (float)M;
-  const float var = fmaxf(sums[C + c] / (float)M - m1 * m1, 0.f);
+  const float m1 = a1 / (float)M;
+  const float var = fmaxf(a2 / (float)M - m1 * m1, 0.f);
   const float mu = piv + m1;
   mean[c] = mu;
   rstd[c] = 1.0f / sqrtf(var + eps);
@@ -239,6 +258,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __re
       db[i] = dg[i] = 0.f;
     }
     if (active) {
+#pragma unroll 2
       for (int64_t r = (int64_t)blockIdx.x * rpi + slot; r < M; r += (int64_t)gridDim.x * rpi) {
         const int w = (int)(r % W);
         const int h = (int)((r / W) % H);
@@ -268,14 +288,29 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __re
           dg[i] += o[V + i];
         }
       }
+      float* __restrict__ part = dsums + (size_t)(blockIdx.x + 1) * 2 * C;  // slot 0 holds the final sums
 #pragma unroll
       for (int i = 0; i < V; ++i) {
-        atomicAdd(dsums + cg * V + i, db[i]);
-        atomicAdd(dsums + C + cg * V + i, dg[i]);
+        part[cg * V + i] = db[i];
+        part[C + cg * V + i] = dg[i];
       }
     }
     __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict__ dsums, int nparts, int C) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  float a = 0.f;
+  if (i < 2 * C) {
+#pragma unroll 4
+    for (int p = 1 + wave; p <= nparts; p += 4) a += dsums[(size_t)p * 2 * C + i];
+  }
+  red[wave][lane] = a;
+  __syncthreads();
+  if (wave == 0 && i < 2 * C) dsums[i] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
 // dx = gamma * rstd * (g - dbeta/M - xhat * dgamma/M);  d_residual = g (pool == 1 with residual)
@@ -406,15 +441,13 @@ extern "C" int coin_bn_stats(const void* x, int N, int H, int W, int C, float ep
   if (!sums_workspace || !mean || !rstd) return COIN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int64_t M = (int64_t)N * H * W;
-  hipError_t e = hipMemsetAsync(sums_workspace, 0, sizeof(float) * 2 * C, st);
-  if (e != hipSuccess) return (int)e;
   const int v = dtype == COIN_F32 ? 4 : 8;
   const int ncg = C / v, tpr = ncg < BN_THREADS ? ncg : BN_THREADS, rpi = BN_THREADS / tpr;
   int64_t g = (M + rpi - 1) / rpi;
-  if (g > 2048) g = 2048;
+  if (g > COIN_BN_MAX_PARTS) g = COIN_BN_MAX_PARTS;
   const size_t lds = sizeof(float) * BN_THREADS * 2 * v;
 #define GO(T) bn_stats_kernel<T><<<(int)g, BN_THREADS, lds, st>>>((const T*)x, M, C, sums_workspace); \
-  bn_finalize_kernel<T><<<(C + 255) / 256, 256, 0, st>>>((const T*)x, sums_workspace, M, C, eps, momentum, mean, rstd, running_mean, running_var)
+  bn_finalize_kernel<T><<<(C + 63) / 64, 256, 0, st>>>((const T*)x, sums_workspace, (int)g, M, C, eps, momentum, mean, rstd, running_mean, running_var)
   BN_DISPATCH(dtype, GO(float), GO(bf16_t));
 #undef GO
   return coin_launch_status();
@@ -446,15 +479,14 @@ extern "C" int coin_bn_bwd(const void* x, const void* dy, const void* y, const f
   if (relu && pool == 1 && !y) return COIN_EINVAL;  // the ReLU mask is read from the saved output
   if (pool == 2 && d_residual) return COIN_ESHAPE;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(dsums, 0, sizeof(float) * 2 * C, st);
-  if (e != hipSuccess) return (int)e;
   const int v = dtype == COIN_F32 ? 4 : 8;
   const int64_t M = (int64_t)N * H * W;
   const int ncg = C / v, tpr = ncg < BN_THREADS ? ncg : BN_THREADS, rpi = BN_THREADS / tpr;
   int64_t g = (M + rpi - 1) / rpi;
-  if (g > 2048) g = 2048;
+  if (g > COIN_BN_MAX_PARTS) g = COIN_BN_MAX_PARTS;
   const size_t lds = sizeof(float) * BN_THREADS * 2 * v;
 #define GO(T) bn_bwd_reduce_kernel<T><<<(int)g, BN_THREADS, lds, st>>>((const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, beta, N, H, W, C, relu, pool, dsums); \
+  bn_bwd_finalize_kernel<<<(2 * C + 63) / 64, 256, 0, st>>>(dsums, (int)g, C); \
   bn_bwd_dx_kernel<T><<<stream_grid(M * ncg), BN_THREADS, 0, st>>>((const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, beta, dsums, N, H, W, C, relu, pool, (T*)dx, (T*)d_residual)
   BN_DISPATCH(dtype, GO(float), GO(bf16_t));
 #undef GO

@@ -319,6 +319,9 @@ def rpn_losses(logits: torch.Tensor, labels: torch.Tensor, deltas: torch.Tensor,
 
 
 # --------------------------------------------------------------------------- fused BatchNorm / pooling (NHWC)
+BN_MAX_PARTS = 512  # COIN_BN_MAX_PARTS in include/coin_hip.h
+
+
 def _nhwc(t: torch.Tensor, name: str):
     if t.dim() != 4 or not t.is_contiguous():
         raise CoinHipError(f"{name} must be a contiguous [N,H,W,C] tensor")
@@ -330,7 +333,7 @@ def bn_stats(x: torch.Tensor, eps: float, momentum: float, running_mean: Optiona
     """Batch mean / rstd of x [N,H,W,C] (+ in-place running-statistics update)."""
     _dev(x, running_mean, running_var)
     n, h, w, c = _nhwc(x, "x")
-    ws = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    ws = torch.empty(BN_MAX_PARTS * 2 * c, dtype=torch.float32, device=x.device)
     mean = torch.empty(c, dtype=torch.float32, device=x.device)
     rstd = torch.empty(c, dtype=torch.float32, device=x.device)
     check(_lib.lib().coin_bn_stats(_p(x), n, h, w, c, float(eps), float(momentum), _p(ws), _p(mean), _p(rstd), _p(running_mean),
@@ -357,12 +360,12 @@ def bn_bwd(x: torch.Tensor, dy: torch.Tensor, y: Optional[torch.Tensor], mean, r
     n, h, w, c = _nhwc(x, "x")
     if not dy.is_contiguous() or dy.dtype != x.dtype:
         raise CoinHipError("dy must be contiguous NHWC of x's dtype")
-    dsums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    dsums = torch.empty((BN_MAX_PARTS + 1) * 2 * c, dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     dres = torch.empty_like(dy) if want_dres else None
     check(_lib.lib().coin_bn_bwd(_p(x), _p(dy), _p(y), _p(mean), _p(rstd), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")), n, h, w, c,
                                  int(relu), int(pool), _p(dsums), _p(dx), _p(dres), _dt(x), _stream()), "coin_bn_bwd")
-    return dx, dsums[c:], dsums[:c], dres
+    return dx, dsums[c:2 * c], dsums[:c], dres
 
 
 def avgpool2_fwd(x: torch.Tensor) -> torch.Tensor:

@@ -109,13 +109,16 @@ int coin_bias_act_bwd(const void* dC, const void* C, void* dZ, int ld, int M, in
  *
  * coin_bn_stats     : batch mean and 1/sqrt(biased var + eps) over N*H*W (fp32, pivoted sums), and the
  *                     nn.BatchNorm2d running-statistics update (momentum, unbiased variance) when
- *                     running_mean/var are non-NULL.  sums_workspace: 2*C floats (contents undefined).
+ *                     running_mean/var are non-NULL.  sums_workspace: COIN_BN_MAX_PARTS*2*C floats (contents
+ *                     undefined): per-workgroup partial sums combined in a fixed order (no atomics, reproducible).
  * coin_bn_apply_fwd : y = pool( relu?( (x-mean)*rstd*gamma + beta [+ residual] ) ); pool in {1,2};
  *                     pool == 2 writes y [N,H/2,W/2,C] (floor, as nn.AvgPool2d(2)); residual requires pool == 1.
- * coin_bn_bwd       : given dy (shape of y) computes dsums[0..C) = dbeta, dsums[C..2C) = dgamma, dx (shape of x)
+ * coin_bn_bwd       : given dy (shape of y) computes dsums[0..C) = dbeta, dsums[C..2C) = dgamma (dsums must hold
+ *                     (COIN_BN_MAX_PARTS+1)*2*C floats: the result followed by the partial sums), dx (shape of x)
  *                     and, if d_residual != NULL, d_residual = dy * relu'  (shape of y, pool == 1).
  *                     `y` (the saved forward output) supplies the ReLU mask when relu && pool == 1.
  * ---------------------------------------------------------------------------------------- */
+#define COIN_BN_MAX_PARTS 512
 int coin_bn_stats(const void* x, int N, int H, int W, int C, float eps, float momentum, float* sums_workspace,
                   float* mean, float* rstd, float* running_mean, float* running_var, int dtype, void* stream);
 int coin_bn_apply_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
