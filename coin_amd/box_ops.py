@@ -26,16 +26,17 @@ class Matcher:
         self.thresholds, self.labels, self.allow_low_quality_matches = th, list(labels), allow_low_quality_matches
 
     def __call__(self, iou: torch.Tensor):
+        """-> (matched gt index [P] int64, label [P] int8).  Pure elementwise / reduction ops: no host sync."""
         if iou.numel() == 0:
             n = iou.size(1)
             return iou.new_zeros((n,), dtype=torch.int64), iou.new_full((n,), self.labels[0], dtype=torch.int8)
         vals, matches = iou.max(dim=0)
-        labels = matches.new_full(matches.size(), 1, dtype=torch.int8)
+        labels = torch.ones_like(matches, dtype=torch.int8)
         for l, lo, hi in zip(self.labels, self.thresholds[:-1], self.thresholds[1:]):
-            labels[(vals >= lo) & (vals < hi)] = l
+            labels = torch.where((vals >= lo) & (vals < hi), torch.full_like(labels, l), labels)
         if self.allow_low_quality_matches:
             best_per_gt = iou.max(dim=1, keepdim=True).values
-            labels[(iou == best_per_gt).any(dim=0)] = 1
+            labels = torch.where((iou == best_per_gt).any(dim=0), torch.ones_like(labels), labels)
         return matches, labels
 
 
@@ -48,6 +49,27 @@ def subsample_labels(labels: torch.Tensor, num_samples: int, positive_fraction: 
     p1 = torch.randperm(positive.numel(), device=positive.device)[:num_pos]
     p2 = torch.randperm(negative.numel(), device=negative.device)[:num_neg]
     return positive[p1], negative[p2]
+
+
+def sample_masks(cls: torch.Tensor, num_samples: int, positive_fraction: float, bg_label: int):
+    """Sync-free form of `subsample_labels` for a batch: cls [N, M] (-1 = ignore, bg_label = negative, else positive) ->
+    boolean masks (chosen_pos, chosen_neg), each row a uniformly random subset with
+    |pos| = min(#pos, int(num_samples*positive_fraction)), |neg| = min(#neg, num_samples - |pos|).
+    One random key per element and ONE sort; no data-dependent shapes, so nothing is read back to the host.  The random
+    stream differs from torch.randperm's (the reference's), the distribution does not."""
+    n, m = cls.shape
+    pos = (cls != -1) & (cls != bg_label)
+    neg = cls == bg_label
+    tier = torch.where(pos, 0.0, torch.where(neg, 2.0, 4.0))
+    keys = torch.rand((n, m), device=cls.device) + tier
+    order = keys.argsort(dim=1)
+    rank = torch.empty_like(order)
+    rank.scatter_(1, order, torch.arange(m, device=cls.device).expand(n, m))
+    cnt_pos = pos.sum(dim=1, keepdim=True)
+    n_pos = cnt_pos.clamp(max=int(num_samples * positive_fraction))
+    chosen_pos = pos & (rank < n_pos)
+    chosen_neg = neg & ((rank - cnt_pos) < (num_samples - n_pos))
+    return chosen_pos, chosen_neg
 
 
 class Box2BoxTransform:
@@ -130,9 +152,19 @@ def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, i
     return nms(boxes + offsets[:, None], scores, iou_threshold)
 
 
+class PackedProposals:
+    """Fixed-shape RPN output of the sync-free path: boxes [N,P,4], logits [N,P], valid [N,P] (bool)."""
+
+    def __init__(self, boxes, logits, valid, image_sizes):
+        self.boxes, self.logits, self.valid, self.image_sizes = boxes, logits, valid, image_sizes
+
+    def __len__(self):
+        return self.boxes.shape[0]
+
+
 @torch.no_grad()
 def find_top_rpn_proposals(proposals: torch.Tensor, logits: torch.Tensor, image_sizes: List[Tuple[int, int]], nms_thresh: float,
-                           pre_nms_topk: int, post_nms_topk: int, min_box_size: float, training: bool) -> List[Instances]:
+                           pre_nms_topk: int, post_nms_topk: int, min_box_size: float, training: bool, packed: bool = False):
     """Single-level detectron2 find_top_rpn_proposals, batched: top-k -> clip -> drop empties -> NMS -> top-k.
     proposals [N, A, 4], logits [N, A].  One host sync (the per-image keep counts)."""
     n, a = logits.shape
@@ -140,7 +172,7 @@ def find_top_rpn_proposals(proposals: torch.Tensor, logits: torch.Tensor, image_
     top_logits, idx = logits.float().sort(descending=True, dim=1)
     top_logits, idx = top_logits[:, :k], idx[:, :k]
     boxes = torch.gather(proposals.float(), 1, idx.unsqueeze(-1).expand(-1, -1, 4))
-    if training and not bool(torch.isfinite(boxes).all() & torch.isfinite(top_logits).all()):
+    if training and not packed and not bool(torch.isfinite(boxes).all() & torch.isfinite(top_logits).all()):
         raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")
     hw = torch.tensor(image_sizes, dtype=torch.float32, device=boxes.device)  # [N, 2] (h, w)
     wmax, hmax = hw[:, 1].view(n, 1), hw[:, 0].view(n, 1)
@@ -154,6 +186,14 @@ def find_top_rpn_proposals(proposals: torch.Tensor, logits: torch.Tensor, image_
     top_logits = torch.gather(top_logits, 1, order)
     counts = valid.sum(dim=1).to(torch.int32)
     keep, num = K.nms_batched(boxes, counts, nms_thresh, post_nms_topk)
+    if packed:
+        # fixed-shape result, nothing read back: [N, post_nms_topk] rows + a validity mask
+        p = min(post_nms_topk, keep.shape[1])
+        ki = keep[:, :p].long().clamp_(min=0, max=boxes.shape[1] - 1)
+        ok = torch.arange(p, device=boxes.device).unsqueeze(0) < num.unsqueeze(1)
+        pb = torch.gather(boxes, 1, ki.unsqueeze(-1).expand(-1, -1, 4))
+        pl = torch.gather(top_logits, 1, ki)
+        return PackedProposals(torch.where(ok.unsqueeze(-1), pb, torch.zeros_like(pb)), torch.where(ok, pl, torch.full_like(pl, -1e4)), ok, image_sizes)
     num_host = num.tolist()
     out = []
     for i, size in enumerate(image_sizes):

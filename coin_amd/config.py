@@ -364,6 +364,7 @@ def add_config(cfg: CfgNode) -> None:
     # architecture overrides for small-scale tests (0 / [] = take the CLIP architecture of MODEL.TEACHER_OFFLINE.TYPE)
     _C.AMD.ARCH = CN({"LAYERS": [], "WIDTH": 0, "TEXT_WIDTH": 0, "TEXT_LAYERS": 0, "TEXT_HEADS": 0, "TEXT_DIM": 0,
                       "CONTEXT_LENGTH": 77, "VOCAB_SIZE": 49408})
+    _C.AMD.SYNC_FREE = True            # pre_train step without host<->device round trips (random-key sampling)
     _C.AMD.FIXED_ROI_SAMPLER = False   # benchmark mode of SURVEY §8d: exactly 128 fg + 384 bg per view
 
 

@@ -2,16 +2,16 @@
 // batched_nms: coin/modeling/proposal_generator/rpn.py:113-115, coin/modeling/roi_heads/fast_rcnn.py:164).
 //
 // Boxes arrive sorted by descending score.  Kernel 1 builds the upper-triangular suppression bit
-// matrix (one 64-bit word per box x 64-box column block).  Kernel 2 resolves it with ONE wavefront per
+// matrix (one 64-bit word per box x 64-box column block).  Kernel 2 resolves it with one workgroup per
 // image, two-level: inside a 64-box block the greedy order is resolved on a single 64-bit word per lane
-// with wave shuffles (no memory traffic); the rows of the kept boxes are then OR-ed into the running
+// with wave shuffles (no memory traffic); the rows of the block's boxes are then OR-ed into the running
 // "removed" bitmap with independent, coalesced loads.  No host round trip (torchvision resolves the
 // matrix on the CPU).
 #include "common.h"
 
 namespace {
 
-constexpr int NMS_MAX_WORDS_PER_LANE = 4;  // up to 64*64*4 = 16384 boxes per image
+constexpr int NMS_MAX_WORDS = 256;  // one removed-bitmap word per thread of the scan block: up to 16384 boxes per image
 
 __device__ __forceinline__ float box_iou(const f32x4 a, const f32x4 b) {
   const float iw = fminf(a[2], b[2]) - fmaxf(a[0], b[0]);
@@ -45,59 +45,60 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
   mask[((size_t)b * n_max + row) * col_blocks + cb] = bits;
 }
 
-// grid: B; block: 64 (one wave)
-__global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
-                                                      const int* __restrict__ counts, int n_max, int col_blocks,
-                                                      int max_keep, int* __restrict__ keep, int* __restrict__ num_keep) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+// grid: B; block: 256.  Thread t owns 64-bit word t of the running "removed" bitmap (n_max <= 256*64 = 16384).
+// Per 64-box block: wave 0 resolves the greedy order inside the block on the diagonal word with wave shuffles (registers
+// only); then every thread ORs the mask rows of the block's boxes into its word.  The 64 row reads are issued
+// unconditionally (masked by the kept bits afterwards): they do not depend on each other, are coalesced across threads
+// and together read the bit matrix exactly once.
+__global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
+                                                       const int* __restrict__ counts, int n_max, int col_blocks,
+                                                       int max_keep, int* __restrict__ keep, int* __restrict__ num_keep) {
+  __shared__ unsigned long long s_rw, s_kept;
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int n = counts[b];
   const unsigned long long* __restrict__ m = mask + (size_t)b * n_max * col_blocks;
   int* __restrict__ kout = keep + (size_t)b * n_max;
-  unsigned long long remv[NMS_MAX_WORDS_PER_LANE] = {0ull, 0ull, 0ull, 0ull};  // lane owns words lane + 64*k
+  unsigned long long remv = 0ull;
   int nk = 0;
   const int nblk = (n + 63) >> 6;
   for (int blk = 0; blk < nblk && nk < max_keep; ++blk) {
-    // removed-word of this block lives in lane (blk & 63), slot (blk >> 6)
-    unsigned long long rw = 0ull;
-#pragma unroll
-    for (int k = 0; k < NMS_MAX_WORDS_PER_LANE; ++k)
-      if ((blk >> 6) == k) rw = remv[k];
-    rw = __shfl(rw, blk & 63, 64);
-    const int row = blk * 64 + lane;
-    const unsigned long long diag = row < n ? m[(size_t)row * col_blocks + blk] : 0ull;
-    unsigned long long kept = 0ull;
-    const int lim = (n - blk * 64) < 64 ? (n - blk * 64) : 64;
-    for (int j = 0; j < lim; ++j) {
-      const unsigned long long dj = __shfl(diag, j, 64);  // wave-uniform
-      if (!((rw >> j) & 1ull)) {
-        kept |= 1ull << j;
-        rw |= dj;
-      }
-    }
-    // emit kept indices in order
-    const int cnt = __popcll(kept);
-    if ((kept >> lane) & 1ull) {
-      const int pos = nk + __popcll(kept & ((1ull << lane) - 1ull));
-      if (pos < max_keep) kout[pos] = blk * 64 + lane;
-    }
-    nk += cnt;
-    // OR the rows of the kept boxes into the running bitmap (words of later blocks only)
-#pragma unroll
-    for (int k = 0; k < NMS_MAX_WORDS_PER_LANE; ++k) {
-      const int w = lane + 64 * k;
-      if (w > blk && w < col_blocks) {
-        unsigned long long acc = 0ull;
-        unsigned long long kk = kept;
-        while (kk) {
-          const int j = __ffsll((long long)kk) - 1;
-          kk &= kk - 1;
-          acc |= m[(size_t)(blk * 64 + j) * col_blocks + w];
+    if (t == blk) s_rw = remv;
+    __syncthreads();
+    if (wave == 0) {
+      unsigned long long rw = s_rw;
+      const int row = blk * 64 + lane;
+      const unsigned long long diag = row < n ? m[(size_t)row * col_blocks + blk] : 0ull;
+      unsigned long long kept = 0ull;
+      const int lim = (n - blk * 64) < 64 ? (n - blk * 64) : 64;
+      for (int j = 0; j < lim; ++j) {
+        const unsigned long long dj = __shfl(diag, j, 64);
+        if (!((rw >> j) & 1ull)) {
+          kept |= 1ull << j;
+          rw |= dj;
         }
-        remv[k] |= acc;
       }
+      if ((kept >> lane) & 1ull) {
+        const int pos = nk + __popcll(kept & ((1ull << lane) - 1ull));
+        if (pos < max_keep) kout[pos] = row;
+      }
+      if (lane == 0) s_kept = kept;
     }
+    __syncthreads();
+    const unsigned long long kept = s_kept;
+    if (t > blk && t < col_blocks) {
+      unsigned long long acc = 0ull;
+#pragma unroll 16
+      for (int j = 0; j < 64; ++j) {
+        int row = blk * 64 + j;
+        row = row < n_max ? row : n_max - 1;
+        const unsigned long long v = m[(size_t)row * col_blocks + t];
+        acc |= v & (0ull - ((kept >> j) & 1ull));
+      }
+      remv |= acc;
+    }
+    nk += __popcll(kept);
   }
-  if (lane == 0) num_keep[b] = nk < max_keep ? nk : max_keep;
+  if (t == 0) num_keep[b] = nk < max_keep ? nk : max_keep;
 }
 
 }  // namespace
@@ -112,7 +113,7 @@ extern "C" int coin_nms_batched(const float* boxes, const int* counts, int B, in
   if (B < 0 || n_max < 0 || max_keep < 0) return COIN_EINVAL;
   if (B == 0 || n_max == 0) return COIN_OK;
   if (!boxes || !counts || !workspace || !keep || !num_keep) return COIN_EINVAL;
-  if (n_max > 64 * 64 * NMS_MAX_WORDS_PER_LANE) return COIN_ESHAPE;
+  if (n_max > 64 * NMS_MAX_WORDS) return COIN_ESHAPE;
   if ((uintptr_t)boxes & 15) return COIN_EALIGN;
   const int cb = (n_max + 63) / 64;
   hipStream_t st = (hipStream_t)stream;
@@ -120,6 +121,6 @@ extern "C" int coin_nms_batched(const float* boxes, const int* counts, int B, in
   nms_mask_kernel<<<grid, 64, 0, st>>>(boxes, counts, n_max, iou_threshold, (unsigned long long*)workspace, cb);
   int rc = coin_launch_status();
   if (rc) return rc;
-  nms_scan_kernel<<<B, 64, 0, st>>>((const unsigned long long*)workspace, counts, n_max, cb, max_keep, keep, num_keep);
+  nms_scan_kernel<<<B, 256, 0, st>>>((const unsigned long long*)workspace, counts, n_max, cb, max_keep, keep, num_keep);
   return coin_launch_status();
 }

@@ -455,7 +455,9 @@ class SgdTable:
         self._dev.copy_(host, non_blocking=False)
 
     def step(self, grads: Sequence[torch.Tensor], momentum: float, inv_loss_scale: float = 1.0,
-             lrs: Optional[Sequence[float]] = None):
+             lrs: Optional[Sequence[float]] = None, lr_scale: float = 1.0):
+        """`lrs` (re)defines the per-tensor base learning rates held in the device table (re-uploaded only when they or the
+        gradient pointers change); `lr_scale` is the per-step schedule factor passed as a kernel argument."""
         key = (tuple(g.data_ptr() for g in grads), tuple(lrs) if lrs is not None else tuple(self.lrs))
         if lrs is not None:
             self.lrs = list(lrs)
@@ -463,7 +465,7 @@ class SgdTable:
             self._upload(grads)
             self._grads_key = key
         check(_lib.lib().coin_sgd_step(_p(self._dev), len(self.params), self.max_numel, float(momentum),
-                                       float(inv_loss_scale), int(self.first), _stream()), "coin_sgd_step")
+                                       float(inv_loss_scale), float(lr_scale), int(self.first), _stream()), "coin_sgd_step")
         self.first = False
 
 

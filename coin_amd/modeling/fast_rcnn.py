@@ -163,6 +163,42 @@ class FastRCNNOutputLayers(nn.Module):
         norm = float(normalizer) if normalizer is not None else float(max(gt_classes.numel(), 1))
         return L.box_reg_l1(proposal_boxes, gt_boxes, pred_deltas, gt_classes, self.num_classes, self.box2box_transform.weights, norm)
 
+    # ------------------------------------------------------------------ pre_train losses on packed samples (sync-free)
+    def losses_packed(self, predictions, ps, update_prototype=False):
+        """fast_rcnn.py:366-438 for the fixed-shape sample layout: the same three losses, written with per-row labels /
+        weights instead of per-image fg/bg splits (every reduction is a permutation-invariant mean or sum) and with the
+        data-dependent branches (`sum(per_image_fg_nums) != 0`) turned into device-side selects."""
+        (scores, lta), deltas, feats = predictions
+        kc = self.num_classes + 1
+        cls = ps.gt_classes
+        valid = cls >= 0
+        is_fg = valid & (cls < self.num_classes)
+        n_valid = valid.sum().clamp(min=1).float()
+        any_fg = is_fg.any()
+        labels = cls.clamp(min=0)
+        w = torch.where(is_fg, 1.0, float(self.classes_weight[-1])) * valid.float()
+        if self.loss_type != "MILCrossEntropy":
+            raise NotImplementedError("MILFocalLoss is not on the HIP path")
+        if self.dataset != ("cliparttrain",):
+            total = L.mil_cross_entropy(scores, labels=labels, weights=w, avg_positives=True, reduction="sum")
+        else:
+            tgt = F.one_hot(labels, kc).float() * torch.where(is_fg, ps.gt_probs.max(1)[0], torch.ones_like(w)).unsqueeze(1)
+            total = L.mil_cross_entropy(scores, target=tgt, weights=w, avg_positives=False, reduction="sum")
+        losses = {"loss_text_align": lta, "loss_cls": torch.where(any_fg, total / n_valid, torch.zeros_like(total))}
+        if update_prototype:
+            with torch.no_grad():
+                fn = feats.detach().float()
+                fn = fn / fn.norm(dim=1, keepdim=True)
+                oh = F.one_hot(labels, kc).float() * valid.float().unsqueeze(1)
+                te = self.text_encoder
+                new = _prototype_ema(te.per_class_feat.data, fn, oh, self.prototype_update_rate)
+                te.per_class_feat.data = torch.where(any_fg, new, te.per_class_feat.data)
+        # box regression: sum over fg rows / number of sampled rows (fast_rcnn.py:646)
+        reg = L.box_reg_l1(ps.boxes, ps.gt_boxes, deltas, torch.where(is_fg, cls, torch.full_like(cls, -1)), self.num_classes,
+                           self.box2box_transform.weights, 1.0)
+        losses["loss_box_reg"] = reg / n_valid
+        return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
+
     # ------------------------------------------------------------------ losses (fast_rcnn.py:355-571)
     def losses(self, predictions, proposals, merge_module, branch, update_prototype=False):
         kc = self.num_classes + 1

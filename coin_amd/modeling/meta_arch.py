@@ -38,6 +38,11 @@ class OpenVocabularyRCNN(nn.Module):
         self.input_format, self.vis_period = input_format, vis_period
         self.set_compute_dtype(compute_dtype)
 
+    def set_sync_free(self, flag: bool):
+        """Sync-free pre_train step (random-key sampling, fixed shapes): see DualTeacherRPN.sync_free."""
+        if self.proposal_generator is not None:
+            self.proposal_generator.sync_free = bool(flag)
+
     def set_compute_dtype(self, dtype: torch.dtype):
         assert dtype in (torch.bfloat16, torch.float32)
         self.compute_dtype = dtype
@@ -52,7 +57,11 @@ class OpenVocabularyRCNN(nn.Module):
         return cls(backbone=backbone, roi_heads=roi_heads, pixel_mean=cfg.INPUT.TEACHER_OFFLINE.PIXEL_MEAN,
                    pixel_std=cfg.INPUT.TEACHER_OFFLINE.PIXEL_STD, device=cfg.MODEL.DEVICE, input_format=cfg.INPUT.FORMAT,
                    vis_period=cfg.VIS_PERIOD, proposal_generator=build_proposal_generator(cfg, backbone.output_shape()),
-                   compute_dtype=torch.bfloat16 if cfg.AMD.COMPUTE_DTYPE == "bf16" else torch.float32)
+                   compute_dtype=torch.bfloat16 if cfg.AMD.COMPUTE_DTYPE == "bf16" else torch.float32)._with_sync_free(cfg.AMD.SYNC_FREE)
+
+    def _with_sync_free(self, flag):
+        self.set_sync_free(flag)
+        return self
 
     @property
     def device(self):

@@ -13,11 +13,19 @@ import torch
 from torch import nn
 
 from .. import layers as L
-from ..box_ops import Matcher, add_ground_truth_to_proposals, subsample_labels
+from ..box_ops import Matcher, PackedProposals, add_ground_truth_to_proposals, sample_masks, subsample_labels
 from ..registry import ROI_HEADS_REGISTRY
 from ..structures import Boxes, Instances, ShapeSpec, pairwise_iou
 from .fast_rcnn import FastRCNNOutputLayers
 from .text_encoder import TEXT_DIMS, build_text_encoder
+
+
+class PackedSamples:
+    """Sampled RoIs of the sync-free pre_train path, fixed shape [N*R]: rows are (fg..., bg..., invalid...) per image.
+    gt_classes: fg class | num_classes (bg) | -1 (invalid filler when an image has fewer than R candidates)."""
+
+    def __init__(self, boxes, gt_classes, gt_boxes, gt_probs, per_image):
+        self.boxes, self.gt_classes, self.gt_boxes, self.gt_probs, self.per_image = boxes, gt_classes, gt_boxes, gt_probs, per_image
 
 
 class ROIPooler(nn.Module):
@@ -29,7 +37,9 @@ class ROIPooler(nn.Module):
         assert len(scales) == 1 and pooler_type in ("ROIAlignV2", "ROIAlign")
         self.scale, self.sampling_ratio, self.aligned = float(scales[0]), int(sampling_ratio), pooler_type == "ROIAlignV2"
 
-    def forward(self, x: List[torch.Tensor], box_lists: List[Boxes]) -> torch.Tensor:
+    def forward(self, x: List[torch.Tensor], box_lists) -> torch.Tensor:
+        if isinstance(box_lists, torch.Tensor):  # already [R, 5] rows (batch index, box)
+            return L.roi_align(x[0], box_lists, self.output_size, self.scale, self.sampling_ratio, self.aligned)
         rois = torch.cat([torch.cat([b.tensor.new_full((len(b), 1), float(i)), b.tensor], dim=1) for i, b in enumerate(box_lists)], dim=0)
         return L.roi_align(x[0], rois, self.output_size, self.scale, self.sampling_ratio, self.aligned)
 
@@ -77,6 +87,12 @@ class OpenVocabularyRes5ROIHeads(nn.Module):
 
     def forward(self, images, features, proposals, res5, attnpool, branch, merge_module=None, targets=None, update_prototype=False):
         train = self.training and branch != "test"
+        if train and branch == "pre_train" and isinstance(proposals, PackedProposals):
+            ps = self.sample_packed(proposals, targets)
+            n, r = len(proposals), ps.per_image
+            bidx = torch.arange(n, device=ps.boxes.device, dtype=ps.boxes.dtype).repeat_interleave(r).unsqueeze(1)
+            predictions = self.box_predictor(self._pooled(features, torch.cat([bidx, ps.boxes], dim=1), res5, attnpool), branch=branch)
+            return [], self.box_predictor.losses_packed(predictions, ps, update_prototype=update_prototype)
         if train:
             assert targets
             if branch == "pre_train":
@@ -112,6 +128,48 @@ class OpenVocabularyRes5ROIHeads(nn.Module):
         fg, bg = subsample_labels(gt_classes, self.batch_size_per_image, self.positive_fraction, self.num_classes)
         sampled = torch.cat([fg, bg], dim=0)
         return sampled, gt_classes[sampled]
+
+    @torch.no_grad()
+    def sample_packed(self, proposals: PackedProposals, targets) -> PackedSamples:
+        """label_and_sample_proposals(pre_train) (clip_roi_heads.py:286-340) with fixed shapes and no host round trip:
+        candidates = RPN proposals (+ validity) ++ teacher boxes, same Matcher, `sample_masks` instead of randperm."""
+        k, r = self.num_classes, self.batch_size_per_image
+        dev = proposals.boxes.device
+        gmax = max(len(t) for t in targets)
+        cand_b, cand_cls, cand_gt, cand_pr = [], [], [], []
+        for i, t in enumerate(targets):
+            g = len(t)
+            pb, pv = proposals.boxes[i], proposals.valid[i]
+            if self.proposal_append_gt:
+                pb = torch.cat([pb, t.gt_boxes.tensor])
+                pv = torch.cat([pv, torch.ones(g, dtype=torch.bool, device=dev)])
+            pad = gmax - g if self.proposal_append_gt else 0
+            if pad:
+                pb = torch.cat([pb, pb.new_zeros(pad, 4)])
+                pv = torch.cat([pv, torch.zeros(pad, dtype=torch.bool, device=dev)])
+            if g > 0:
+                idx, lab = self.proposal_matcher(pairwise_iou(t.gt_boxes, Boxes(pb)))
+                cls = torch.where(lab == 1, t.gt_classes_offline[idx], torch.full_like(idx, k))
+                gtb = torch.where((lab == 1).unsqueeze(1), t.gt_boxes.tensor[idx], pb)
+                pr = t.gt_probs_offline[idx]
+            else:
+                cls = torch.full((pb.shape[0],), k, dtype=torch.int64, device=dev)
+                gtb, pr = pb, pb.new_zeros(pb.shape[0], k + 1)
+            cand_cls.append(torch.where(pv, cls, torch.full_like(cls, -1)))
+            cand_b.append(pb)
+            cand_gt.append(gtb)
+            cand_pr.append(pr)
+        cls = torch.stack(cand_cls)                                   # [N, M]
+        boxes, gtb, prs = torch.stack(cand_b), torch.stack(cand_gt), torch.stack(cand_pr)
+        fg, bg = sample_masks(cls, r, self.positive_fraction, k)
+        # exactly r rows per image: chosen fg first, then chosen bg, then (only if short) unchosen fillers marked invalid
+        prio = torch.where(fg, 0, torch.where(bg, 1, 2))
+        sel = prio.argsort(dim=1, stable=True)[:, :r]
+        chosen = (fg | bg).gather(1, sel)
+        out_cls = torch.where(chosen, cls.gather(1, sel), torch.full_like(sel, -1))
+        g4 = sel.unsqueeze(-1).expand(-1, -1, 4)
+        return PackedSamples(boxes.gather(1, g4).reshape(-1, 4), out_cls.reshape(-1), gtb.gather(1, g4).reshape(-1, 4),
+                             prs.gather(1, sel.unsqueeze(-1).expand(-1, -1, k + 1)).reshape(-1, k + 1), min(r, sel.shape[1]))
 
     @torch.no_grad()
     def label_and_sample_proposals(self, proposals, targets, branch):

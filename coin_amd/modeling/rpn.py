@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import layers as L
-from ..box_ops import Box2BoxTransform, Matcher, cell_anchors, find_top_rpn_proposals, grid_anchors, subsample_labels
+from ..box_ops import Box2BoxTransform, Matcher, cell_anchors, find_top_rpn_proposals, grid_anchors, sample_masks, subsample_labels
 from ..registry import PROPOSAL_GENERATOR_REGISTRY
 from ..structures import Boxes, ImageList, Instances, pairwise_iou
 
@@ -74,6 +74,9 @@ class DualTeacherRPN(nn.Module):
         self.nms_thresh, self.min_box_size, self.anchor_boundary_thresh = nms_thresh, float(min_box_size), anchor_boundary_thresh
         self.loss_weight = loss_weight or {"loss_rpn_cls": 1.0, "loss_rpn_loc": 1.0, "loss_rpn_distillation": 0.1}
         self.BG_TRAIN = BG_TRAIN
+        # sync-free mode (pre_train branch): anchor sampling by random keys + one sort, fixed-shape proposals; the host
+        # never waits for the device inside the step.  Off = the reference's randperm stream (used by the golden tests).
+        self.sync_free = False
 
     @classmethod
     def from_config(cls, cfg, input_shape):
@@ -107,7 +110,10 @@ class DualTeacherRPN(nn.Module):
         losses = {}
         if self.training and branch != "test":
             assert gt_instances is not None, "RPN requires gt_instances in training!"
-            if branch == "pre_train":
+            if branch == "pre_train" and self.sync_free:
+                labels, gt_boxes = self.label_and_sample_anchors_sync_free(anchors, gt_instances)
+                losses = self.losses(anchors, logits, labels, deltas, gt_boxes)
+            elif branch == "pre_train":
                 labels, gt_boxes = self.label_and_sample_anchors(anchors, gt_instances, branch)
                 losses = self.losses(anchors, logits, labels, deltas, gt_boxes)
             elif branch in ("step_one", "step_two"):
@@ -119,7 +125,8 @@ class DualTeacherRPN(nn.Module):
                 losses.update(self.losses(anchors, logits, dlabels, None, None, teacher_probs=teacher, only_distillation=True))
             else:
                 raise NotImplementedError
-        proposals = self.predict_proposals(anchors, logits, deltas, images.image_sizes)
+        packed = self.sync_free and self.training and branch == "pre_train"
+        proposals = self.predict_proposals(anchors, logits, deltas, images.image_sizes, packed=packed)
         return proposals, losses
 
     # ------------------------------------------------------------------ labels
@@ -129,6 +136,25 @@ class DualTeacherRPN(nn.Module):
         label.scatter_(0, pos, 1)
         label.scatter_(0, neg, 0)
         return label
+
+    @torch.no_grad()
+    def label_and_sample_anchors_sync_free(self, anchors: List[Boxes], gt_instances):
+        """pre_train labelling (rpn.py:139-197) without host round trips: same matcher, sampling via `sample_masks`."""
+        a = Boxes.cat(anchors)
+        labs, boxes = [], []
+        for g in gt_instances:
+            gb = g.gt_boxes
+            if len(gb) == 0:
+                labs.append(torch.full((len(a),), -1, dtype=torch.int8, device=a.tensor.device))
+                boxes.append(torch.zeros_like(a.tensor))
+                continue
+            idx, lab = self.anchor_matcher(pairwise_iou(gb, a))
+            labs.append(lab)
+            boxes.append(gb.tensor[idx])
+        lab = torch.stack(labs)                                    # [N, A] in {-1, 0, 1}
+        pos, neg = sample_masks(lab.to(torch.int64), self.batch_size_per_image, self.positive_fraction, 0)
+        out = torch.where(pos, 1, torch.where(neg, 0, -1)).to(torch.int8)
+        return list(out), boxes
 
     @torch.no_grad()
     def label_and_sample_anchors(self, anchors: List[Boxes], gt_instances, branch):
@@ -200,13 +226,13 @@ class DualTeacherRPN(nn.Module):
 
     # ------------------------------------------------------------------ proposals
     @torch.no_grad()
-    def predict_proposals(self, anchors, logits, deltas, image_sizes):
+    def predict_proposals(self, anchors, logits, deltas, image_sizes, packed: bool = False):
         n = deltas[0].shape[0]
         a = anchors[0].tensor
         d = deltas[0].detach().reshape(-1, 4)
         boxes = self.box2box_transform.apply_deltas(d, a.unsqueeze(0).expand(n, -1, -1).reshape(-1, 4)).view(n, -1, 4)
         return find_top_rpn_proposals(boxes, logits[0].detach(), image_sizes, self.nms_thresh, self.pre_nms_topk[self.training],
-                                      self.post_nms_topk[self.training], self.min_box_size, self.training)
+                                      self.post_nms_topk[self.training], self.min_box_size, self.training, packed=packed)
 
 
 def build_proposal_generator(cfg, input_shape):

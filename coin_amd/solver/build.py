@@ -58,6 +58,7 @@ class FusedSGD:
             g = dict(g)
             g.setdefault("lr", lr)
             g.setdefault("weight_decay", weight_decay)
+            g["base_lr"] = g["lr"]  # the schedule multiplies every group by one common factor
             g["momentum"] = momentum
             assert len(g["params"]) == 1
             self.param_groups.append(g)
@@ -86,7 +87,21 @@ class FusedSGD:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
             grads.append(p.grad)
-        self._table.step(grads, self.momentum, inv_loss_scale, lrs=[g["lr"] for g in self.param_groups])
+        # lr_i(t) = base_lr_i * factor(t): the factor travels as a kernel argument, the table keeps the base rates
+        factor, uniform = None, True
+        for g in self.param_groups:
+            if g["base_lr"] != 0.0:
+                f = g["lr"] / g["base_lr"]
+                if factor is None:
+                    factor = f
+                elif abs(f - factor) > 1e-9 * max(1.0, abs(factor)):
+                    uniform = False
+                    break
+        if uniform:
+            self._table.step(grads, self.momentum, inv_loss_scale, lrs=[g["base_lr"] for g in self.param_groups],
+                             lr_scale=1.0 if factor is None else factor)
+        else:  # groups were edited independently: fall back to uploading the absolute rates
+            self._table.step(grads, self.momentum, inv_loss_scale, lrs=[g["lr"] for g in self.param_groups])
 
     def state_dict(self):
         bufs = self._table.bufs if self._table is not None else None

@@ -234,7 +234,8 @@ int coin_normalize_pad(const uint8_t* img, int h, int w, const float mean[3], co
 /* ------------------------------------------------------------------------------------------
  * Fused SGD with momentum over a table of parameter tensors (replaces the per-tensor loop of
  * torch.optim.SGD over ~170 param groups, coin/solver/build.py:96-103, engine/pre_train.py:201):
- *   g = grad * inv_loss_scale + wd * p ; buf = momentum * buf + g (buf = g on first step) ; p -= lr * buf
+ *   g = grad * inv_loss_scale + wd * p ; buf = momentum * buf + g (buf = g on first step) ; p -= lr * lr_scale * buf
+ * (`lr_scale` = the schedule factor common to all groups, so the device table is uploaded once, not every step.)
  * `table` is a DEVICE array of coin_sgd_tensor descriptors; one launch updates all of them.
  * Optionally also refreshes a bf16 shadow copy of each parameter (shadow may be NULL).
  * ---------------------------------------------------------------------------------------- */
@@ -249,7 +250,7 @@ typedef struct coin_sgd_tensor {
 } coin_sgd_tensor;
 
 int coin_sgd_step(const coin_sgd_tensor* table, int num_tensors, int64_t max_numel, float momentum,
-                  float inv_loss_scale, int first_step, void* stream);
+                  float inv_loss_scale, float lr_scale, int first_step, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Teacher EMA (replaces EnsembleTSModel.update_params, coin/modeling/meta_arch/ts_ensemble.py:39-69)

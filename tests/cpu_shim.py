@@ -113,13 +113,13 @@ class _CpuSgdTable:
         self.bufs = [torch.zeros_like(p) for p in self.params]
         self.first = True
 
-    def step(self, grads, momentum, inv_loss_scale=1.0, lrs=None):
+    def step(self, grads, momentum, inv_loss_scale=1.0, lrs=None, lr_scale=1.0):
         if lrs is not None:
             self.lrs = list(lrs)
         for p, g, b, lr, wd in zip(self.params, grads, self.bufs, self.lrs, self.wds):
             d = g * inv_loss_scale + wd * p
             b.copy_(d if self.first else momentum * b + d)
-            p.sub_(lr * b)
+            p.sub_(lr * lr_scale * b)
         self.first = False
 
 

@@ -432,3 +432,44 @@ def test_avg_pool2_vs_torch():
         out.backward(dy.cuda())
         torch.testing.assert_close(out.detach().cpu().double(), y.detach(), rtol=1e-6, atol=1e-6)
         torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------ NMS
+def test_nms_batched_vs_oracle(K):
+    from oracle import d2
+
+    g = torch.Generator().manual_seed(21)
+    counts = [1000, 0, 777, 3000, 64, 65]
+    n_max = 3000
+    boxes = torch.zeros(len(counts), n_max, 4)
+    for i, n in enumerate(counts):
+        centers = torch.rand(max(n // 6, 1), 2, generator=g) * 800
+        c = centers[torch.randint(0, centers.shape[0], (n,), generator=g)] + torch.randn(n, 2, generator=g) * 12
+        wh = torch.rand(n, 2, generator=g) * 120 + 16
+        boxes[i, :n] = torch.cat([c - wh / 2, c + wh / 2], dim=1)
+    for thr, max_keep in ((0.7, 2000), (0.5, 50)):
+        keep, num = K.nms_batched(dev(boxes), dev(torch.tensor(counts, dtype=torch.int32)), thr, max_keep)
+        keep, num = keep.cpu(), num.cpu()
+        for i, n in enumerate(counts):
+            ref = d2.nms(boxes[i, :n], -torch.arange(n, dtype=torch.float32), thr)[:max_keep]
+            assert int(num[i]) == len(ref), (i, int(num[i]), len(ref))
+            assert torch.equal(keep[i, : len(ref)].long(), ref)
+
+
+def test_nms_large_and_class_aware(K):
+    from coin_amd import box_ops
+    from oracle import d2
+
+    g = torch.Generator().manual_seed(22)
+    n = 12000
+    c = torch.rand(n, 2, generator=g) * torch.tensor([1333.0, 800.0])
+    wh = torch.rand(n, 2, generator=g) * 200 + 20
+    b = torch.cat([c - wh / 2, c + wh / 2], dim=1)
+    s = torch.rand(n, generator=g)
+    got = box_ops.nms(dev(b), dev(s), 0.7).cpu()
+    ref = d2.nms(b, s, 0.7)
+    assert torch.equal(got, ref)
+    idx = torch.randint(0, 8, (n,), generator=g)
+    got = box_ops.batched_nms(dev(b[:3000]), dev(s[:3000]), dev(idx[:3000]), 0.5).cpu()
+    ref = d2.batched_nms(b[:3000], s[:3000], idx[:3000], 0.5)
+    assert torch.equal(got, ref)

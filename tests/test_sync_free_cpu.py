@@ -1,0 +1,119 @@
+"""The sync-free (random-key, fixed-shape) pre_train path computes the SAME quantities as the reference-shaped path:
+`losses_packed` against the golden losses for the reference's sampled RoIs, `sample_masks` / `sample_packed` against the
+counting rules of detectron2's subsample_labels, and the sync-free anchor labelling against the matcher."""
+import numpy as np
+import pytest
+import torch
+
+from cpu_shim import cpu_kernels
+from e2e_util import _inst, tiny_product_detector
+from golden_util import K, T, close, load, load_weights
+
+
+def test_sample_masks_counts_and_membership():
+    from coin_amd.box_ops import sample_masks
+
+    g = torch.Generator().manual_seed(0)
+    cls = torch.randint(-1, 5, (6, 300), generator=g)            # bg label = 4
+    cls[0] = 4                                                    # no positives
+    cls[1, :290] = -1                                             # almost everything ignored
+    cls[2] = torch.where(torch.rand(300, generator=g) < 0.9, torch.tensor(1), torch.tensor(4))  # more positives than the cap
+    torch.manual_seed(1)
+    pos, neg = sample_masks(cls, 64, 0.25, 4)
+    is_pos, is_neg = (cls != -1) & (cls != 4), cls == 4
+    assert not (pos & ~is_pos).any() and not (neg & ~is_neg).any()
+    for i in range(6):
+        n_pos = min(int(is_pos[i].sum()), 16)
+        n_neg = min(int(is_neg[i].sum()), 64 - n_pos)
+        assert int(pos[i].sum()) == n_pos and int(neg[i].sum()) == n_neg
+    # uniformity: every candidate of a row is picked with the same frequency
+    hits = torch.zeros(300)
+    for s in range(400):
+        torch.manual_seed(100 + s)
+        p, _ = sample_masks(cls[2:3], 64, 0.25, 4)
+        hits += p[0].float()
+    cand = is_pos[2]
+    freq = hits[cand] / 400
+    assert abs(float(freq.mean()) - 16 / int(cand.sum())) < 1e-6 and float(freq.std()) < 0.03
+
+
+def test_losses_packed_equal_reference_losses_on_the_same_samples():
+    from coin_amd.modeling.roi_heads import PackedSamples
+
+    for tag in ("a", "empty_image", "no_fg", "clipart"):
+        z = load(f"box_predictor_pretrain_{tag}")
+        with cpu_kernels():
+            det = tiny_product_detector()
+            from coin_amd.modeling.fast_rcnn import FastRCNNOutputLayers
+            from coin_amd.box_ops import Box2BoxTransform
+            from coin_amd.structures import ShapeSpec
+            from golden_util import LOSS_W
+
+            bp = FastRCNNOutputLayers(ShapeSpec(channels=64, height=1, width=1), text_encoder=det.roi_heads.box_predictor.text_encoder,
+                                      pooling_type="meanpool", box2box_transform=Box2BoxTransform((10.0, 10.0, 5.0, 5.0)), text_dim=32,
+                                      classes_weight=[1.0] * K + [0.9], loss_type="MILCrossEntropy", cls_agnostic_bbox_reg=True,
+                                      loss_weight=LOSS_W, batch_size_per_image=32, cls_b_thresh=0.3, dataset=(str(z["dataset"]),),
+                                      prototype_update_rate=0.9996)
+            load_weights(bp, z)
+            bp.train()
+            n_img = int(z["n_img"])
+            boxes, cls, gtb, prs = [], [], [], []
+            for i in range(n_img):
+                fg, bg = _inst(z, f"p{i}.fg", (96, 128)), _inst(z, f"p{i}.bg", (96, 128))
+                boxes += [fg.proposal_boxes.tensor, bg.proposal_boxes.tensor]
+                cls += [fg.gt_classes_offline, bg.gt_classes]
+                gtb += [fg.gt_boxes.tensor, bg.proposal_boxes.tensor]
+                prs += [fg.gt_probs_offline, torch.zeros(len(bg), K + 1)]
+            x = T(z["x"])
+            # 3 invalid filler rows (fewer candidates than the batch size): they must not change anything
+            x_ext = torch.cat([x, torch.randn(3, x.shape[1])]).requires_grad_(True)
+            ps = PackedSamples(torch.cat(boxes + [torch.tensor([[1.0, 1, 20, 20]] * 3)]), torch.cat(cls + [torch.full((3,), -1)]),
+                               torch.cat(gtb + [torch.tensor([[1.0, 1, 20, 20]] * 3)]), torch.cat(prs + [torch.zeros(3, K + 1)]), 0)
+            preds = bp(x_ext, "pre_train")
+            losses = bp.losses_packed(preds, ps, update_prototype=bool(z["update_prototype"]))
+            ref = {k[6:]: float(z[k]) for k in z.files if k.startswith("loss::")}
+            assert set(losses) == set(ref)
+            for k, v in ref.items():
+                assert abs(float(losses[k]) - v) < 1e-4 * max(1.0, abs(v)), (tag, k, float(losses[k]), v)
+            sum(losses.values()).backward()
+            close(x_ext.grad[: x.shape[0]], z["gx"], 1e-5, "gx")
+            assert float(x_ext.grad[x.shape[0]:].abs().max()) == 0.0
+            close(bp.text_encoder.per_class_feat, z["prototype_after"], 1e-6, "prototype")
+
+
+def test_sync_free_detector_step_matches_counting_rules():
+    """Whole sync-free forward on CPU (shimmed kernels): 32 rows per image, <= 8 fg, labels consistent with IoU >= 0.5."""
+    from coin_amd.structures import pairwise_iou, Boxes
+
+    z = load("e2e_pretrain")
+    with cpu_kernels():
+        model = tiny_product_detector()
+        load_weights(model, z)
+        model.set_sync_free(True)
+        model.train()
+        batch = []
+        for i in range(2):
+            img = T(z[f"img{i}"])
+            size = (img.shape[1], img.shape[2])
+            batch.append({"image": img, "height": size[0], "width": size[1], "RCNN": _inst(z, f"rcnn{i}", size), "RPN": _inst(z, f"rpn{i}", size)})
+        rec = {}
+        orig = model.roi_heads.sample_packed
+        model.roi_heads.sample_packed = lambda p, t: rec.setdefault("ps", orig(p, t))
+        torch.manual_seed(5)
+        losses = model(batch, branch="pre_train", update_prototype=True)
+        assert set(losses) == {"loss_text_align", "loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc"}
+        assert all(torch.isfinite(v) for v in losses.values())
+        sum(losses.values()).backward()
+        ps = rec["ps"]
+        assert ps.per_image == 32 and ps.gt_classes.shape[0] == 64
+        for i in range(2):
+            c = ps.gt_classes[i * 32:(i + 1) * 32]
+            b = ps.boxes[i * 32:(i + 1) * 32]
+            fg = (c >= 0) & (c < K)
+            assert int(fg.sum()) <= 8 and int((c == K).sum()) == 32 - int(fg.sum()) - int((c < 0).sum())
+            iou = pairwise_iou(batch[i]["RCNN"].gt_boxes, Boxes(b)).max(dim=0).values
+            assert bool((iou[fg] >= 0.5).all()) and bool((iou[c == K] < 0.5).all())
+            # fg rows carry the matched teacher box / class
+            m = pairwise_iou(batch[i]["RCNN"].gt_boxes, Boxes(b)).argmax(dim=0)
+            assert torch.equal(c[fg], batch[i]["RCNN"].gt_classes_offline[m[fg]])
+            close(ps.gt_boxes[i * 32:(i + 1) * 32][fg], batch[i]["RCNN"].gt_boxes.tensor[m[fg]], 0)
