@@ -1,0 +1,72 @@
+"""Data-parallel path (one process per GPU, gradients all-reduced by DistributedDataParallel) on CPU with the gloo
+backend, world_size 2.  Kernels are shimmed (tests/cpu_shim.py); what is checked is the N>1 plumbing of PRETrainer:
+batch split (IMG_PER_BATCH_UNLABEL / world), per-rank seeds, gradient averaging, identical parameters on all ranks after
+a step, BatchNorm statistics staying per-rank (broadcast_buffers=False, as coin/engine/pre_train.py:59-62)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cpu_shim import cpu_kernels
+    from coin_amd.config import get_cfg
+    from coin_amd.engine import PRETrainer
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(HERE, "..", "configs", "coin", "PRETRAINS", "CLIPDET_synthetic.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu", "AMD.COMPUTE_DTYPE", "fp32", "AMD.SYNTHETIC.HEIGHT", 96, "AMD.SYNTHETIC.WIDTH", 128,
+                         "AMD.SYNTHETIC.BOXES_PER_IMAGE", 4, "SOLVER.IMG_PER_BATCH_UNLABEL", 2, "AMD.SYNTHETIC.NUM_IMAGES", 2,
+                         "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 16, "MODEL.RPN.PRE_NMS_TOPK_TRAIN", 100, "MODEL.RPN.POST_NMS_TOPK_TRAIN", 30,
+                         "AMD.TEXT_TEMPLATES", 1, "AMD.ARCH.LAYERS", [1, 1, 1, 1], "AMD.ARCH.WIDTH", 8, "AMD.ARCH.TEXT_WIDTH", 32,
+                         "AMD.ARCH.TEXT_LAYERS", 2, "AMD.ARCH.TEXT_HEADS", 2, "AMD.ARCH.TEXT_DIM", 32, "AMD.ARCH.CONTEXT_LENGTH", 16,
+                         "AMD.ARCH.VOCAB_SIZE", 64])
+    with cpu_kernels():
+        torch.manual_seed(0)  # identical initial weights on every rank (the reference broadcasts from rank 0 after loading)
+        tr = PRETrainer(cfg)
+        torch.manual_seed(100 + rank)
+        assert tr.world_size == world and len(next(tr._data_loader_iter)[0]) == 1  # 2 images / 2 ranks
+        with torch.no_grad():
+            for n, p in tr.model.named_parameters():
+                if n.endswith("bn3.weight"):
+                    p.fill_(0.5)
+        for _ in range(2):
+            rec = tr.run_step()
+    sd = {k: v.clone() for k, v in tr.model.state_dict().items()}
+    torch.save({"sd": sd, "loss": {k: float(v) for k, v in rec.items()}}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_training_keeps_parameters_in_sync(tmp_path):
+    world, port = 2, _free_port()
+    mp.start_processes(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    a = torch.load(tmp_path / "rank0.pt")
+    b = torch.load(tmp_path / "rank1.pt")
+    params_equal, buffers_differ = 0, 0
+    for k in a["sd"]:
+        if "running_" in k or "num_batches" in k or "per_class_feat" in k or "prototype" in k:
+            buffers_differ += int(not torch.equal(a["sd"][k], b["sd"][k]))
+            continue
+        assert torch.allclose(a["sd"][k], b["sd"][k], rtol=0, atol=1e-7), f"{k} diverged across ranks"
+        params_equal += 1
+    assert params_equal > 50
+    assert buffers_differ > 0  # BatchNorm running statistics are per rank: different images -> different statistics
+    assert a["loss"] != b["loss"]  # each rank trained on its own shard
