@@ -6,7 +6,8 @@
 // separate library launches (statistics, normalise, add, relu, pool and their five backward kernels) they cost more
 // device time than the res5 convolutions.  Here:
 //   forward  = 1 statistics pass (read x) + 1 apply pass (read x [, residual], write y; y already pooled if pool=2)
-//   backward = 1 reduction pass (read x, dy [, y]) + 1 dx pass (read x, dy [, y], write dx [, d_residual])
+//   backward = 1 reduction pass (read x, dy [, y]) + 1 dx pass (read x, dy [, y], write dx [, d_residual]);
+//              y is read only when the forward added a residual, otherwise the ReLU mask is recomputed from x
 // All four are pure HBM streams: lane = 8 (bf16) or 4 (f32) consecutive channels = one 16-byte access, rows are
 // grid-strided, per-channel sums are kept in registers, combined through LDS and flushed with one float atomic per
 // (block, channel).  Statistics are accumulated in fp32 around a per-channel pivot (the first row) so that
@@ -199,20 +200,77 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restric
   }
 }
 
+// pool == 0: y[n][c] = mean over the H*W positions of relu?( x*sc + sh [+ residual] )  -- the RoI head's spatial mean
+// (clip_roi_heads.py:207-208 `x.mean(dim=[2,3])`) folded into the last BatchNorm of res5: the [N,H,W,C] activation is
+// never written.  One thread owns one (n, 16-byte channel group) and walks the H*W rows: coalesced, no cross-lane reduction.
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_mean_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, const T* __restrict__ residual,
+                                                                    T* __restrict__ y, int N, int HW, int C, int relu) {
+  constexpr int V = Ld<T>::V;
+  const int ncg = C / V;
+  const int cg = blockIdx.x * BN_THREADS + threadIdx.x;
+  const int n = blockIdx.y;
+  if (cg >= ncg) return;
+  float sc[V], sh[V], acc[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = cg * V + i;
+    sc[i] = rstd[c] * gamma[c];
+    sh[i] = beta[c] - mean[c] * sc[i];
+    acc[i] = 0.f;
+  }
+  const size_t base = (size_t)n * HW * C + (size_t)cg * V;
+#pragma unroll 7
+  for (int r = 0; r < HW; ++r) {
+    float v[V];
+    Ld<T>::load(x + base + (size_t)r * C, v);
+    if (residual) {
+      float rr[V];
+      Ld<T>::load(residual + base + (size_t)r * C, rr);
+#pragma unroll
+      for (int i = 0; i < V; ++i) v[i] = v[i] * sc[i] + sh[i] + rr[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < V; ++i) v[i] = v[i] * sc[i] + sh[i];
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] += relu ? fmaxf(v[i], 0.f) : v[i];
+  }
+  const float inv = 1.0f / (float)HW;
+#pragma unroll
+  for (int i = 0; i < V; ++i) acc[i] *= inv;
+  Ld<T>::store(y + (size_t)n * C + (size_t)cg * V, acc);
+}
+
 // Upstream gradient of the pre-activation at input pixel (n,h,w): dy (through pool / relu mask).
 template <typename T>
 __device__ __forceinline__ void upstream(const T* __restrict__ dy, const T* __restrict__ yout, const float (&xv)[Ld<T>::V],
                                          const float (&sc)[Ld<T>::V], const float (&sh)[Ld<T>::V], int n, int h, int w, int H, int W,
                                          int C, int cg, int relu, int pool, float (&g)[Ld<T>::V]) {
   constexpr int V = Ld<T>::V;
-  if (pool == 1) {
+  if (pool == 0) {  // global mean: dy is [N,C]; `yout` carries the forward's RESIDUAL input (or NULL), the mask is recomputed
+    Ld<T>::load(dy + (size_t)n * C + (size_t)cg * V, g);
+    const float inv = 1.0f / (float)(H * W);
+    float rr[V];
+    if (yout) Ld<T>::load(yout + (((size_t)n * H + h) * W + w) * C + (size_t)cg * V, rr);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float pre = xv[i] * sc[i] + sh[i] + (yout ? rr[i] : 0.f);
+      g[i] = (relu && !(pre > 0.f)) ? 0.f : g[i] * inv;
+    }
+  } else if (pool == 1) {
     const size_t off = (((size_t)n * H + h) * W + w) * C + (size_t)cg * V;
     Ld<T>::load(dy + off, g);
-    if (relu) {
+    if (relu && yout) {  // forward had a residual: the mask is only known from the saved output
       float yv[V];
       Ld<T>::load(yout + off, yv);
 #pragma unroll
       for (int i = 0; i < V; ++i) g[i] = yv[i] > 0.f ? g[i] : 0.f;
+    } else if (relu) {  // no residual: recompute the pre-activation from x (same expression as bn_apply_kernel), y is not read
+#pragma unroll
+      for (int i = 0; i < V; ++i) g[i] = (xv[i] * sc[i] + sh[i] > 0.f) ? g[i] : 0.f;
     }
   } else {
     const int OH = H / 2, OW = W / 2;
@@ -407,7 +465,7 @@ __global__ __launch_bounds__(BN_THREADS) void avgpool2_bwd_kernel(const T* __res
 int bn_check(const void* x, int N, int H, int W, int C, int pool, int dtype) {
   if (!x || N <= 0 || H <= 0 || W <= 0 || C <= 0) return COIN_EINVAL;
   if (dtype != COIN_F32 && dtype != COIN_BF16) return COIN_EINVAL;
-  if (pool != 1 && pool != 2) return COIN_EINVAL;
+  if (pool != 0 && pool != 1 && pool != 2) return COIN_EINVAL;
   const int v = dtype == COIN_F32 ? 4 : 8;
   if (C % v) return COIN_ESHAPE;
   if (C / v > BN_THREADS && (C / v) % BN_THREADS) return COIN_ESHAPE;  // uniform trip count of the channel-group loops
@@ -462,8 +520,16 @@ extern "C" int coin_bn_apply_fwd(const void* x, const float* mean, const float* 
   if (pool == 2 && residual) return COIN_ESHAPE;
   if (pool == 2 && (H < 2 || W < 2)) return COIN_ESHAPE;
   const int v = dtype == COIN_F32 ? 4 : 8;
-  const int64_t items = (int64_t)N * (H / pool) * (W / pool) * (C / v);
   hipStream_t st = (hipStream_t)stream;
+  if (pool == 0) {
+    if (N > 65535) return COIN_ESHAPE;
+    dim3 grid((C / v + BN_THREADS - 1) / BN_THREADS, N);
+#define GO(T) bn_apply_mean_kernel<T><<<grid, BN_THREADS, 0, st>>>((const T*)x, mean, rstd, gamma, beta, (const T*)residual, (T*)y, N, H * W, C, relu)
+    BN_DISPATCH(dtype, GO(float), GO(bf16_t));
+#undef GO
+    return coin_launch_status();
+  }
+  const int64_t items = (int64_t)N * (H / pool) * (W / pool) * (C / v);
 #define GO(T) bn_apply_kernel<T><<<stream_grid(items), BN_THREADS, 0, st>>>((const T*)x, mean, rstd, gamma, beta, (const T*)residual, (T*)y, N, H, W, C, relu, pool)
   BN_DISPATCH(dtype, GO(float), GO(bf16_t));
 #undef GO
@@ -476,7 +542,8 @@ extern "C" int coin_bn_bwd(const void* x, const void* dy, const void* y, const f
   int rc = bn_check(x, N, H, W, C, pool, dtype);
   if (rc) return rc;
   if (!dy || !mean || !rstd || !gamma || !beta || !dsums || !dx) return COIN_EINVAL;
-  if (relu && pool == 1 && !y) return COIN_EINVAL;  // the ReLU mask is read from the saved output
+  if (relu && pool == 1 && d_residual && !y) return COIN_EINVAL;  // with a residual the ReLU mask is only in the saved output
+  if (pool == 0 && d_residual && !y) return COIN_EINVAL;          // pool == 0: `y` is the forward's residual input
   if (pool == 2 && d_residual) return COIN_ESHAPE;
   hipStream_t st = (hipStream_t)stream;
   const int v = dtype == COIN_F32 ? 4 : 8;

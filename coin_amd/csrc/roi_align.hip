@@ -10,10 +10,10 @@
 // All row-blocks of one RoI are placed on one XCD (blocks b and b+8 share an XCD) so that the
 // RoI's footprint is fetched into a single L2.
 //
-// Backward accumulates each RoI's footprint in LDS (ds_add_f32, lane = channel, conflict-free)
-// and flushes it with 256-byte-contiguous global float atomics: ~(samples*4)/(footprint) fewer
-// global atomics than the per-tap scheme, which is what bounds a naive backward on this chip
-// (~1.3 TB/s of atomic bytes, MI355X_MICROARCH.md "Global float atomics").
+// Backward is a separable gather per RoI (see the kernel): the RoI's gradient tile is staged in LDS once,
+// every footprint pixel of the map contracts the few bins that touch it and receives ONE 256-byte-contiguous
+// float atomic: ~(samples*4)/(footprint) fewer global atomics than the per-tap scheme, which is what bounds a
+// naive backward on this chip (~1.3 TB/s of atomic bytes, MI355X_MICROARCH.md "Global float atomics").
 //
 // The NCHW kernels are the layout-compatible (reference layout) path: one thread per element.
 #include "common.h"

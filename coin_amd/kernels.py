@@ -344,9 +344,10 @@ def bn_stats(x: torch.Tensor, eps: float, momentum: float, running_mean: Optiona
 def bn_apply_fwd(x: torch.Tensor, mean, rstd, gamma, beta, residual: Optional[torch.Tensor], relu: bool, pool: int) -> torch.Tensor:
     _dev(x, mean, rstd, gamma, beta, residual)
     n, h, w, c = _nhwc(x, "x")
-    y = torch.empty((n, h // pool, w // pool, c), dtype=x.dtype, device=x.device)
-    if residual is not None and (residual.shape != y.shape or residual.dtype != x.dtype or not residual.is_contiguous()):
-        raise CoinHipError("residual must match the output (contiguous NHWC, same dtype)")
+    # pool: 1 = none, 2 = 2x2 average pool, 0 = global spatial mean (y is [N,1,1,C]; the full activation is never written)
+    y = torch.empty((n, 1, 1, c) if pool == 0 else (n, h // pool, w // pool, c), dtype=x.dtype, device=x.device)
+    if residual is not None and (residual.shape != x.shape or pool == 2 or residual.dtype != x.dtype or not residual.is_contiguous()):
+        raise CoinHipError("residual must match the pre-pool activation (contiguous NHWC, same dtype)")
     check(_lib.lib().coin_bn_apply_fwd(_p(x), _p(_f32c(mean, "mean")), _p(_f32c(rstd, "rstd")), _p(_f32c(gamma, "gamma")),
                                        _p(_f32c(beta, "beta")), _p(residual), _p(y), n, h, w, c, int(relu), int(pool), _dt(x), _stream()),
           "coin_bn_apply_fwd")
@@ -355,14 +356,16 @@ def bn_apply_fwd(x: torch.Tensor, mean, rstd, gamma, beta, residual: Optional[to
 
 def bn_bwd(x: torch.Tensor, dy: torch.Tensor, y: Optional[torch.Tensor], mean, rstd, gamma, beta, relu: bool, pool: int,
            want_dres: bool):
-    """-> dx [N,H,W,C], dgamma [C], dbeta [C], d_residual (or None)."""
+    """-> dx [N,H,W,C], dgamma [C], dbeta [C], d_residual (or None).
+    `y`: the saved forward output (pool 1, only needed when the forward added a residual) or, for pool 0 (global mean), the
+    forward's residual INPUT (the activation was never stored; the ReLU mask is recomputed)."""
     _dev(x, dy, y)
     n, h, w, c = _nhwc(x, "x")
     if not dy.is_contiguous() or dy.dtype != x.dtype:
         raise CoinHipError("dy must be contiguous NHWC of x's dtype")
     dsums = torch.empty((BN_MAX_PARTS + 1) * 2 * c, dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
-    dres = torch.empty_like(dy) if want_dres else None
+    dres = torch.empty_like(x) if want_dres else None
     check(_lib.lib().coin_bn_bwd(_p(x), _p(dy), _p(y), _p(mean), _p(rstd), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")), n, h, w, c,
                                  int(relu), int(pool), _p(dsums), _p(dx), _p(dres), _dt(x), _stream()), "coin_bn_bwd")
     return dx, dsums[c:2 * c], dsums[:c], dres
@@ -427,6 +430,10 @@ def normalize_pad(images: Sequence[torch.Tensor], mean: Sequence[float], std: Se
     return out, sizes
 
 
+def _dense(t: torch.Tensor) -> bool:
+    return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
 class SgdTable:
     """Device table of (param, grad, momentum, lr, wd) descriptors for the one-launch SGD step."""
 
@@ -434,31 +441,55 @@ class SgdTable:
                  shadows: Optional[Sequence[Optional[torch.Tensor]]] = None):
         _dev(*params)
         self.params = list(params)
-        self.bufs = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
+        self.bufs = [torch.zeros_like(p) for p in self.params]  # same (dense) strides as the parameter: the kernel is elementwise on storage
         self.shadows = list(shadows) if shadows is not None else [None] * len(self.params)
         self.lrs, self.wds = list(lrs), list(wds)
         self.first = True
         self.max_numel = max((p.numel() for p in self.params), default=0)
         self._host = (_lib.SgdTensor * max(len(self.params), 1))()
-        self._dev = torch.empty(ctypes.sizeof(self._host), dtype=torch.uint8, device=self.params[0].device) if self.params else None
+        nbytes = ctypes.sizeof(self._host)
+        self._dev = torch.empty(nbytes, dtype=torch.uint8, device=self.params[0].device) if self.params else None
+        # pinned staging ring: the table is re-uploaded asynchronously whenever a gradient pointer changed (gradients are
+        # released every step and re-allocated by autograd); a slot is reused only after its copy has executed
+        self._stage = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(self.STAGES)] if self.params else []
+        self._stage_ev = [None] * self.STAGES
+        self._stage_i = 0
         self._grads_key = None
+
+    STAGES = 4
 
     def _upload(self, grads):
         for i, (p, g, b, s) in enumerate(zip(self.params, grads, self.bufs, self.shadows)):
-            if not (p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32 and g.dtype == torch.float32):
-                raise CoinHipError("SGD needs contiguous float32 params and grads")
             e = self._host[i]
+            if g is None:  # torch.optim.SGD skips parameters without a gradient (no weight decay, no momentum update)
+                e.numel = 0
+                continue
+            if not (_dense(p) and g.stride() == p.stride() and b.stride() == p.stride() and p.dtype == torch.float32 and g.dtype == torch.float32):
+                raise CoinHipError("SGD needs dense float32 params with identically laid out grads (contiguous or channels_last)")
+            if s is not None and (s.stride() != p.stride() or s.dtype != torch.bfloat16):
+                raise CoinHipError("a bf16 shadow must share its parameter's layout")
             e.param, e.grad, e.momentum_buf = p.data_ptr(), g.data_ptr(), b.data_ptr()
             e.bf16_shadow = s.data_ptr() if s is not None else None
             e.numel, e.lr, e.weight_decay = p.numel(), float(self.lrs[i]), float(self.wds[i])
-        host = torch.frombuffer(memoryview(self._host).cast("B"), dtype=torch.uint8)
-        self._dev.copy_(host, non_blocking=False)
+        k = self._stage_i
+        self._stage_i = (k + 1) % self.STAGES
+        if self._stage_ev[k] is not None:
+            self._stage_ev[k].synchronize()
+        ctypes.memmove(self._stage[k].data_ptr(), ctypes.addressof(self._host), ctypes.sizeof(self._host))
+        self._dev.copy_(self._stage[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._stage_ev[k] = ev
 
     def step(self, grads: Sequence[torch.Tensor], momentum: float, inv_loss_scale: float = 1.0,
-             lrs: Optional[Sequence[float]] = None, lr_scale: float = 1.0):
+             lrs: Optional[Sequence[float]] = None, lr_scale: float = 1.0,
+             shadows: Optional[Sequence[Optional[torch.Tensor]]] = None):
         """`lrs` (re)defines the per-tensor base learning rates held in the device table (re-uploaded only when they or the
         gradient pointers change); `lr_scale` is the per-step schedule factor passed as a kernel argument."""
-        key = (tuple(g.data_ptr() for g in grads), tuple(lrs) if lrs is not None else tuple(self.lrs))
+        if shadows is not None:
+            self.shadows = list(shadows)
+        key = (tuple(g.data_ptr() if g is not None else 0 for g in grads), tuple(lrs) if lrs is not None else tuple(self.lrs),
+               tuple(s.data_ptr() if s is not None else 0 for s in self.shadows))
         if lrs is not None:
             self.lrs = list(lrs)
         if key != self._grads_key:
@@ -484,3 +515,5 @@ class EmaTable:
 
     def update(self, keep: float):
         check(_lib.lib().coin_ema_update(_p(self._dev), self.n, self.max_numel, float(keep), _stream()), "coin_ema_update")
+        from . import layers  # late import (layers imports this module): the teacher's bf16 weight shadows are now stale
+        layers.invalidate_shadows(self._keep[0])

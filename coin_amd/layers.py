@@ -5,6 +5,7 @@ Reference call sites are cited per class (paths under /root/reference).
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -21,6 +22,94 @@ def _pad_rows(x: torch.Tensor, mult: int) -> torch.Tensor:
         return x
     pad = x.new_zeros((mult - m % mult,) + tuple(x.shape[1:]))
     return torch.cat([x, pad], dim=0)
+
+
+# --------------------------------------------------------------------------- compute-dtype weight shadows
+# bf16 throughput mode keeps fp32 master parameters (state dict, optimizer) and a persistent bf16 copy ("shadow") of each.
+# The one-launch SGD kernel refreshes the shadow together with the master (coin_sgd_tensor.bf16_shadow), so a training step
+# contains no per-parameter fp32->bf16 cast kernels (torch.autocast issues one per weight per step: ~230 launches here).
+class _Shadow:
+    __slots__ = ("ref", "tensor", "version", "ptr")
+
+
+_SHADOWS: dict = {}
+
+
+def _shadow_entry(param: torch.Tensor, dtype: torch.dtype) -> "_Shadow":
+    e = _SHADOWS.get(id(param))
+    if e is not None and e.ref() is not param:
+        e = None
+    if e is None or e.tensor.dtype != dtype or e.tensor.shape != param.shape or e.tensor.device != param.device:
+        e = _Shadow()
+        e.ref = weakref.ref(param, lambda _r, k=id(param): _SHADOWS.pop(k, None))
+        e.tensor = torch.empty_like(param, dtype=dtype)  # preserve_format: same dense strides as the master (SGD kernel is elementwise)
+        e.version, e.ptr = -1, 0
+        _SHADOWS[id(param)] = e
+    if e.version != param._version or e.ptr != param.data_ptr():
+        # the master was written by something other than the fused SGD / EMA kernels (init, load_state_dict, .data = ...)
+        with torch.no_grad():
+            e.tensor.copy_(param.detach())
+        e.version, e.ptr = param._version, param.data_ptr()
+    return e
+
+
+def shadow_of(param: torch.Tensor) -> Optional[torch.Tensor]:
+    """The live compute-dtype copy of `param` (None if it never had one); used by the optimizer's tensor table."""
+    e = _SHADOWS.get(id(param))
+    return e.tensor if e is not None and e.ref() is param and e.tensor.stride() == param.stride() else None
+
+
+def invalidate_shadows(params: Sequence[torch.Tensor]) -> None:
+    """Call after writing masters through raw pointers WITHOUT refreshing their shadows (the EMA kernel)."""
+    for p in params:
+        e = _SHADOWS.get(id(p))
+        if e is not None:
+            e.version = -1
+
+
+class _ShadowCast(Function):
+    @staticmethod
+    def forward(ctx, param, shadow):
+        return shadow.detach()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        return g.float(), None
+
+
+def compute_weight(param: Optional[torch.Tensor], dtype: torch.dtype) -> Optional[torch.Tensor]:
+    """`param` in the compute dtype: the parameter itself (fp32 mode), else its persistent shadow, wired into autograd so
+    that the fp32 master receives the gradient."""
+    if param is None or param.dtype == dtype or not param.is_cuda:
+        return param
+    e = _shadow_entry(param, dtype)
+    if param.requires_grad and torch.is_grad_enabled():
+        return _ShadowCast.apply(param, e.tensor)
+    return e.tensor
+
+
+def compute_dtype_of(x: torch.Tensor) -> torch.dtype:
+    """Dtype the weights should take for input x: the autocast dtype inside an autocast region, else x's own."""
+    if x.is_cuda and torch.is_autocast_enabled():
+        return torch.get_autocast_gpu_dtype()
+    return x.dtype
+
+
+def conv2d(x: torch.Tensor, conv: torch.nn.Conv2d) -> torch.Tensor:
+    """conv(x) with the weight (and bias) taken from their compute-dtype shadows."""
+    dt = compute_dtype_of(x)
+    if x.dtype != dt:
+        x = x.to(dt)
+    return torch.nn.functional.conv2d(x, compute_weight(conv.weight, dt), compute_weight(conv.bias, dt), conv.stride, conv.padding,
+                                      conv.dilation, conv.groups)
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    dt = compute_dtype_of(x)
+    if x.dtype != dt:
+        x = x.to(dt)
+    return torch.nn.functional.linear(x, compute_weight(weight, dt), compute_weight(bias, dt))
 
 
 # --------------------------------------------------------------------------- RoIAlign
@@ -74,7 +163,13 @@ class _BNAct(Function):
         mean, rstd = K.bn_stats(xn, eps, momentum, running_mean, running_var)
         y = K.bn_apply_fwd(xn, mean, rstd, g, b, rn, relu, pool)
         ctx.relu, ctx.pool, ctx.has_res = relu, pool, residual is not None
-        ctx.save_for_backward(xn, y if (relu and pool == 1) else None, mean, rstd, g, b)
+        # pool 1: the saved output is only needed for the ReLU mask when a residual was added (otherwise coin_bn_bwd recomputes
+        # it from x).  pool 0 (global mean): the activation does not exist; the residual input is kept instead.
+        if pool == 0:
+            keep = rn
+        else:
+            keep = y if (relu and pool == 1 and residual is not None) else None
+        ctx.save_for_backward(xn, keep, mean, rstd, g, b)
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -91,7 +186,8 @@ class _BNAct(Function):
 
 def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm2d, relu: bool, residual: Optional[torch.Tensor] = None, pool: int = 1) -> torch.Tensor:
     """Train-mode BatchNorm with batch statistics (per GPU, as the reference) fused with the elementwise tail.
-    x / residual / result: logical [N,C,H,W] in channels-last memory format."""
+    x / residual / result: logical [N,C,H,W] in channels-last memory format.
+    pool: 1 = none, 2 = nn.AvgPool2d(2) fused in, 0 = global spatial mean fused in (result [N,C,1,1])."""
     if bn.training:
         if bn.momentum is None:
             raise CoinHipError("cumulative-average BatchNorm (momentum=None) is not used by the reference")
@@ -108,6 +204,8 @@ def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm2d, relu: bool, residual: Opti
         y = y + residual
     if relu:
         y = torch.relu(y)
+    if pool == 0:
+        return y.mean(dim=[2, 3], keepdim=True)
     return avg_pool2(y) if pool == 2 else y
 
 
@@ -134,8 +232,9 @@ class _LinearAct(Function):
     """nn.Linear (+ LeakyReLU) of FastRCNNOutputLayers (fast_rcnn.py:237-251,331-337) on the MFMA GEMM."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act, alpha, out_dtype):
-        wq = weight.to(x.dtype) if weight.dtype != x.dtype else weight
+    def forward(ctx, x, weight, bias, act, alpha, out_dtype, wq):
+        if wq is None:  # wq: the weight's compute-dtype shadow (the gradient still goes to the fp32 master `weight`)
+            wq = weight.to(x.dtype) if weight.dtype != x.dtype else weight
         y = K.gemm_nt(x, wq.contiguous(), bias.float() if bias is not None else None, act, alpha, out_dtype=out_dtype)
         ctx.act, ctx.alpha, ctx.has_bias = act, alpha, bias is not None
         ctx.save_for_backward(x, wq, y if act != ACT_NONE else None)
@@ -176,12 +275,13 @@ class _LinearAct(Function):
             dzt = K.transpose2d(_pad_rows(dz, kmult))   # [N, Mp]
             xt = K.transpose2d(_pad_rows(x, kmult))     # [K, Mp]
             dw = K.gemm_nt(dzt, xt, out_dtype=torch.float32)
-        return dx, dw, (dbias if ctx.has_bias else None), None, None, None
+        return dx, dw, (dbias if ctx.has_bias else None), None, None, None, None
 
 
 def linear_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE, alpha: float = 0.01,
                out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-    return _LinearAct.apply(x.contiguous(), weight, bias, act, alpha, out_dtype or x.dtype)
+    wq = _shadow_entry(weight, x.dtype).tensor if (weight.dtype != x.dtype and weight.is_cuda) else None
+    return _LinearAct.apply(x.contiguous(), weight, bias, act, alpha, out_dtype or x.dtype, wq)
 
 
 # --------------------------------------------------------------------------- cosine classifier

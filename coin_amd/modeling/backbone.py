@@ -15,6 +15,7 @@ Weights are random-initialised as CLIP does (bn3.weight = 0) - there is no netwo
 """
 from __future__ import annotations
 
+import weakref
 from collections import OrderedDict
 from typing import Dict
 
@@ -66,12 +67,30 @@ def _conv_bn(x, conv: nn.Conv2d, bn: nn.Module, relu: bool):
     """conv -> norm (-> relu).  In the bf16 throughput mode a frozen norm is folded into the convolution; the fp32
     parity mode keeps the reference's operation order (conv, then x*scale + shift)."""
     if isinstance(bn, FrozenBatchNorm2d) and x.dtype != torch.float32:
-        s, b = bn.scale_shift()
-        w = conv.weight * s.view(-1, 1, 1, 1)
-        y = F.conv2d(x, w.to(x.dtype), b.to(x.dtype), conv.stride, conv.padding)
+        w, b = _folded(conv, bn, x.dtype)
+        y = F.conv2d(x, w, b, conv.stride, conv.padding)
     else:
-        y = bn(conv(x))
+        y = bn(L.conv2d(x, conv))
     return F.relu(y) if relu else y
+
+
+_FOLDED: dict = {}
+
+
+def _folded(conv: nn.Conv2d, bn: "FrozenBatchNorm2d", dtype: torch.dtype):
+    """Frozen conv + frozen norm folded into one (weight, bias) pair in the compute dtype; both are constants of the
+    training run, so the pair is computed once and re-derived only if one of the five source tensors is written."""
+    src = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    key = tuple((t.data_ptr(), t._version) for t in src) + (dtype,)
+    hit = _FOLDED.get(id(conv))
+    if hit is not None and hit[0] == key and hit[1]() is conv:
+        return hit[2], hit[3]
+    with torch.no_grad():
+        s, b = bn.scale_shift()
+        w = (conv.weight * s.view(-1, 1, 1, 1)).to(dtype).contiguous(memory_format=torch.channels_last)
+        b = b.to(dtype)
+    _FOLDED[id(conv)] = (key, weakref.ref(conv, lambda _r, k=id(conv): _FOLDED.pop(k, None)), w, b)
+    return w, b
 
 
 class Bottleneck(nn.Module):
@@ -94,7 +113,11 @@ class Bottleneck(nn.Module):
             self.downsample = nn.Sequential(OrderedDict([
                 ("-1", nn.AvgPool2d(stride)), ("0", nn.Conv2d(inplanes, out, 1, stride=1, bias=False)), ("1", nn.BatchNorm2d(out))]))
 
-    def forward(self, x):
+    def forward(self, x, mean_pool: bool = False):
+        """mean_pool: return the spatial mean [N,C,1,1] of the block output instead of the output (the RoI head's
+        `x.mean(dim=[2,3])`, clip_roi_heads.py:207-208, folded into bn3 + identity + ReLU: the activation is never stored)."""
+        if mean_pool and isinstance(self.bn1, FrozenBatchNorm2d):
+            return self.forward(x).mean(dim=[2, 3], keepdim=True)
         if isinstance(self.bn1, FrozenBatchNorm2d):  # frozen stage (layer1 at FREEZE_AT=2): plain inference ops
             y = _conv_bn(x, self.conv1, self.bn1, True)
             y = _conv_bn(y, self.conv2, self.bn2, True)
@@ -105,14 +128,14 @@ class Bottleneck(nn.Module):
         # trainable stage: every BatchNorm + elementwise tail is a fused HIP stream (coin_amd.layers.bn_act)
         pool = 2 if self.stride > 1 else 1
         assert self.stride in (1, 2)
-        y = L.bn_act(self.conv1(x), self.bn1, relu=True)
-        y = L.bn_act(self.conv2(y), self.bn2, relu=True, pool=pool)          # ReLU and the anti-aliasing avg-pool fused in
+        y = L.bn_act(L.conv2d(x, self.conv1), self.bn1, relu=True)
+        y = L.bn_act(L.conv2d(y, self.conv2), self.bn2, relu=True, pool=pool)          # ReLU and the anti-aliasing avg-pool fused in
         if self.downsample is not None:
             sx = L.avg_pool2(x) if pool == 2 else x
-            sx = L.bn_act(self.downsample[1](sx), self.downsample[2], relu=False)
+            sx = L.bn_act(L.conv2d(sx, self.downsample[1]), self.downsample[2], relu=False)
         else:
             sx = x
-        return L.bn_act(self.conv3(y), self.bn3, relu=True, residual=sx)      # bn3 + identity add + ReLU
+        return L.bn_act(L.conv2d(y, self.conv3), self.bn3, relu=True, residual=sx, pool=0 if mean_pool else 1)  # bn3 + identity + ReLU
 
 
 class ModifiedResNet(nn.Module):

@@ -132,8 +132,18 @@ def build_model(cfg):
     (GroundingDINO, GLIP) are out of scope: their cached outputs are an input of this path."""
     dev = torch.device(cfg.MODEL.DEVICE)
     arch = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)
+
+    def make():
+        m = arch.from_config(cfg).to(dev)
+        if dev.type == "cuda":
+            # activations are channels-last end to end; keeping the 4-D convolution weights (fp32 masters, their gradients,
+            # momentum buffers and bf16 shadows) in the same memory format removes a per-call weight re-layout from every
+            # convolution forward / backward.  Logical shapes and state-dict contents are unchanged.
+            nn.Module.to(m, memory_format=torch.channels_last)
+        return m
+
     if cfg.CLOUD.Trainer in ("PRETRAIN", "ORACLE", "ModelZoo_test"):
-        return arch.from_config(cfg).to(dev)
+        return make()
     if cfg.CLOUD.Trainer == "CoinTrainer":
-        return arch.from_config(cfg).to(dev), arch.from_config(cfg).to(dev)
+        return make(), make()
     raise NotImplementedError(f"CLOUD.Trainer={cfg.CLOUD.Trainer!r} is outside the adaptation-training hot path")

@@ -78,6 +78,12 @@ class OpenVocabularyRes5ROIHeads(nn.Module):
         return backbone_res5(self.pooler(features, boxes))
 
     def _pooled(self, features, boxes, res5, attnpool):
+        if self.pooling_type == "meanpool" and isinstance(res5, torch.nn.Sequential) and len(res5) > 0 and hasattr(res5[-1], "conv3"):
+            # res5 (clip_roi_heads.py:172-176) with the spatial mean (:207-208) folded into the last block's epilogue
+            x = self.pooler([features[f] for f in self.in_features], boxes)
+            for block in list(res5)[:-1]:
+                x = block(x)
+            return res5[-1](x, mean_pool=True).flatten(1).to(self.compute_dtype)
         x = self._shared_roi_transform([features[f] for f in self.in_features], boxes, res5)
         if self.pooling_type == "meanpool":
             return x.mean(dim=[2, 3]).to(self.compute_dtype)

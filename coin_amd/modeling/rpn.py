@@ -33,9 +33,9 @@ class StandardRPNHead(nn.Module):
     def forward(self, features: List[torch.Tensor]):
         lg, dl = [], []
         for x in features:
-            t = F.relu(self.conv(x))
-            lg.append(self.objectness_logits(t))
-            dl.append(self.anchor_deltas(t))
+            t = F.relu(L.conv2d(x, self.conv))
+            lg.append(L.conv2d(t, self.objectness_logits))
+            dl.append(L.conv2d(t, self.anchor_deltas))
         return lg, dl
 
 

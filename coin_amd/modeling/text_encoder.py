@@ -19,6 +19,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import layers as L
 from ..registry import MERGE_REGISTRY, TEXT_ENCODER_REGISTRY
 
 TEXT_DIMS = {"RN50": 1024, "RN101": 512, "RN50x4": 640, "RN50x16": 768}  # fast_rcnn.py:283
@@ -40,9 +41,9 @@ class _Attention(nn.Module):
 
     def forward(self, x):  # [N, L, D]
         n, l, d = x.shape
-        q, k, v = F.linear(x, self.in_proj_weight, self.in_proj_bias).view(n, l, 3, self.heads, d // self.heads).permute(2, 0, 3, 1, 4)
+        q, k, v = L.linear(x, self.in_proj_weight, self.in_proj_bias).view(n, l, 3, self.heads, d // self.heads).permute(2, 0, 3, 1, 4)
         o = F.scaled_dot_product_attention(q, k, v, is_causal=True)
-        return self.out_proj(o.transpose(1, 2).reshape(n, l, d))
+        return L.linear(o.transpose(1, 2).reshape(n, l, d), self.out_proj.weight, self.out_proj.bias)
 
 
 class ResidualAttentionBlock(nn.Module):
@@ -55,8 +56,8 @@ class ResidualAttentionBlock(nn.Module):
 
     def forward(self, x):
         x = x + self.attn(self.ln_1(x))
-        h = self.mlp.c_fc(self.ln_2(x))
-        return x + self.mlp.c_proj(h * torch.sigmoid(1.702 * h))  # QuickGELU
+        h = L.linear(self.ln_2(x), self.mlp.c_fc.weight, self.mlp.c_fc.bias)
+        return x + L.linear(h * torch.sigmoid(1.702 * h), self.mlp.c_proj.weight, self.mlp.c_proj.bias)  # QuickGELU
 
 
 class Transformer(nn.Module):
@@ -140,8 +141,13 @@ class TEXT_ENCODER(nn.Module):
             x = self.token_embedding(text.long())
             eot = text.argmax(dim=-1)
         x = x.float() + self.positional_embedding
+        if x.is_cuda and torch.is_autocast_enabled():
+            # bf16 throughput mode: keep the residual stream in the compute dtype, as the reference's fp16 encoder does
+            # (clip_text.py:137,194 `x.type(self.dtype)`); an fp32 stream turns every residual add into a mixed-dtype kernel
+            x = x.to(torch.get_autocast_gpu_dtype())
         x = self.ln_final(self.transformer(x))
-        x = x[torch.arange(x.shape[0], device=x.device), eot.long()] @ self.text_projection
+        x = x[torch.arange(x.shape[0], device=x.device), eot.long()]
+        x = x @ L.compute_weight(self.text_projection, L.compute_dtype_of(x))
         return x / torch.norm(x, dim=-1, keepdim=True)
 
 

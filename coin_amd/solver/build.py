@@ -12,6 +12,7 @@ from typing import Any, Dict, List, Optional
 import torch
 
 from .. import kernels as K
+from .. import layers as L
 from .lr_scheduler import WarmupTwoStageMultiStepLR
 
 _NORM_TYPES = (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d, torch.nn.SyncBatchNorm, torch.nn.GroupNorm,
@@ -69,7 +70,7 @@ class FusedSGD:
     def params(self):
         return [g["params"][0] for g in self.param_groups]
 
-    def zero_grad(self, set_to_none: bool = False):
+    def zero_grad(self, set_to_none: bool = True):
         grads = [p.grad for p in self.params if p.grad is not None]
         if set_to_none:
             for p in self.params:
@@ -82,11 +83,7 @@ class FusedSGD:
         params = self.params
         if self._table is None:
             self._table = K.SgdTable(params, [g["lr"] for g in self.param_groups], [g["weight_decay"] for g in self.param_groups])
-        grads = []
-        for p in params:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-            grads.append(p.grad)
+        grads = [p.grad for p in params]  # None -> the tensor is skipped this step, as torch.optim.SGD does
         # lr_i(t) = base_lr_i * factor(t): the factor travels as a kernel argument, the table keeps the base rates
         factor, uniform = None, True
         for g in self.param_groups:
@@ -97,11 +94,13 @@ class FusedSGD:
                 elif abs(f - factor) > 1e-9 * max(1.0, abs(factor)):
                     uniform = False
                     break
+        # compute-dtype copies of the weights (bf16 mode) are rewritten by the same launch as their fp32 masters
+        shadows = [L.shadow_of(p) for p in params]
         if uniform:
             self._table.step(grads, self.momentum, inv_loss_scale, lrs=[g["base_lr"] for g in self.param_groups],
-                             lr_scale=1.0 if factor is None else factor)
+                             lr_scale=1.0 if factor is None else factor, shadows=shadows)
         else:  # groups were edited independently: fall back to uploading the absolute rates
-            self._table.step(grads, self.momentum, inv_loss_scale, lrs=[g["lr"] for g in self.param_groups])
+            self._table.step(grads, self.momentum, inv_loss_scale, lrs=[g["lr"] for g in self.param_groups], shadows=shadows)
 
     def state_dict(self):
         bufs = self._table.bufs if self._table is not None else None

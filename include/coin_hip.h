@@ -111,12 +111,18 @@ int coin_bias_act_bwd(const void* dC, const void* C, void* dZ, int ld, int M, in
  *                     nn.BatchNorm2d running-statistics update (momentum, unbiased variance) when
  *                     running_mean/var are non-NULL.  sums_workspace: COIN_BN_MAX_PARTS*2*C floats (contents
  *                     undefined): per-workgroup partial sums combined in a fixed order (no atomics, reproducible).
- * coin_bn_apply_fwd : y = pool( relu?( (x-mean)*rstd*gamma + beta [+ residual] ) ); pool in {1,2};
- *                     pool == 2 writes y [N,H/2,W/2,C] (floor, as nn.AvgPool2d(2)); residual requires pool == 1.
+ * coin_bn_apply_fwd : y = pool( relu?( (x-mean)*rstd*gamma + beta [+ residual] ) ); pool in {0,1,2};
+ *                     pool == 2 writes y [N,H/2,W/2,C] (floor, as nn.AvgPool2d(2)); residual requires pool != 2.
+ *                     pool == 0 writes only the spatial mean y [N,C] (the RoI head's `x.mean(dim=[2,3])`,
+ *                     coin/modeling/roi_heads/clip_roi_heads.py:207-208): the activation itself is never stored.
  * coin_bn_bwd       : given dy (shape of y) computes dsums[0..C) = dbeta, dsums[C..2C) = dgamma (dsums must hold
  *                     (COIN_BN_MAX_PARTS+1)*2*C floats: the result followed by the partial sums), dx (shape of x)
  *                     and, if d_residual != NULL, d_residual = dy * relu'  (shape of y, pool == 1).
- *                     `y` (the saved forward output) supplies the ReLU mask when relu && pool == 1.
+ *                     pool == 0: dy is [N,C], `y` must be the forward's RESIDUAL input (or NULL if there was none)
+ *                     and d_residual, if requested, has the shape of x.
+ *                     `y` (the saved forward output) supplies the ReLU mask when relu && pool == 1 and the forward
+ *                     added a residual; pass y = NULL when it did not: the mask is then recomputed from x and the
+ *                     output tensor is not read at all.
  * ---------------------------------------------------------------------------------------- */
 #define COIN_BN_MAX_PARTS 512
 int coin_bn_stats(const void* x, int N, int H, int W, int C, float eps, float momentum, float* sums_workspace,

@@ -81,6 +81,8 @@ def _bn_act(x, bn, relu, residual=None, pool=1):
         y = y + residual
     if relu:
         y = F.relu(y)
+    if pool == 0:
+        return y.mean(dim=[2, 3], keepdim=True)
     return F.avg_pool2d(y, 2) if pool == 2 else y
 
 
@@ -113,10 +115,12 @@ class _CpuSgdTable:
         self.bufs = [torch.zeros_like(p) for p in self.params]
         self.first = True
 
-    def step(self, grads, momentum, inv_loss_scale=1.0, lrs=None, lr_scale=1.0):
+    def step(self, grads, momentum, inv_loss_scale=1.0, lrs=None, lr_scale=1.0, shadows=None):
         if lrs is not None:
             self.lrs = list(lrs)
         for p, g, b, lr, wd in zip(self.params, grads, self.bufs, self.lrs, self.wds):
+            if g is None:
+                continue
             d = g * inv_loss_scale + wd * p
             b.copy_(d if self.first else momentum * b + d)
             p.sub_(lr * lr_scale * b)

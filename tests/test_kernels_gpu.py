@@ -345,12 +345,14 @@ def test_sgd_table_matches_torch_sgd(K):
     dp = [dev(p.clone()) for p in ps]
     shadows = [torch.empty_like(p, dtype=torch.bfloat16) for p in dp]
     table = K.SgdTable(dp, lrs, wds, shadows)
-    for step in range(3):
+    for step in range(5):
         grads = [torch.randn(s, generator=g) for s in shapes]
+        if step in (0, 3):
+            grads[2] = None  # a tensor without a gradient is skipped (torch.optim.SGD semantics), also on its first step
         for p, gr in zip(ref, grads):
-            p.grad = gr.clone()
+            p.grad = gr.clone() if gr is not None else None
         opt.step()
-        table.step([dev(gr) for gr in grads], momentum=0.9)
+        table.step([dev(gr) if gr is not None else None for gr in grads], momentum=0.9)  # new pointers every step: async re-upload
     for p, r, s in zip(dp, ref, shadows):
         torch.testing.assert_close(p.cpu(), r.detach(), rtol=1e-5, atol=1e-6)
         assert torch.equal(s.cpu(), p.cpu().to(torch.bfloat16))
@@ -371,6 +373,7 @@ def test_ema_golden(K):
 @pytest.mark.parametrize("relu,res,pool,shape", [
     (True, False, 1, (6, 16, 14, 14)), (True, False, 2, (5, 32, 14, 14)), (True, True, 1, (4, 64, 7, 7)),
     (False, False, 1, (3, 2048, 7, 7)), (True, False, 2, (2, 8, 9, 11)), (True, True, 1, (2, 4096, 3, 3)),
+    (True, True, 0, (5, 2048, 7, 7)), (True, False, 0, (3, 64, 5, 3)), (False, True, 0, (2, 16, 7, 7)),  # global-mean epilogue
 ])
 def test_bn_act_vs_torch(dtype, relu, res, pool, shape):
     from coin_amd import layers as L
@@ -396,6 +399,8 @@ def test_bn_act_vs_torch(dtype, relu, res, pool, shape):
         y = F.relu(y)
     if pool == 2:
         y = F.avg_pool2d(y, 2)
+    if pool == 0:
+        y = y.mean(dim=[2, 3], keepdim=True)
     dy = torch.randn(y.shape, generator=g).to(dtype)
     y.backward(dy.double())
     bn = bn.cuda()
