@@ -6,6 +6,7 @@ sites) with device tensors throughout; NMS runs in the HIP kernel ``coin_nms_bat
 """
 from __future__ import annotations
 
+import functools
 import math
 from typing import List, Sequence, Tuple
 
@@ -162,6 +163,13 @@ class PackedProposals:
         return self.boxes.shape[0]
 
 
+@functools.lru_cache(maxsize=64)
+def _sizes_on_device(image_sizes, device):
+    """Image sizes as a device tensor, cached: a pageable host->device copy is a blocking, stream-draining call, and the
+    training batches repeat a handful of size tuples."""
+    return torch.tensor(image_sizes, dtype=torch.float32, device=device)
+
+
 @torch.no_grad()
 def find_top_rpn_proposals(proposals: torch.Tensor, logits: torch.Tensor, image_sizes: List[Tuple[int, int]], nms_thresh: float,
                            pre_nms_topk: int, post_nms_topk: int, min_box_size: float, training: bool, packed: bool = False):
@@ -174,7 +182,7 @@ def find_top_rpn_proposals(proposals: torch.Tensor, logits: torch.Tensor, image_
     boxes = torch.gather(proposals.float(), 1, idx.unsqueeze(-1).expand(-1, -1, 4))
     if training and not packed and not bool(torch.isfinite(boxes).all() & torch.isfinite(top_logits).all()):
         raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")
-    hw = torch.tensor(image_sizes, dtype=torch.float32, device=boxes.device)  # [N, 2] (h, w)
+    hw = _sizes_on_device(tuple(tuple(int(v) for v in sz) for sz in image_sizes), boxes.device)  # [N, 2] (h, w)
     wmax, hmax = hw[:, 1].view(n, 1), hw[:, 0].view(n, 1)
     boxes = torch.stack((torch.minimum(boxes[..., 0].clamp(min=0), wmax), torch.minimum(boxes[..., 1].clamp(min=0), hmax),
                          torch.minimum(boxes[..., 2].clamp(min=0), wmax), torch.minimum(boxes[..., 3].clamp(min=0), hmax)), dim=-1)

@@ -135,48 +135,76 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const T* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------ apply (forward)
-// x: [N, H, W, C]; y: [N, H/pool, W/pool, C] (floor); residual (pool == 1 only): same shape as y
-template <typename T>
+// Streaming kernels below share one thread mapping: the launch has gridDim.x*BN_THREADS = a multiple of ncg = C/V threads,
+// so a thread keeps ONE 16-byte channel group for its whole life (per-channel constants are computed once, in registers)
+// and walks rows with a constant stride: no integer division and no per-channel table reads inside the loop.
+struct RowWalk {
+  int cg;
+  int64_t row0, rstep;
+};
+__device__ __forceinline__ RowWalk row_walk(int ncg) {
+  const int64_t tid = (int64_t)blockIdx.x * BN_THREADS + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * BN_THREADS;
+  RowWalk r;
+  r.cg = (int)(tid % ncg);
+  r.row0 = tid / ncg;
+  r.rstep = nthreads / ncg;
+  return r;
+}
+
+// x: [N, H, W, C]; y: [N, H/POOL, W/POOL, C] (floor); residual (POOL == 1 only): same shape as y
+template <typename T, int POOL>
 __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, const T* __restrict__ residual,
-                                                               T* __restrict__ y, int N, int H, int W, int C, int relu, int pool) {
+                                                               T* __restrict__ y, int N, int H, int W, int C, int relu) {
   constexpr int V = Ld<T>::V;
   const int ncg = C / V;
-  const int OH = H / pool, OW = W / pool;
+  const RowWalk rw = row_walk(ncg);
+  const int OH = H / POOL, OW = W / POOL;
   const int64_t rows = (int64_t)N * OH * OW;
-  const int64_t total = rows * ncg;
-  for (int64_t idx = (int64_t)blockIdx.x * BN_THREADS + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BN_THREADS) {
-    const int cg = (int)(idx % ncg);
-    const int64_t orow = idx / ncg;
-    float sc[V], sh[V];
+  float sc[V], sh[V];
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-      const int c = cg * V + i;
-      sc[i] = rstd[c] * gamma[c];
-      sh[i] = beta[c] - mean[c] * sc[i];
-    }
-    float o[V];
-    if (pool == 1) {
-      float v[V];
-      Ld<T>::load(x + (size_t)orow * C + (size_t)cg * V, v);
-      if (residual) {
-        float rr[V];
-        Ld<T>::load(residual + (size_t)orow * C + (size_t)cg * V, rr);
+  for (int i = 0; i < V; ++i) {
+    const int c = rw.cg * V + i;
+    sc[i] = rstd[c] * gamma[c];
+    sh[i] = beta[c] - mean[c] * sc[i];
+  }
+  const size_t coff = (size_t)rw.cg * V;
+  if (POOL == 1) {
+    if (residual) {
+#pragma unroll 2
+      for (int64_t r = rw.row0; r < rows; r += rw.rstep) {
+        float v[V], rr[V], o[V];
+        Ld<T>::load(x + (size_t)r * C + coff, v);
+        Ld<T>::load(residual + (size_t)r * C + coff, rr);
 #pragma unroll
-        for (int i = 0; i < V; ++i) o[i] = v[i] * sc[i] + sh[i] + rr[i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < V; ++i) o[i] = v[i] * sc[i] + sh[i];
-      }
-      if (relu) {
-#pragma unroll
-        for (int i = 0; i < V; ++i) o[i] = fmaxf(o[i], 0.f);
+        for (int i = 0; i < V; ++i) {
+          o[i] = v[i] * sc[i] + sh[i] + rr[i];
+          if (relu) o[i] = fmaxf(o[i], 0.f);
+        }
+        Ld<T>::store(y + (size_t)r * C + coff, o);
       }
     } else {
-      const int ow = (int)(orow % OW);
-      const int oh = (int)((orow / OW) % OH);
-      const int n = (int)(orow / ((int64_t)OW * OH));
+#pragma unroll 4
+      for (int64_t r = rw.row0; r < rows; r += rw.rstep) {
+        float v[V], o[V];
+        Ld<T>::load(x + (size_t)r * C + coff, v);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          o[i] = v[i] * sc[i] + sh[i];
+          if (relu) o[i] = fmaxf(o[i], 0.f);
+        }
+        Ld<T>::store(y + (size_t)r * C + coff, o);
+      }
+    }
+  } else {
+    for (int64_t r = rw.row0; r < rows; r += rw.rstep) {
+      const int r32 = (int)r;  // rows < 2^31 (checked on the host)
+      const int ow = r32 % OW;
+      const int t = r32 / OW;
+      const int oh = t % OH, n = t / OH;
+      float o[V];
 #pragma unroll
       for (int i = 0; i < V; ++i) o[i] = 0.f;
 #pragma unroll
@@ -184,19 +212,19 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restric
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
           float v[V];
-          Ld<T>::load(x + (((size_t)n * H + (2 * oh + dy)) * W + (2 * ow + dx)) * C + (size_t)cg * V, v);
+          Ld<T>::load(x + (((size_t)n * H + (2 * oh + dy)) * W + (2 * ow + dx)) * C + coff, v);
 #pragma unroll
           for (int i = 0; i < V; ++i) {
-            float t = v[i] * sc[i] + sh[i];
-            if (relu) t = fmaxf(t, 0.f);
+            float tt = v[i] * sc[i] + sh[i];
+            if (relu) tt = fmaxf(tt, 0.f);
             // the un-pooled activation is rounded to the storage type before pooling, as nn.AvgPool2d sees it
-            o[i] += (float)(T)t;
+            o[i] += (float)(T)tt;
           }
         }
 #pragma unroll
       for (int i = 0; i < V; ++i) o[i] *= 0.25f;
+      Ld<T>::store(y + (size_t)r * C + coff, o);
     }
-    Ld<T>::store(y + (size_t)orow * C + (size_t)cg * V, o);
   }
 }
 
@@ -244,42 +272,52 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_mean_kernel(const T* __re
   Ld<T>::store(y + (size_t)n * C + (size_t)cg * V, acc);
 }
 
-// Upstream gradient of the pre-activation at input pixel (n,h,w): dy (through pool / relu mask).
-template <typename T>
+// Upstream gradient g of the pre-activation at row r = (n,h,w) of x, channel group cg (through pool / ReLU mask).
+//   POOL 1: dy has x's shape.  The mask comes from the saved output `yout` when the forward added a residual, otherwise it
+//           is recomputed from x (same expression as bn_apply_kernel) and y is never read.
+//   POOL 2: dy is [N,H/2,W/2,C]; mask recomputed from x.
+//   POOL 0: dy is [N,C] (global mean); `yout` carries the forward's RESIDUAL input (or NULL); mask recomputed.
+template <typename T, int POOL>
 __device__ __forceinline__ void upstream(const T* __restrict__ dy, const T* __restrict__ yout, const float (&xv)[Ld<T>::V],
-                                         const float (&sc)[Ld<T>::V], const float (&sh)[Ld<T>::V], int n, int h, int w, int H, int W,
-                                         int C, int cg, int relu, int pool, float (&g)[Ld<T>::V]) {
+                                         const float (&sc)[Ld<T>::V], const float (&sh)[Ld<T>::V], int64_t r, int H, int W, int C,
+                                         size_t coff, int relu, float (&g)[Ld<T>::V]) {
   constexpr int V = Ld<T>::V;
-  if (pool == 0) {  // global mean: dy is [N,C]; `yout` carries the forward's RESIDUAL input (or NULL), the mask is recomputed
-    Ld<T>::load(dy + (size_t)n * C + (size_t)cg * V, g);
-    const float inv = 1.0f / (float)(H * W);
+  if (POOL == 1) {
+    const size_t off = (size_t)r * C + coff;
+    Ld<T>::load(dy + off, g);
+    if (relu && yout) {
+      float yv[V];
+      Ld<T>::load(yout + off, yv);
+#pragma unroll
+      for (int i = 0; i < V; ++i) g[i] = yv[i] > 0.f ? g[i] : 0.f;
+    } else if (relu) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) g[i] = (xv[i] * sc[i] + sh[i] > 0.f) ? g[i] : 0.f;
+    }
+  } else if (POOL == 0) {
+    const int hw = H * W;
+    const int n = (int)(r / hw);
+    Ld<T>::load(dy + (size_t)n * C + coff, g);
+    const float inv = 1.0f / (float)hw;
     float rr[V];
-    if (yout) Ld<T>::load(yout + (((size_t)n * H + h) * W + w) * C + (size_t)cg * V, rr);
+    if (yout) Ld<T>::load(yout + (size_t)r * C + coff, rr);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       const float pre = xv[i] * sc[i] + sh[i] + (yout ? rr[i] : 0.f);
       g[i] = (relu && !(pre > 0.f)) ? 0.f : g[i] * inv;
     }
-  } else if (pool == 1) {
-    const size_t off = (((size_t)n * H + h) * W + w) * C + (size_t)cg * V;
-    Ld<T>::load(dy + off, g);
-    if (relu && yout) {  // forward had a residual: the mask is only known from the saved output
-      float yv[V];
-      Ld<T>::load(yout + off, yv);
-#pragma unroll
-      for (int i = 0; i < V; ++i) g[i] = yv[i] > 0.f ? g[i] : 0.f;
-    } else if (relu) {  // no residual: recompute the pre-activation from x (same expression as bn_apply_kernel), y is not read
-#pragma unroll
-      for (int i = 0; i < V; ++i) g[i] = (xv[i] * sc[i] + sh[i] > 0.f) ? g[i] : 0.f;
-    }
   } else {
+    const int r32 = (int)r;
+    const int w = r32 % W;
+    const int t = r32 / W;
+    const int h = t % H, n = t / H;
     const int OH = H / 2, OW = W / 2;
     if ((h >> 1) >= OH || (w >> 1) >= OW) {
 #pragma unroll
       for (int i = 0; i < V; ++i) g[i] = 0.f;
       return;
     }
-    Ld<T>::load(dy + (((size_t)n * OH + (h >> 1)) * OW + (w >> 1)) * C + (size_t)cg * V, g);
+    Ld<T>::load(dy + (((size_t)n * OH + (h >> 1)) * OW + (w >> 1)) * C + coff, g);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       g[i] *= 0.25f;
@@ -290,12 +328,12 @@ __device__ __forceinline__ void upstream(const T* __restrict__ dy, const T* __re
 
 // ------------------------------------------------------------------------------------------ backward reductions
 // dsums[0..C) = sum g (= dbeta), dsums[C..2C) = sum g * xhat (= dgamma)
-template <typename T>
+template <typename T, int POOL>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                     const T* __restrict__ yout, const float* __restrict__ mean,
                                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, int N, int H, int W, int C,
-                                                                    int relu, int pool, float* __restrict__ dsums) {
+                                                                    int relu, float* __restrict__ dsums) {
   constexpr int V = Ld<T>::V;
   extern __shared__ float red[];
   const int ncg = C / V;
@@ -315,15 +353,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __re
       sh[i] = beta[c] - mu[i] * sc[i];
       db[i] = dg[i] = 0.f;
     }
+    const size_t coff = (size_t)cg * V;
     if (active) {
 #pragma unroll 2
       for (int64_t r = (int64_t)blockIdx.x * rpi + slot; r < M; r += (int64_t)gridDim.x * rpi) {
-        const int w = (int)(r % W);
-        const int h = (int)((r / W) % H);
-        const int n = (int)(r / ((int64_t)W * H));
         float xv[V], g[V];
-        Ld<T>::load(x + (size_t)r * C + (size_t)cg * V, xv);
-        upstream<T>(dy, yout, xv, sc, sh, n, h, w, H, W, C, cg, relu, pool, g);
+        Ld<T>::load(x + (size_t)r * C + coff, xv);
+        upstream<T, POOL>(dy, yout, xv, sc, sh, r, H, W, C, coff, relu, g);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
           db[i] += g[i];
@@ -371,42 +407,43 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
   if (wave == 0 && i < 2 * C) dsums[i] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
-// dx = gamma * rstd * (g - dbeta/M - xhat * dgamma/M);  d_residual = g (pool == 1 with residual)
-template <typename T>
+// dx = gamma * rstd * (g - dbeta/M - xhat * dgamma/M);  d_residual = g (forward had a residual)
+template <typename T, int POOL>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                 const T* __restrict__ yout, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, const float* __restrict__ dsums,
-                                                                int N, int H, int W, int C, int relu, int pool, T* __restrict__ dx,
+                                                                int N, int H, int W, int C, int relu, T* __restrict__ dx,
                                                                 T* __restrict__ dres) {
   constexpr int V = Ld<T>::V;
   const int ncg = C / V;
+  const RowWalk rw = row_walk(ncg);
   const int64_t M = (int64_t)N * H * W;
-  const int64_t total = M * ncg;
   const float invM = 1.0f / (float)M;
-  for (int64_t idx = (int64_t)blockIdx.x * BN_THREADS + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BN_THREADS) {
-    const int cg = (int)(idx % ncg);
-    const int64_t r = idx / ncg;
-    const int w = (int)(r % W);
-    const int h = (int)((r / W) % H);
-    const int n = (int)(r / ((int64_t)W * H));
-    float sc[V], sh[V], xv[V], g[V], o[V];
+  float sc[V], sh[V], mu[V], rs[V], kb[V], kg[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = rw.cg * V + i;
+    mu[i] = mean[c];
+    rs[i] = rstd[c];
+    sc[i] = rs[i] * gamma[c];
+    sh[i] = beta[c] - mu[i] * sc[i];
+    kb[i] = dsums[c] * invM;
+    kg[i] = dsums[C + c] * invM;
+  }
+  const size_t coff = (size_t)rw.cg * V;
+#pragma unroll 2
+  for (int64_t r = rw.row0; r < M; r += rw.rstep) {
+    float xv[V], g[V], o[V];
+    Ld<T>::load(x + (size_t)r * C + coff, xv);
+    upstream<T, POOL>(dy, yout, xv, sc, sh, r, H, W, C, coff, relu, g);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-      const int c = cg * V + i;
-      sc[i] = rstd[c] * gamma[c];
-      sh[i] = beta[c] - mean[c] * sc[i];
+      const float xhat = (xv[i] - mu[i]) * rs[i];
+      o[i] = sc[i] * (g[i] - kb[i] - xhat * kg[i]);
     }
-    Ld<T>::load(x + (size_t)r * C + (size_t)cg * V, xv);
-    upstream<T>(dy, yout, xv, sc, sh, n, h, w, H, W, C, cg, relu, pool, g);
-#pragma unroll
-    for (int i = 0; i < V; ++i) {
-      const int c = cg * V + i;
-      const float xhat = (xv[i] - mean[c]) * rstd[c];
-      o[i] = sc[i] * (g[i] - dsums[c] * invM - xhat * dsums[C + c] * invM);
-    }
-    Ld<T>::store(dx + (size_t)r * C + (size_t)cg * V, o);
-    if (dres) Ld<T>::store(dres + (size_t)r * C + (size_t)cg * V, g);
+    Ld<T>::store(dx + (size_t)r * C + coff, o);
+    if (dres) Ld<T>::store(dres + (size_t)r * C + coff, g);
   }
 }
 
@@ -469,6 +506,8 @@ int bn_check(const void* x, int N, int H, int W, int C, int pool, int dtype) {
   const int v = dtype == COIN_F32 ? 4 : 8;
   if (C % v) return COIN_ESHAPE;
   if (C / v > BN_THREADS && (C / v) % BN_THREADS) return COIN_ESHAPE;  // uniform trip count of the channel-group loops
+  if (C / v < BN_THREADS && BN_THREADS % (C / v)) return COIN_ESHAPE;   // a thread keeps one channel group (row-walk kernels)
+  if ((int64_t)N * H * W >= (int64_t)1 << 31) return COIN_ESHAPE;
   if ((uintptr_t)x & 15) return COIN_EALIGN;
   return COIN_OK;
 }
@@ -477,6 +516,16 @@ int stream_grid(int64_t work_items) {
   int64_t g = (work_items + BN_THREADS - 1) / BN_THREADS;
   if (g > 256 * 16) g = 256 * 16;
   return (int)(g < 1 ? 1 : g);
+}
+
+// Grid for the row-walk kernels: gridDim.x * BN_THREADS must be a multiple of ncg (bn_check guarantees ncg <= BN_THREADS and
+// a power-of-two-free divisor relation, or ncg = k * BN_THREADS), and enough workgroups to fill 256 CUs several times over.
+int walk_grid(int64_t rows, int ncg) {
+  const int unit = ncg <= BN_THREADS ? 1 : ncg / BN_THREADS;  // blocks per full row of channel groups
+  int64_t g = (rows * ncg + BN_THREADS - 1) / BN_THREADS;
+  if (g > 256 * 16) g = 256 * 16;
+  g = (g + unit - 1) / unit * unit;
+  return (int)(g < unit ? unit : g);
 }
 
 }  // namespace
@@ -529,8 +578,12 @@ extern "C" int coin_bn_apply_fwd(const void* x, const float* mean, const float* 
 #undef GO
     return coin_launch_status();
   }
-  const int64_t items = (int64_t)N * (H / pool) * (W / pool) * (C / v);
-#define GO(T) bn_apply_kernel<T><<<stream_grid(items), BN_THREADS, 0, st>>>((const T*)x, mean, rstd, gamma, beta, (const T*)residual, (T*)y, N, H, W, C, relu, pool)
+  const int grid = walk_grid((int64_t)N * (H / pool) * (W / pool), C / v);
+#define GO(T)                                                                                                                     \
+  if (pool == 1)                                                                                                                  \
+    bn_apply_kernel<T, 1><<<grid, BN_THREADS, 0, st>>>((const T*)x, mean, rstd, gamma, beta, (const T*)residual, (T*)y, N, H, W, C, relu); \
+  else                                                                                                                            \
+    bn_apply_kernel<T, 2><<<grid, BN_THREADS, 0, st>>>((const T*)x, mean, rstd, gamma, beta, (const T*)residual, (T*)y, N, H, W, C, relu)
   BN_DISPATCH(dtype, GO(float), GO(bf16_t));
 #undef GO
   return coin_launch_status();
@@ -552,11 +605,22 @@ extern "C" int coin_bn_bwd(const void* x, const void* dy, const void* y, const f
   int64_t g = (M + rpi - 1) / rpi;
   if (g > COIN_BN_MAX_PARTS) g = COIN_BN_MAX_PARTS;
   const size_t lds = sizeof(float) * BN_THREADS * 2 * v;
-#define GO(T) bn_bwd_reduce_kernel<T><<<(int)g, BN_THREADS, lds, st>>>((const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, beta, N, H, W, C, relu, pool, dsums); \
-  bn_bwd_finalize_kernel<<<(2 * C + 63) / 64, 256, 0, st>>>(dsums, (int)g, C); \
-  bn_bwd_dx_kernel<T><<<stream_grid(M * ncg), BN_THREADS, 0, st>>>((const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, beta, dsums, N, H, W, C, relu, pool, (T*)dx, (T*)d_residual)
+  const int wg = walk_grid(M, ncg);
+#define GO1(T, P)                                                                                                                  \
+  bn_bwd_reduce_kernel<T, P><<<(int)g, BN_THREADS, lds, st>>>((const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, beta, N, H, W, C, relu, dsums); \
+  bn_bwd_finalize_kernel<<<(2 * C + 63) / 64, 256, 0, st>>>(dsums, (int)g, C);                                                      \
+  bn_bwd_dx_kernel<T, P><<<wg, BN_THREADS, 0, st>>>((const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, beta, dsums, N, H, W, C, relu, (T*)dx, (T*)d_residual)
+#define GO(T)                 \
+  if (pool == 1) {            \
+    GO1(T, 1);                \
+  } else if (pool == 2) {     \
+    GO1(T, 2);                \
+  } else {                    \
+    GO1(T, 0);                \
+  }
   BN_DISPATCH(dtype, GO(float), GO(bf16_t));
 #undef GO
+#undef GO1
   return coin_launch_status();
 }
 
