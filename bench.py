@@ -33,6 +33,29 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0
 FLOP_PER_VIEW = 4.259e12     # fwd 1449 + bwd 2811 GFLOP per 800x1333 view, RN50-C4, 512 RoIs
 
 
+# C-ABI entry point -> the device kernels one call launches (rocprofv3 lists these; their average durations add up to the
+# entry point's `mean_launch_ms`)
+ENTRY_KERNELS = {
+    "coin_roi_align_fwd": ["roi_align_fwd_nhwc_kernel"], "coin_roi_align_bwd": ["roi_align_bwd_nhwc_kernel"],
+    "coin_bn_stats": ["bn_stats_kernel", "bn_finalize_kernel"], "coin_bn_apply_fwd": ["bn_apply_kernel | bn_apply_mean_kernel"],
+    "coin_bn_bwd": ["bn_bwd_reduce_kernel", "bn_bwd_finalize_kernel", "bn_bwd_dx_kernel"], "coin_gemm_nt": ["gemm_nt_bf16_kernel"],
+}
+
+
+def pmc_traffic(entry: str, alg_bytes: float):
+    """HBM bytes per launch from the committed PMC passes (profiles/r1_pmc_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB
+    units, MI355X_MICROARCH.md) -- only when that pass measured this entry point at this launch size, else None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+            table = json.load(f)
+        rec = table.get(entry)
+        if rec and abs(rec["alg_bytes"] - alg_bytes) <= 0.01 * alg_bytes:
+            return rec["hbm_bytes"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def build_cfg(world: int, device: str, dtype: str, extra=()):
     from coin_amd.config import get_cfg
 
@@ -151,7 +174,7 @@ def main():
     for _ in range(args.warmup):
         trainer.run_step()
     sync()
-    timed = ["coin_roi_align_fwd", "coin_roi_align_bwd", "coin_gemm_nt"]
+    timed = ["coin_roi_align_fwd", "coin_roi_align_bwd", "coin_gemm_nt", "coin_bn_stats", "coin_bn_apply_fwd", "coin_bn_bwd"]
     K.timing_begin(timed)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -174,9 +197,10 @@ def main():
         detail = {}
         for name, (n, ms, units) in ktimes.items():
             if name == "coin_gemm_nt":
-                detail[name] = {"launches": n, "mean_ms": ms, "TFLOP/s": units / (ms * 1e-3) / 1e12}
+                detail[name] = {"launches": n, "mean_ms": ms, "total_ms_per_step": n * ms / args.steps, "TFLOP/s": units / (ms * 1e-3) / 1e12}
             else:
-                detail[name] = {"launches": n, "mean_ms": ms, "GB/s": units / (ms * 1e-3) / 1e9, "alg_bytes": units}
+                detail[name] = {"launches": n, "mean_ms": ms, "total_ms_per_step": n * ms / args.steps, "GB/s": units / (ms * 1e-3) / 1e9,
+                                "alg_bytes": units, "device_kernels": ENTRY_KERNELS.get(name)}
         if best is not None:
             name, (n, ms, units) = best
             if name == "coin_gemm_nt":
@@ -186,7 +210,8 @@ def main():
             else:
                 ach = units / (ms * 1e-3) / 1e9
                 roofline = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                            "frac": ach / HBM_PEAK_GBPS, "traffic": None}
+                            "frac": ach / HBM_PEAK_GBPS, "traffic": pmc_traffic(name, units), "alg_bytes_per_launch": units,
+                            "device_kernels": ENTRY_KERNELS.get(name)}
             roofline["launches_timed"] = n
             roofline["mean_launch_ms"] = ms
         out = {

@@ -83,6 +83,10 @@ class _timed:
         return False
 
 
+def _nbytes(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.numel() * t.element_size()
+
+
 def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
     if t.dtype != torch.float32 or not t.is_contiguous():
         raise CoinHipError(f"{name} must be contiguous float32")
@@ -336,8 +340,9 @@ def bn_stats(x: torch.Tensor, eps: float, momentum: float, running_mean: Optiona
     ws = torch.empty(BN_MAX_PARTS * 2 * c, dtype=torch.float32, device=x.device)
     mean = torch.empty(c, dtype=torch.float32, device=x.device)
     rstd = torch.empty(c, dtype=torch.float32, device=x.device)
-    check(_lib.lib().coin_bn_stats(_p(x), n, h, w, c, float(eps), float(momentum), _p(ws), _p(mean), _p(rstd), _p(running_mean),
-                                   _p(running_var), _dt(x), _stream()), "coin_bn_stats")
+    with _timed("coin_bn_stats", _nbytes(x)):
+        check(_lib.lib().coin_bn_stats(_p(x), n, h, w, c, float(eps), float(momentum), _p(ws), _p(mean), _p(rstd), _p(running_mean),
+                                       _p(running_var), _dt(x), _stream()), "coin_bn_stats")
     return mean, rstd
 
 
@@ -348,9 +353,10 @@ def bn_apply_fwd(x: torch.Tensor, mean, rstd, gamma, beta, residual: Optional[to
     y = torch.empty((n, 1, 1, c) if pool == 0 else (n, h // pool, w // pool, c), dtype=x.dtype, device=x.device)
     if residual is not None and (residual.shape != x.shape or pool == 2 or residual.dtype != x.dtype or not residual.is_contiguous()):
         raise CoinHipError("residual must match the pre-pool activation (contiguous NHWC, same dtype)")
-    check(_lib.lib().coin_bn_apply_fwd(_p(x), _p(_f32c(mean, "mean")), _p(_f32c(rstd, "rstd")), _p(_f32c(gamma, "gamma")),
-                                       _p(_f32c(beta, "beta")), _p(residual), _p(y), n, h, w, c, int(relu), int(pool), _dt(x), _stream()),
-          "coin_bn_apply_fwd")
+    with _timed("coin_bn_apply_fwd", _nbytes(x) + _nbytes(residual) + _nbytes(y)):
+        check(_lib.lib().coin_bn_apply_fwd(_p(x), _p(_f32c(mean, "mean")), _p(_f32c(rstd, "rstd")), _p(_f32c(gamma, "gamma")),
+                                           _p(_f32c(beta, "beta")), _p(residual), _p(y), n, h, w, c, int(relu), int(pool), _dt(x), _stream()),
+              "coin_bn_apply_fwd")
     return y
 
 
@@ -366,8 +372,12 @@ def bn_bwd(x: torch.Tensor, dy: torch.Tensor, y: Optional[torch.Tensor], mean, r
     dsums = torch.empty((BN_MAX_PARTS + 1) * 2 * c, dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
-    check(_lib.lib().coin_bn_bwd(_p(x), _p(dy), _p(y), _p(mean), _p(rstd), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")), n, h, w, c,
-                                 int(relu), int(pool), _p(dsums), _p(dx), _p(dres), _dt(x), _stream()), "coin_bn_bwd")
+    # algorithmic bytes of the two-pass backward: the channel sums must be complete before any dx can be formed and the
+    # tensors are far larger than the caches, so every input is streamed twice; outputs once
+    alg = 2 * (_nbytes(x) + _nbytes(dy) + _nbytes(y)) + _nbytes(dx) + _nbytes(dres)
+    with _timed("coin_bn_bwd", alg):
+        check(_lib.lib().coin_bn_bwd(_p(x), _p(dy), _p(y), _p(mean), _p(rstd), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")), n, h, w, c,
+                                     int(relu), int(pool), _p(dsums), _p(dx), _p(dres), _dt(x), _stream()), "coin_bn_bwd")
     return dx, dsums[c:2 * c], dsums[:c], dres
 
 
