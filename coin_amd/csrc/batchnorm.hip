@@ -97,30 +97,33 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restric
   }
 }
 
-// mean / rstd from the per-block pivoted partial sums (+ running statistics).  Block = 64 channels x 4 waves; each wave
-// sums every 4th partial with coalesced 256-byte reads, the four are combined through LDS in a fixed order.
+// mean / rstd from the per-block pivoted partial sums (+ running statistics).  Block = 64 channels x 16 waves: waves 0-7 sum
+// the first-moment partials p = w, w+8, ..., waves 8-15 the second-moment ones, each with coalesced 256-byte reads; the 8 + 8
+// wave results are combined through LDS in a fixed order (bit-reproducible).
 template <typename T>
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const T* __restrict__ x, const float* __restrict__ sums, int nparts, int64_t M,
-                                                           int C, float eps, float momentum, float* __restrict__ mean,
-                                                           float* __restrict__ rstd, float* __restrict__ running_mean,
-                                                           float* __restrict__ running_var) {
-  __shared__ float red[2][4][64];
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const T* __restrict__ x, const float* __restrict__ sums, int nparts, int64_t M,
+                                                            int C, float eps, float momentum, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, float* __restrict__ running_mean,
+                                                            float* __restrict__ running_var) {
+  __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
-  float a1 = 0.f, a2 = 0.f;
+  const int which = wave >> 3, w8 = wave & 7;
+  float a = 0.f;
   if (c < C) {
+    const float* __restrict__ src = sums + (size_t)which * C + c;
 #pragma unroll 4
-    for (int p = wave; p < nparts; p += 4) {
-      a1 += sums[(size_t)p * 2 * C + c];
-      a2 += sums[(size_t)p * 2 * C + C + c];
-    }
+    for (int p = w8; p < nparts; p += 8) a += src[(size_t)p * 2 * C];
   }
-  red[0][wave][lane] = a1;
-  red[1][wave][lane] = a2;
+  red[wave][lane] = a;
   __syncthreads();
   if (wave != 0 || c >= C) return;
-  a1 = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
-  a2 = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+  float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    a1 += red[k][lane];
+    a2 += red[8 + k][lane];
+  }
   const float piv = (float)x[c];
   const float m1 = a1 / (float)M;
   const float var = fmaxf(a2 / (float)M - m1 * m1, 0.f);
@@ -393,18 +396,23 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __re
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict__ dsums, int nparts, int C) {
-  __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(float* __restrict__ dsums, int nparts, int C) {
+  __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
   float a = 0.f;
   if (i < 2 * C) {
 #pragma unroll 4
-    for (int p = 1 + wave; p <= nparts; p += 4) a += dsums[(size_t)p * 2 * C + i];
+    for (int p = 1 + wave; p <= nparts; p += 16) a += dsums[(size_t)p * 2 * C + i];
   }
   red[wave][lane] = a;
   __syncthreads();
-  if (wave == 0 && i < 2 * C) dsums[i] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+  if (wave == 0 && i < 2 * C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][lane];
+    dsums[i] = t;
+  }
 }
 
 // dx = gamma * rstd * (g - dbeta/M - xhat * dgamma/M);  d_residual = g (forward had a residual)
@@ -554,7 +562,7 @@ extern "C" int coin_bn_stats(const void* x, int N, int H, int W, int C, float ep
   if (g > COIN_BN_MAX_PARTS) g = COIN_BN_MAX_PARTS;
   const size_t lds = sizeof(float) * BN_THREADS * 2 * v;
 #define GO(T) bn_stats_kernel<T><<<(int)g, BN_THREADS, lds, st>>>((const T*)x, M, C, sums_workspace); \
-  bn_finalize_kernel<T><<<(C + 63) / 64, 256, 0, st>>>((const T*)x, sums_workspace, (int)g, M, C, eps, momentum, mean, rstd, running_mean, running_var)
+  bn_finalize_kernel<T><<<(C + 63) / 64, 1024, 0, st>>>((const T*)x, sums_workspace, (int)g, M, C, eps, momentum, mean, rstd, running_mean, running_var)
   BN_DISPATCH(dtype, GO(float), GO(bf16_t));
 #undef GO
   return coin_launch_status();
@@ -608,7 +616,7 @@ extern "C" int coin_bn_bwd(const void* x, const void* dy, const void* y, const f
   const int wg = walk_grid(M, ncg);
 #define GO1(T, P)                                                                                                                  \
   bn_bwd_reduce_kernel<T, P><<<(int)g, BN_THREADS, lds, st>>>((const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, beta, N, H, W, C, relu, dsums); \
-  bn_bwd_finalize_kernel<<<(2 * C + 63) / 64, 256, 0, st>>>(dsums, (int)g, C);                                                      \
+  bn_bwd_finalize_kernel<<<(2 * C + 63) / 64, 1024, 0, st>>>(dsums, (int)g, C);                                                      \
   bn_bwd_dx_kernel<T, P><<<wg, BN_THREADS, 0, st>>>((const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, beta, dsums, N, H, W, C, relu, (T*)dx, (T*)d_residual)
 #define GO(T)                 \
   if (pool == 1) {            \

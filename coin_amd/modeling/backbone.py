@@ -201,6 +201,12 @@ class ModifiedResNet(nn.Module):
     def output_shape(self):
         return {n: ShapeSpec(channels=self._out_feature_channels[n], stride=self._out_feature_strides[n]) for n in self._out_features}
 
+    @staticmethod
+    def res4_hw(h: int, w: int):
+        """Spatial size of res4 for an [h, w] input: stride-2 3x3 conv (pad 1), then three floor-halving average pools."""
+        f = lambda v: ((v + 1) // 2) // 2 // 2 // 2
+        return f(int(h)), f(int(w))
+
 
 class _ImageEncoder(nn.Module):
     def __init__(self, visual):

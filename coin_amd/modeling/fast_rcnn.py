@@ -138,8 +138,19 @@ class FastRCNNOutputLayers(nn.Module):
             return scores, proposal_deltas, class_feats
         return scores, proposal_deltas
 
+    def prefetch_text(self):
+        """Run the prompt-conditioned text encoder ahead of `forward` (it does not depend on the images): the caller puts it
+        on a side stream so that its ~300 small launches overlap the backbone convolutions.  Consumed by the next forward."""
+        self._text_prefetch = self.text_encoder(added=True)
+        return self._text_prefetch
+
+    _text_prefetch = None
+
     def do_classify(self, image_features, branch):
-        text = self.text_encoder(added=True)
+        if self._text_prefetch is not None:
+            text, self._text_prefetch = self._text_prefetch, None
+        else:
+            text = self.text_encoder(added=True)
         # the kernel L2-normalises both operands (the encoder output is already unit-norm: normalising twice, as the
         # reference does at fast_rcnn.py:344, is the identity up to rounding)
         scores = L.cosine_logits(image_features, text, self._inv_scale)

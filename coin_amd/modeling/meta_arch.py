@@ -72,6 +72,28 @@ class OpenVocabularyRCNN(nn.Module):
         self.target_device = device
         return result
 
+    overlap_streams = True
+
+    def _overlap_side_work(self, images, rpn_targets):
+        """Work of the pre_train step that does not depend on the network's activations -- the prompt-conditioned text encoder
+        (~300 small launches) and the anchor labelling / sampling (~150) -- is issued on a second HIP stream so that it runs
+        concurrently with the backbone convolutions instead of serialising ~3 ms of tiny kernels on the main stream.
+        Autograd replays the text encoder's backward on the same side stream.  Returns the stream to wait on (or None)."""
+        pg, bp = self.proposal_generator, self.roi_heads.box_predictor
+        if not (self.overlap_streams and images.tensor.is_cuda and pg is not None and pg.sync_free and hasattr(self.backbone, "encoder")):
+            return None
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(device=images.tensor.device)
+        side, cur = self._side_stream, torch.cuda.current_stream()
+        side.wait_stream(cur)
+        hw = self.backbone.encoder.visual.res4_hw(*images.tensor.shape[-2:])
+        with torch.cuda.stream(side):
+            text = bp.prefetch_text()
+            labels, boxes = pg.prefetch_labels(hw, images.tensor.device, rpn_targets)
+        for t in [text, *labels, *boxes]:
+            t.record_stream(cur)
+        return side
+
     def _autocast(self):
         return torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.compute_dtype == torch.bfloat16)
 
@@ -87,11 +109,15 @@ class OpenVocabularyRCNN(nn.Module):
         dev = self.pixel_mean.device
         images = self.preprocess_image(batched_inputs)
         with self._autocast():
-            features = self.backbone(images.tensor)
             if branch == "pre_train":
                 rcnn = [x["RCNN"].to(dev) for x in batched_inputs]
                 rpn = [x["RPN"].to(dev) for x in batched_inputs]
                 merge_module = None
+                side = self._overlap_side_work(images, rpn)
+            features = self.backbone(images.tensor)
+            if branch == "pre_train":
+                if side is not None:
+                    torch.cuda.current_stream().wait_stream(side)
             elif branch in ("step_one", "step_two"):
                 assert dual_teacher_instances is not None, "dual_teacher_instances must not be None when brach is step_one and step_two"
                 rcnn, rpn = dual_teacher_instances

@@ -54,9 +54,13 @@ class DefaultAnchorGenerator(nn.Module):
 
     def forward(self, features: List[torch.Tensor]) -> List[Boxes]:
         f = features[0]
-        key = (tuple(f.shape[-2:]), str(f.device))
+        return self.for_hw(tuple(f.shape[-2:]), f.device)
+
+    def for_hw(self, hw: Tuple[int, int], device) -> List[Boxes]:
+        """Anchors of an [h, w] feature map (they depend on nothing else): lets the labelling run before the backbone."""
+        key = (tuple(int(v) for v in hw), str(device))
         if key not in self._cache:
-            self._cache[key] = grid_anchors(self.cell_anchors_0, f.shape[-2:], self.strides[0], self.offset, f.device)
+            self._cache[key] = grid_anchors(self.cell_anchors_0, key[0], self.strides[0], self.offset, device)
         return [Boxes(self._cache[key])]
 
 
@@ -77,6 +81,13 @@ class DualTeacherRPN(nn.Module):
         # sync-free mode (pre_train branch): anchor sampling by random keys + one sort, fixed-shape proposals; the host
         # never waits for the device inside the step.  Off = the reference's randperm stream (used by the golden tests).
         self.sync_free = False
+        self._prefetched = None
+
+    def prefetch_labels(self, feature_hw, device, gt_instances):
+        """Anchor labelling + sampling of the sync-free pre_train step ahead of time (it depends only on the anchor grid and
+        the teacher boxes, not on the network): the caller runs it on a side stream concurrently with the backbone."""
+        self._prefetched = self.label_and_sample_anchors_sync_free(self.anchor_generator.for_hw(feature_hw, device), gt_instances)
+        return self._prefetched
 
     @classmethod
     def from_config(cls, cfg, input_shape):
@@ -111,7 +122,11 @@ class DualTeacherRPN(nn.Module):
         if self.training and branch != "test":
             assert gt_instances is not None, "RPN requires gt_instances in training!"
             if branch == "pre_train" and self.sync_free:
-                labels, gt_boxes = self.label_and_sample_anchors_sync_free(anchors, gt_instances)
+                if self._prefetched is not None:
+                    (labels, gt_boxes), self._prefetched = self._prefetched, None
+                    assert labels[0].shape[0] == len(anchors[0]), "prefetched anchor labels do not match the feature map"
+                else:
+                    labels, gt_boxes = self.label_and_sample_anchors_sync_free(anchors, gt_instances)
                 losses = self.losses(anchors, logits, labels, deltas, gt_boxes)
             elif branch == "pre_train":
                 labels, gt_boxes = self.label_and_sample_anchors(anchors, gt_instances, branch)
