@@ -36,7 +36,7 @@ FLOP_PER_VIEW = 4.259e12     # fwd 1449 + bwd 2811 GFLOP per 800
 # C-ABI entry point -> the device kernels one call launches (rocprofv3 lists these; their average durations add up to the
 # entry point's `mean_launch_ms`)
 ENTRY_KERNELS = {
-    "coin_roi_align_fwd": ["roi_align_fwd_nhwc_kernel"], "coin_roi_align_bwd": ["roi_align_bwd_nhwc_kernel"],
+    "coin_roi_align_fwd": ["roi_align_fwd_nhwc_kernel"], "coin_roi_align_bwd": ["roi_align_bwd_tiled_kernel"],
     "coin_bn_stats": ["bn_stats_kernel", "bn_finalize_kernel"], "coin_bn_apply_fwd": ["bn_apply_kernel | bn_apply_mean_kernel"],
     "coin_bn_bwd": ["bn_bwd_reduce_kernel", "bn_bwd_finalize_kernel", "bn_bwd_dx_kernel"], "coin_gemm_nt": ["gemm_nt_bf16_kernel"],
 }

@@ -125,13 +125,13 @@ def roi_align_fwd(feat: torch.Tensor, rois: torch.Tensor, output_size: Tuple[int
 def roi_align_bwd(grad_out: torch.Tensor, rois: torch.Tensor, feat_shape: Sequence[int], spatial_scale: float,
                   sampling_ratio: int = 0, aligned: bool = True, layout: int = COIN_NHWC,
                   grad_feat: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Returns (or accumulates into) the float32 gradient map of shape ``feat_shape``."""
+    """Returns the float32 gradient map of shape ``feat_shape`` (`grad_feat`, if given, is overwritten)."""
     _dev(grad_out, rois, grad_feat)
     if not grad_out.is_contiguous():
         raise CoinHipError("grad_out must be contiguous")
     rois = _f32c(rois, "rois")
     if grad_feat is None:
-        grad_feat = torch.zeros(tuple(feat_shape), dtype=torch.float32, device=grad_out.device)
+        grad_feat = torch.empty(tuple(feat_shape), dtype=torch.float32, device=grad_out.device)
     else:
         _f32c(grad_feat, "grad_feat")
     if layout == COIN_NCHW:

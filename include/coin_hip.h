@@ -62,9 +62,10 @@ int coin_roi_align_fwd(const void* feat, int N, int C, int H, int W, int layout,
 
 /* Adjoint of coin_roi_align_fwd (torchvision roi_align backward).
  * grad_out : same shape/layout/dtype as `out` above.
- * grad_feat: [N,C,H,W] / [N,H,W,C] FLOAT32, ACCUMULATED INTO (caller zeroes it; several calls
- *            may add into the same map, e.g. the proposal pass and the C-box pass of
- *            clip_roi_heads.py:201-219).  Float atomics: summation order is not fixed.
+ * grad_feat: [N,C,H,W] / [N,H,W,C] FLOAT32, fully OVERWRITTEN (no need to zero it; R == 0 writes zeros).
+ *            NHWC with ph, pw <= 16 runs the atomic-free tiled gather: every element is written once, RoIs are
+ *            summed in index order (bit-reproducible).  Larger bins and NCHW fall back to zero-fill + float
+ *            atomics (summation order not fixed).
  * workspace: none. */
 int coin_roi_align_bwd(const void* grad_out, int N, int C, int H, int W, int layout,
                        const float* rois, int R, int ph, int pw, float spatial_scale,

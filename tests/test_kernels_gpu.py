@@ -105,6 +105,26 @@ def test_roi_align_res4_shape_vs_oracle(K, dtype):
     torch.testing.assert_close(gin.double(), fd.grad, rtol=2e-4, atol=2e-4)
 
 
+def test_roi_align_bwd_many_rois_large_bins_and_reproducibility(K):
+    """More RoIs than one LDS list chunk (4096) on the tiled path; 20x20 bins take the zero-fill + atomics fallback;
+    the tiled path sums RoIs in index order, so two runs agree bit for bit."""
+    from oracle import d2
+
+    g = torch.Generator().manual_seed(8)
+    n, c, h, w, r = 2, 8, 21, 19, 4500
+    rois = make_rois(n, r, h * 16, w * 16, g)
+    for ph in (14, 20):
+        go = torch.randn(r, ph, ph, c, generator=g)
+        fd = torch.zeros(n, c, h, w, dtype=torch.float64, requires_grad=True)
+        d2.roi_align_torch(fd, rois.double(), (ph, ph), 1 / 16.0, 0, True).backward(go.double().permute(0, 3, 1, 2))
+        stale = torch.full((n, h, w, c), 7.0, device="cuda")  # the output buffer is overwritten, not accumulated into
+        gin = K.roi_align_bwd(dev(go), dev(rois), (n, h, w, c), 1 / 16.0, grad_feat=stale)
+        torch.testing.assert_close(gin.permute(0, 3, 1, 2).cpu().double(), fd.grad, rtol=2e-4, atol=2e-4)
+        if ph == 14:
+            again = K.roi_align_bwd(dev(go), dev(rois), (n, h, w, c), 1 / 16.0)
+            assert torch.equal(gin, again)
+
+
 def test_roi_align_full_size_properties(K):
     """BASELINE size (4 views x 512 RoIs, C=1024, bf16): constant map -> 1 inside the image; adjointness."""
     g = torch.Generator().manual_seed(7)
