@@ -14,11 +14,12 @@ feat = torch.randn(n, h, w, c, device="cuda").to(torch.bfloat16)
 go = torch.randn(r, 14, 14, c, device="cuda").to(torch.bfloat16)
 x = torch.randn(2048, 7, 7, 2048, device="cuda").to(torch.bfloat16)
 res = torch.randn_like(x)
+dy = torch.randn_like(x)
 gam, bet = torch.rand(2048, device="cuda") + 0.5, torch.randn(2048, device="cuda")
 for _ in range(3):
     out = K.roi_align_fwd(feat, rois, (14, 14), 1 / 16.0)
     gf = K.roi_align_bwd(go, rois, (n, h, w, c), 1 / 16.0)
     mean, rstd = K.bn_stats(x, 1e-5, 0.1)
     y = K.bn_apply_fwd(x, mean, rstd, gam, bet, res, True, 1)
-    K.bn_bwd(x, y, y, mean, rstd, gam, bet, True, 1, True)
+    K.bn_bwd(x, dy, y, mean, rstd, gam, bet, True, 1, True)
 torch.cuda.synchronize()
