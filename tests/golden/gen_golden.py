@@ -850,10 +850,103 @@ def case_ema():
     ens.update_params(0.9996, "offline")
     npz("ema", **before, **{"s::" + k: v for k, v in s.state_dict().items()}, **{"after::" + k: v for k, v in t.state_dict().items()})
 
+# --------------------------------------------------------------------------- #
+# CoinTrainer: dual-teacher box matching (trainer.py:338-485, util.py:434-507)
+# --------------------------------------------------------------------------- #
+def import_ref_trainer():
+    """coin/engine/trainer.py imports the whole training stack; everything that is not the matching logic is stubbed."""
+    for n in ("coin.data", "coin.data.build", "coin.data.dataset_mapper", "coin.evaluation", "coin.engine.hooks", "coin.checkpoint",
+              "coin.checkpoint.detection_checkpoint", "fvcore.common", "fvcore.common.checkpoint", "detectron2.engine.hooks"):
+        if n not in sys.modules:
+            shim._mod(n)
+    shim.install()
+    ma = sys.modules["coin.modeling.meta_arch"]
+    if not hasattr(ma, "build_model"):
+        ma.build_model = None
+        ma.EnsembleTSModel = shim.ref("coin.modeling.meta_arch.ts_ensemble").EnsembleTSModel
+    if not hasattr(sys.modules["detectron2.engine"], "hooks"):
+        sys.modules["detectron2.engine"].hooks = sys.modules["detectron2.engine.hooks"]
+    return shim.ref("coin.engine.trainer")
+
+
+def _teacher_inst(boxes, classes, probs, size):
+    """What BASE_Trainer.process leaves on an online / offline result: gt_boxes, gt_classes, scores, probs."""
+    util = shim.ref("coin.utils.util")
+    inst = util.MyInstances(size)
+    inst.gt_boxes = d2.Boxes(boxes.clone())
+    inst.gt_classes = classes.clone()
+    inst.probs = probs.clone()
+    inst.scores = probs[:, :-1].max(dim=1).values.clone()
+    return inst
+
+
+def _match_cases():
+    """name -> (online boxes/classes, offline boxes/classes) designed to hit every branch of match_dual_teacher."""
+    B = lambda rows: torch.tensor(rows, dtype=torch.float32)
+    C = lambda xs: torch.tensor(xs, dtype=torch.long)
+    base_on = B([[10, 10, 60, 70], [80, 20, 140, 90], [30, 100, 90, 150], [150, 60, 200, 120], [5, 5, 25, 25], [100, 100, 160, 150]])
+    cases = {}
+    # normal: A (same class), B (different class), offline-only C, online-only C, one online box matched by two offline boxes
+    cases["normal"] = (base_on, C([0, 1, 2, 0, 1, 2]),
+                       B([[12, 12, 62, 68], [82, 22, 138, 88], [28, 98, 92, 152], [210, 10, 250, 60], [101, 99, 158, 149], [98, 102, 161, 152], [60, 160, 100, 190]]),
+                       C([0, 2, 2, 1, 2, 0, 1]))
+    cases["online_empty"] = (B([]).reshape(0, 4), C([]), B([[12, 12, 62, 68], [82, 22, 138, 88], [28, 98, 92, 152], [210, 10, 250, 60]]), C([0, 2, 2, 1]))
+    cases["offline_empty"] = (base_on[:4], C([0, 1, 2, 0]), B([]).reshape(0, 4), C([]))
+    cases["both_empty"] = (B([]).reshape(0, 4), C([]), B([]).reshape(0, 4), C([]))
+    # the teacher's class-wise NMS emits the SAME box under several labels: duplicates matched (same label present / absent) and unmatched
+    cases["offline_duplicates"] = (base_on, C([0, 1, 2, 0, 1, 2]),
+                                   B([[12, 12, 62, 68], [12, 12, 62, 68], [82, 22, 138, 88], [82, 22, 138, 88], [28, 98, 92, 152], [220, 130, 260, 180], [220, 130, 260, 180],
+                                      [220, 130, 260, 180], [150, 62, 199, 118]]),
+                                   C([0, 1, 2, 0, 2, 0, 1, 2, 0]))
+    # two online boxes with IoU >= 0.95 and different classes, both matched: online_boxes_merging (consistent / inconsistent offline votes)
+    cases["online_self_overlap"] = (B([[10, 10, 60, 70], [10, 10, 60, 70.5], [80, 20, 140, 90], [80.2, 20, 140, 90], [30, 100, 90, 150]]), C([0, 1, 1, 2, 2]),
+                                    B([[11, 11, 61, 69], [81, 21, 139, 89], [79, 19, 141, 91], [29, 99, 91, 151]]), C([0, 1, 2, 2]))
+    return cases
+
+
+def case_match_dual_teacher():
+    import random
+    tr = import_ref_trainer()
+    out_all = {}
+    g = torch.Generator().manual_seed(171)
+    size = (200, 300)
+    for name, (bon, con, boff, coff) in _match_cases().items():
+        pon, poff = rand_probs(len(bon), g), rand_probs(len(boff), g)
+        # make argmax of the teacher probabilities agree with the labels (as the collectors guarantee)
+        for p, c in ((pon, con), (poff, coff)):
+            if len(c):
+                top = p[:, :-1].max(dim=1).values
+                p[torch.arange(len(c)), c] = top + 0.05
+                p /= p.sum(dim=1, keepdim=True)
+        if name == "online_empty":  # scores around the 0.8 split of trainer.py:351
+            poff[0] = torch.tensor([0.9, 0.04, 0.03, 0.03])
+            poff[1] = torch.tensor([0.05, 0.05, 0.85, 0.05])
+        out_all.update({f"{name}::on_boxes": bon, f"{name}::on_classes": con, f"{name}::on_probs": pon,
+                        f"{name}::off_boxes": boff, f"{name}::off_classes": coff, f"{name}::off_probs": poff})
+        for wname, weight in (("w1", 1.0), ("w05", 0.5)):
+            for tag in ("RCNN", "RPN"):
+                stub = type("Stub", (), {})()
+                stub.cfg = type("Cfg", (), {})()
+                stub.cfg.CLOUD = type("Cloud", (), {})()
+                stub.cfg.CLOUD.MATCHER = type("Matcher", (), {"IOU_THRESHOLDS": 0.5})()
+                stub.WEIGHT_FOR_BOX_A = weight
+                stub.merge_boxes = lambda *a, _s=stub: tr.CoinTrainer.merge_boxes(_s, *a)
+                online = {"RCNN": _teacher_inst(bon, con, pon, size), "RPN": _teacher_inst(bon, con, pon, size)}
+                offline = _teacher_inst(boff, coff, poff, size)
+                random.seed(1234)
+                a, b, c = tr.CoinTrainer.match_dual_teacher(stub, online, offline, tag, torch.device("cpu"))
+                key = f"{name}::{wname}::{tag}"
+                out_all.update(instances_arrays(key + "::a", a))
+                if b is not None:
+                    out_all.update(instances_arrays(key + "::b", b))
+                out_all.update(instances_arrays(key + "::c", c))
+                out_all[key + "::n"] = np.array([len(a), -1 if b is None else len(b), len(c)])
+    npz("match_dual_teacher", **out_all)
+
 
 CASES = [case_mil_losses, case_bottleneck, case_resnet, case_box_predictor_pretrain, case_box_predictor_step,
          case_text_encoder, case_ckg, case_lr_and_fusion, case_optimizer_groups, case_rpn, case_roi_sampling,
-         case_e2e_pretrain, case_e2e_step_and_inference, case_ema]
+         case_e2e_pretrain, case_e2e_step_and_inference, case_ema, case_match_dual_teacher]
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])

@@ -427,3 +427,47 @@ def test_inference_path():
         close(got, ref, 1e-4)
         # and the order is by descending score up to ties
         assert bool((inst.scores[:-1] >= inst.scores[1:] - 1e-6).all())
+
+
+# ------------------------------------------------------------------------------------------ CoinTrainer: dual-teacher matching
+def _teacher_inst(z, case, who, size=(200, 300)):
+    from oracle import trainer as OT
+
+    inst = OT.MyInstances(size)
+    probs = T(z[f"{case}::{who}_probs"])
+    inst.gt_boxes = d2.Boxes(T(z[f"{case}::{who}_boxes"]).reshape(-1, 4))
+    inst.gt_classes = T(z[f"{case}::{who}_classes"]).long()
+    inst.probs = probs
+    inst.scores = probs[:, :-1].max(dim=1).values
+    return inst
+
+
+MATCH_CASES = ["normal", "online_empty", "offline_empty", "both_empty", "offline_duplicates", "online_self_overlap"]
+
+
+@pytest.mark.parametrize("case", MATCH_CASES)
+def test_match_dual_teacher_vs_reference(case):
+    """trainer.py:338-461 + util.py:434-507 (A / B / C split of cloud vs CLIP-teacher boxes), all branches, seeded tie-breaks."""
+    import random
+
+    from oracle import trainer as OT
+
+    z = load("match_dual_teacher")
+    for wname, weight in (("w1", 1.0), ("w05", 0.5)):
+        for tag in ("RCNN", "RPN"):
+            online = {"RCNN": _teacher_inst(z, case, "on"), "RPN": _teacher_inst(z, case, "on")}
+            offline = _teacher_inst(z, case, "off")
+            random.seed(1234)
+            a, b, c = OT.match_dual_teacher(online, offline, tag, 0.5, weight)
+            key = f"{case}::{wname}::{tag}"
+            n = z[key + "::n"]
+            assert [len(a), -1 if b is None else len(b), len(c)] == n.tolist(), key
+            for name, inst in (("a", a), ("b", b), ("c", c)):
+                if inst is None:
+                    continue
+                fields = {k[len(key) + 3 + len(name):]: z[k] for k in z.files if k.startswith(f"{key}::{name}.")}
+                assert set(fields) == set(inst.get_fields()), (key, name, sorted(fields), sorted(inst.get_fields()))
+                for f, ref in fields.items():
+                    v = inst.get(f)
+                    v = v.tensor if isinstance(v, d2.Boxes) else v
+                    np.testing.assert_allclose(v.numpy(), ref, rtol=1e-6, atol=1e-6, err_msg=f"{key} {name}.{f}")
