@@ -108,3 +108,33 @@ class SyntheticTwoViewLoader:
             s.append(dict(a))
             w.append(dict(b))
         return s, w
+
+
+def synthetic_offline_detections(cloud_result: Dict, g: torch.Generator, jitter_px: float = 4.0, relabel_frac: float = 0.25,
+                                 extra: int = 8, device="cpu") -> Dict:
+    """A CLIP-detector-like detection set for one image: the cloud boxes jittered by N(0, jitter_px), a quarter
+    of the labels permuted (-> inconsistent 'B' boxes) plus `extra` private boxes (-> 'C').  Same schema as
+    OpenVocabularyRCNN.inference output: {"instances": Instances(pred_boxes, scores, pred_classes, probs)} in image pixels."""
+    src = cloud_result["RCNN"]["instances"]
+    h, w = cloud_result["height"], cloud_result["width"]
+    boxes = src.pred_boxes.tensor.detach().cpu() + jitter_px * torch.randn(len(src), 4, generator=g)
+    probs = src.probs.detach().cpu().clone()
+    k = probs.shape[1] - 1
+    n = len(src)
+    flip = torch.rand(n, generator=g) < relabel_frac
+    for i in flip.nonzero()[:, 0].tolist():
+        perm = torch.randperm(k, generator=g)
+        probs[i, :k] = probs[i, :k][perm]
+    if extra:
+        boxes = torch.cat([boxes, _boxes(extra, h, w, g, hi=min(400.0, min(h, w) * 0.6))])
+        p = torch.softmax(3.0 * torch.randn(extra, k + 1, generator=g), dim=1)
+        p[:, -1] = p.min(dim=1).values * 0.5
+        probs = torch.cat([probs, p / p.sum(dim=1, keepdim=True)])
+    boxes[:, 0::2] = boxes[:, 0::2].clamp(0, w)
+    boxes[:, 1::2] = boxes[:, 1::2].clamp(0, h)
+    inst = Instances((h, w))
+    inst.pred_boxes = Boxes(boxes.to(device))
+    inst.scores = probs[:, :-1].max(dim=1).values.to(device)
+    inst.pred_classes = probs[:, :-1].argmax(dim=1).to(device)
+    inst.probs = probs.to(device)
+    return {"instances": inst}

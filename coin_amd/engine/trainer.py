@@ -1,0 +1,150 @@
+"""CoinTrainer: the target-detector (targetDET) distillation step of COIN on one MI355X per process.
+
+``run_step`` follows coin/engine/trainer.py:160-218:
+
+  1. EMA of the student into the offline (CLIP-detector) teacher every OFFLINE_TEACHER_UPDATE_ITER steps once the burn-up
+     phase is over (ts_ensemble.py:39-69) -- one ``coin_ema_update`` launch over the whole state dict;
+  2. teacher inference on the weak views (``branch='test'``, no grad);
+  3. ``match_boxes``: teacher detections + cached cloud-detector results -> (A, B, C) targets for the RoI head and
+     (A, None, C) for the RPN (``coin_amd.engine.matching``);
+  4. student forward on the strong views, branch ``step_one`` (burn-up) or ``step_two``, with the CKG merge module;
+  5. CKG update: ``loss_merge_grad`` (gradient_discrepancy_loss) + ``loss_merge_base`` -> merge optimizer;
+  6. student update with the remaining loss terms.
+
+Differences that do not change values: step 5 differentiates only with respect to the CKG parameters
+(``backward(inputs=...)``) -- the reference back-propagates this loss through the whole detector and then throws those
+gradients away (``optimizer.zero_grad()``, trainer.py:199); bf16 autocast needs no GradScaler; no per-step
+``empty_cache()/gc.collect()``; metrics are read back every ``log_period`` steps.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .. import kernels as K
+from ..data import SyntheticTwoViewLoader
+from ..modeling import build_model
+from ..modeling.text_encoder import build_merge
+from ..solver import build_lr_scheduler, build_optimizer
+from .base import BASE_Trainer
+from .matching import match_dual_teacher
+
+_MERGE_TERMS = ("loss_merge_grad", "loss_merge_a", "loss_merge_b", "loss_merge_base")
+
+
+class CoinTrainer(BASE_Trainer):
+    def __init__(self, cfg, data_loader=None, cloud_results=None):
+        self.cfg = cfg
+        self.device = torch.device(cfg.MODEL.DEVICE)
+        self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world_size > 1 else 0
+        self.model, self.offline_teacher = build_model(cfg)
+        self.merge = build_merge(cfg).to(self.device)
+        for p in self.offline_teacher.parameters():
+            p.requires_grad = False
+        self.model.train()
+        self.offline_teacher.train()
+        self.optimizer = build_optimizer(cfg, self.model, name="all")
+        self.optimizer_merge = build_optimizer(cfg, self.merge, name="all")
+        self.ddp_model, self.ddp_merge = self.model, self.merge
+        if self.world_size > 1:  # trainer.py:66-72
+            ids = [self.device.index] if self.device.type == "cuda" else None
+            self.ddp_model = torch.nn.parallel.DistributedDataParallel(self.model, device_ids=ids, broadcast_buffers=False,
+                                                                       gradient_as_bucket_view=True, bucket_cap_mb=32)
+            self.ddp_merge = torch.nn.parallel.DistributedDataParallel(self.merge, device_ids=ids, broadcast_buffers=False)
+        self.scheduler = build_lr_scheduler(cfg, self.optimizer)
+        self.scheduler_merge = build_lr_scheduler(cfg, self.optimizer_merge)
+        if data_loader is None:
+            assert cfg.AMD.SYNTHETIC.ENABLED, "only the synthetic loader is built in (the input pipeline is out of scope)"
+            per_gpu = cfg.SOLVER.IMG_PER_BATCH_UNLABEL // self.world_size
+            assert per_gpu >= 1 and cfg.SOLVER.IMG_PER_BATCH_UNLABEL % self.world_size == 0  # coin/data/build.py:153-157
+            data_loader = SyntheticTwoViewLoader(per_gpu, cfg.AMD.SYNTHETIC.HEIGHT, cfg.AMD.SYNTHETIC.WIDTH, len(cfg.AMD.CLASS_NAMES),
+                                                 cfg.AMD.SYNTHETIC.BOXES_PER_IMAGE, seed=cfg.SEED + self.rank, device=self.device,
+                                                 num_images=max(per_gpu, cfg.AMD.SYNTHETIC.NUM_IMAGES // self.world_size))
+            cloud_results = data_loader.cache
+        self._data_loader_iter = iter(data_loader)
+        self.model_CLOUD = cloud_results  # file name -> cached cloud-detector result (gdino_collector.py:51-75)
+        self.iter = self.start_iter = 0
+        self.max_iter = cfg.SOLVER.MAX_ITER
+        self.WEIGHT_FOR_BOX_A = 1.0
+        self.last_losses: Optional[Dict[str, torch.Tensor]] = None
+        self._ema = None
+
+    # ------------------------------------------------------------------ teacher EMA (ts_ensemble.py:39-69)
+    @torch.no_grad()
+    def update_teacher(self, keep_rate: float):
+        if self._ema is None:
+            t_sd, s_sd = self.offline_teacher.state_dict(), self.model.state_dict()
+            missing = [k for k in t_sd if k not in s_sd]
+            if missing:
+                raise Exception("{} is not found in student model".format(missing[0]))
+            fl = [k for k, v in t_sd.items() if v.dtype == torch.float32]
+            self._ema = (K.EmaTable([t_sd[k] for k in fl], [s_sd[k] for k in fl]),
+                         [(t_sd[k], s_sd[k]) for k, v in t_sd.items() if v.dtype != torch.float32])
+        table, others = self._ema
+        table.update(keep_rate)
+        for t, s in others:  # integer buffers (num_batches_tracked): float arithmetic, then truncation on the copy
+            t.copy_(s * (1 - keep_rate) + t * keep_rate)
+
+    # ------------------------------------------------------------------ targets (trainer.py:463-485)
+    @torch.no_grad()
+    def match_boxes(self, batched_input: List[Dict], offline_results: List[Dict]):
+        rcnn, rpn = [], []
+        thr = self.cfg.CLOUD.MATCHER.IOU_THRESHOLDS
+        for data, off in zip(batched_input, offline_results):
+            dev = off["instances"].pred_boxes.tensor.device
+            online = self.model_CLOUD(data["file_name"])
+            net = tuple(data["image"].shape[1:])
+            off_i = self.process(off["instances"].to("cpu"), (data["height"], data["width"]), net, "no")
+            assert online["height"] == data["height"] and online["width"] == data["width"] and online["image_id"] == data["image_id"]
+            online = self.preprocess_results(online, net, data["random_flip"], thresh=None)
+            rcnn.append(match_dual_teacher(online, off_i, "RCNN", thr, self.WEIGHT_FOR_BOX_A, device=dev))
+            rpn.append(match_dual_teacher(online, off_i, "RPN", thr, self.WEIGHT_FOR_BOX_A, device=dev))
+        return rcnn, rpn
+
+    # ------------------------------------------------------------------ one step (trainer.py:160-218)
+    def run_step(self):
+        cfg = self.cfg
+        assert self.model.training, "[PTrainer] model was changed to eval mode!"
+        strong, weak = next(self._data_loader_iter)
+        burn = cfg.CLOUD.BURN_UP_STEP
+        if self.iter >= burn and (self.iter - burn) % cfg.CLOUD.OFFLINE_TEACHER_UPDATE_ITER == 0:
+            self.update_teacher(cfg.CLOUD.EMA_KEEP_RATE_OFFLINE)
+        with torch.no_grad():
+            self.offline_teacher.eval()
+            offline_results = self.offline_teacher(weak, branch="test")
+            self.offline_teacher.train()
+            dual_teacher_instances = self.match_boxes(weak, offline_results)
+        start = cfg.CLOUD.PROTOTYPE_UPDATE_START
+        update_prototype = start != -1 and self.iter >= start
+        branch = "step_one" if self.iter < burn else "step_two"
+        record = self.ddp_model(strong, self.ddp_merge, dual_teacher_instances, branch=branch, update_prototype=update_prototype)
+        self.optimizer.zero_grad()
+        self.optimizer_merge.zero_grad()
+        if "loss_merge_a" in record:
+            # CKG update (trainer.py:192-197); gradients are formed for the merge parameters only
+            record["loss_merge_grad"] = self.model.roi_heads.box_predictor.merge_grad_loss()
+            (record["loss_merge_grad"] + record["loss_merge_base"]).backward(inputs=list(self.merge.parameters()), retain_graph=True)
+            self.optimizer_merge.step()
+        self.optimizer.zero_grad()
+        self.optimizer_merge.zero_grad()
+        skip = _MERGE_TERMS if self.iter >= burn else _MERGE_TERMS + ("loss_cls_b",)
+        losses = sum(v for k, v in record.items() if k not in skip)
+        losses.backward()
+        self.optimizer.step()
+        self.scheduler.step()
+        self.scheduler_merge.step()
+        self.last_losses = record
+        if self.iter >= burn:  # trainer.py:150-157 (after_step): fused A boxes from the next step on
+            self.WEIGHT_FOR_BOX_A = 0.5
+        self.iter += 1
+        return record
+
+    def train(self):
+        for _ in range(self.start_iter, self.max_iter):
+            rec = self.run_step()
+            m = self._write_metrics(rec, self.iter)
+            if m is not None and self.rank == 0:
+                print(f"iter {self.iter}: " + "  ".join(f"{k} {v:.4f}" for k, v in m.items()), flush=True)

@@ -517,8 +517,8 @@ class EmaTable:
         self.max_numel = max((t.numel() for t in teacher), default=0)
         host = (_lib.EmaTensor * max(self.n, 1))()
         for i, (t, s) in enumerate(zip(teacher, student)):
-            if not (t.is_contiguous() and s.is_contiguous() and t.dtype == torch.float32 and s.dtype == torch.float32):
-                raise CoinHipError("EMA needs contiguous float32 tensors")
+            if not (_dense(t) and s.stride() == t.stride() and t.dtype == torch.float32 and s.dtype == torch.float32):
+                raise CoinHipError("EMA needs dense float32 tensors with identical layout (contiguous or channels_last)")
             host[i].teacher, host[i].student, host[i].numel = t.data_ptr(), s.data_ptr(), t.numel()
         self._keep = (list(teacher), list(student))
         self._dev = torch.frombuffer(memoryview(host).cast("B"), dtype=torch.uint8).to(teacher[0].device) if self.n else None

@@ -135,8 +135,44 @@ class FastRCNNOutputLayers(nn.Module):
         scores = self.do_classify(class_feats, branch)
         proposal_deltas = L.linear_act(h, self.bbox_pred.weight, self.bbox_pred.bias, ACT_NONE, out_dtype=torch.float32)
         if return_feats and self.training and branch != "test":
+            self._last_input = x  # pooled RoI features of the proposal pass: `merge_grad_loss` re-differentiates a few rows
             return scores, proposal_deltas, class_feats
         return scores, proposal_deltas
+
+    _last_input = _last_text = _merge_ctx = None
+
+    def merge_grad_loss(self) -> torch.Tensor:
+        """``gradient_discrepancy_loss`` (coin/utils/losses.py:75-96, called at coin/engine/trainer.py:192-197): 1 - mean cosine
+        between d loss_merge_a / d theta (detached) and d loss_merge_b / d theta over the parameters theta of `trans`.
+
+        It needs a second derivative (the CKG parameters receive their gradient THROUGH d loss_merge_b / d theta, via the merged
+        target m_b), which the fused one-launch kernels do not provide.  Only the A and B rows enter (tens of rows), so the
+        sub-graph  trans -> cls_score -> cosine logits -> softmax -> MSE  is replayed for those rows in fp32 with
+        differentiable torch ops; everything upstream (pooled features, text embeddings) is a constant of this loss, exactly as
+        in the reference where theta are the only differentiation variables.  Call after `losses()` of a step_one / step_two
+        forward that produced `loss_merge_a`."""
+        assert self._merge_ctx is not None, "merge_grad_loss needs the context of a step_one/step_two losses() call with B boxes"
+        x_a, x_b, text, oh_a, m_b = self._merge_ctx
+        na = x_a.shape[0]
+        with torch.autocast(x_a.device.type, enabled=False):
+            x = torch.cat([x_a, x_b]).detach().float()
+            t = self.trans
+            h = F.leaky_relu(F.linear(x, t[0].weight, t[0].bias), 0.01)
+            h = F.leaky_relu(F.linear(h, t[2].weight, t[2].bias), 0.01)
+            h = F.linear(h, t[4].weight, t[4].bias)
+            cf = F.linear(h, self.cls_score.weight, self.cls_score.bias)
+            scores = F.normalize(cf, dim=1) @ F.normalize(text.detach().float(), dim=1).t() * self._inv_scale
+            p = F.softmax(scores, dim=1)
+            loss_a = F.mse_loss(p[:na], oh_a.float())
+            loss_b = F.mse_loss(p[na:], m_b.float())
+            cos = []
+            for prm in t.parameters():
+                if not prm.requires_grad:
+                    continue
+                ga = torch.autograd.grad(loss_a, prm, retain_graph=True)[0]
+                gb = torch.autograd.grad(loss_b, prm, create_graph=True)[0]
+                cos.append(F.cosine_similarity(ga, gb, dim=1).mean() if prm.dim() > 1 else F.cosine_similarity(ga, gb, dim=0))
+            return (1.0 - torch.stack(cos)).mean()
 
     def prefetch_text(self):
         """Run the prompt-conditioned text encoder ahead of `forward` (it does not depend on the images): the caller puts it
@@ -151,6 +187,7 @@ class FastRCNNOutputLayers(nn.Module):
             text, self._text_prefetch = self._text_prefetch, None
         else:
             text = self.text_encoder(added=True)
+        self._last_text = text
         # the kernel L2-normalises both operands (the encoder output is already unit-norm: normalising twice, as the
         # reference does at fast_rcnn.py:344, is the identity up to rounding)
         scores = L.cosine_logits(image_features, text, self._inv_scale)
@@ -298,6 +335,7 @@ class FastRCNNOutputLayers(nn.Module):
                 p_a = F.softmax(s_a, dim=1)
                 losses["loss_merge_b"] = F.mse_loss(p_b, m_b)
                 losses["loss_merge_a"] = F.mse_loss(p_a, oh_a.float())
+                self._merge_ctx = (self._last_input[ia], self._last_input[ib], self._last_text, oh_a, m_b)
                 if branch == "step_two":
                     keep = (m_b.max(1)[0] >= self.cls_b_thresh).detach()
                     if bool(keep.any()):

@@ -127,6 +127,15 @@ class _CpuSgdTable:
         self.first = False
 
 
+class _CpuEmaTable:
+    def __init__(self, teacher, student):
+        self.t, self.s = list(teacher), list(student)
+
+    def update(self, keep):
+        for t, s in zip(self.t, self.s):
+            t.copy_(s * (1 - keep) + t * keep)
+
+
 @contextlib.contextmanager
 def cpu_kernels():
     import coin_amd.kernels as K
@@ -136,7 +145,7 @@ def cpu_kernels():
         L: dict(linear_act=_linear_act, cosine_logits=_cosine_logits, mil_cross_entropy=_mil, kl_div_from_logits=_kl_logits,
                 kl_div_from_probs=_kl_probs, kl_div_binary=_kl_binary, box_reg_l1=_box_reg, l1_mean=lambda a, b: F.l1_loss(a, b),
                 rpn_losses=_rpn_losses, roi_align=_roi_align, bn_act=_bn_act, avg_pool2=lambda x: F.avg_pool2d(x, 2)),
-        K: dict(normalize_pad=_normalize_pad, nms_batched=_nms_batched, SgdTable=_CpuSgdTable),
+        K: dict(normalize_pad=_normalize_pad, nms_batched=_nms_batched, SgdTable=_CpuSgdTable, EmaTable=_CpuEmaTable),
     }
     saved = {mod: {k: getattr(mod, k) for k in d} for mod, d in patches.items()}
     try:

@@ -154,3 +154,65 @@ def run_product_step_two(case, device="cuda:0", dtype=torch.float32):
     skip = ["loss_merge_grad", "loss_merge_a", "loss_merge_b", "loss_merge_base"]
     sum(v for k, v in losses.items() if k not in skip).backward()
     return {k: v.detach().float().cpu() for k, v in losses.items()}, _grads(model, case["ref_grads"].keys())
+
+
+# ------------------------------------------------------------------------------------------ box predictor: step branches + CKG update
+def _product_box_predictor(in_ch=64):
+    from coin_amd.box_ops import Box2BoxTransform
+    from coin_amd.modeling.fast_rcnn import FastRCNNOutputLayers
+    from coin_amd.modeling.text_encoder import CLIP_TEXT
+    from coin_amd.structures import ShapeSpec
+
+    toks = torch.zeros(K + 1, 16, dtype=torch.int)
+    for i in range(K + 1):
+        seq = [62, 1, 2, 3, 1, 6, 6, 6, 6, 10 + i, 5, 63]
+        toks[i, : len(seq)] = torch.tensor(seq)
+    te = CLIP_TEXT("RN50", ["car", "person", "bus", "backgroud"], embed_dim=32, context_length=16, vocab_size=64, width=32, heads=2,
+                   layers=2, tokenized_prompts=toks, n_templates=2)
+    return FastRCNNOutputLayers(ShapeSpec(channels=in_ch, height=1, width=1), text_encoder=te, pooling_type="meanpool",
+                                box2box_transform=Box2BoxTransform((10.0, 10.0, 5.0, 5.0)), text_dim=32, classes_weight=[1.0] * K + [0.9],
+                                loss_type="MILCrossEntropy", test_score_thresh=0.05, test_nms_thresh=0.5, test_topk_per_image=100,
+                                cls_agnostic_bbox_reg=True, loss_weight=LOSS_W, batch_size_per_image=32, cls_b_thresh=0.3,
+                                dataset=("foggytrain_0.02",), prototype_update_rate=0.9996)
+
+
+def run_product_box_predictor_step(tag, device="cpu"):
+    """The reference's FastRCNNOutputLayers.losses(step_one / step_two) + trainer.py:192-197 (CKG update through
+    gradient_discrepancy_loss) on the product's predictor; returns what the golden recorded."""
+    from coin_amd.modeling.text_encoder import CKGNet
+
+    z = load(f"box_predictor_{tag}")
+    branch = str(z["branch"])
+    bp = _product_box_predictor()
+    load_weights(bp, z)
+    merge = CKGNet(32, 32, K + 1, head_num=4)
+    load_weights(merge, z, "m::")
+    bp.to(device).train()
+    merge.to(device)
+    n_img = int(z["n_img"])
+    size = (96, 128)
+    props = [tuple(_inst(z, f"p{i}.{t}", size).to(device) for t in ("a", "b", "bg")) for i in range(n_img)]
+    cs = [_inst(z, f"p{i}.c", size).to(device) for i in range(n_img)]
+    x = T(z["x"]).to(device).requires_grad_(True)
+    xc = T(z["xc"]).to(device)
+    preds = bp(x, branch)
+    upd = bool(z["update_prototype"])
+    if xc.shape[0]:
+        losses = bp.losses((preds, bp(xc, branch, return_feats=False)), (props, cs), merge, branch, update_prototype=upd)
+    else:
+        losses = bp.losses((preds, ((None, None), None)), (props, None), merge, branch, update_prototype=upd)
+    out = {"losses": {k: float(v) for k, v in losses.items()}, "ref": {k[6:]: float(z[k]) for k in z.files if k.startswith("loss::")}, "z": z}
+    if "loss_merge_a" in losses:
+        lg = bp.merge_grad_loss()
+        out["losses"]["loss_merge_grad"] = float(lg)
+        (lg + losses["loss_merge_base"]).backward(inputs=list(merge.parameters()), retain_graph=True)
+        out["merge_grads"] = {n: p.grad.detach().cpu().clone() for n, p in merge.named_parameters()}
+        assert all(p.grad is None for p in bp.parameters()), "the CKG update must not touch the detector's gradients"
+    skip = ["loss_merge_grad", "loss_merge_a", "loss_merge_b", "loss_merge_base"] + ([] if branch == "step_two" else ["loss_cls_b"])
+    sum(v for k, v in losses.items() if k not in skip).backward()
+    out["gx"] = x.grad.detach().cpu()
+    params = dict(bp.named_parameters())
+    out["grads"] = {k[3:]: params[k[3:]].grad.detach().cpu() for k in z.files if k.startswith("g::")}
+    return out
+
+

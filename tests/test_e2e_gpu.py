@@ -80,3 +80,22 @@ def test_full_size_trainer_steps_bf16_and_fp32_agree():
     assert set(out["fp32"]) == {"loss_text_align", "loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc"}
     for k in out["fp32"]:
         assert abs(out["fp32"][k] - out["bf16"][k]) < 0.05 * max(1.0, abs(out["fp32"][k])), (k, out)
+
+
+@pytest.mark.parametrize("tag", ["one", "two", "two_nobg_noC", "two_noB", "one_noproto"])
+def test_box_predictor_step_and_ckg_update_fp32_vs_reference_golden(tag):
+    """FastRCNNOutputLayers.losses(step_one / step_two) on the HIP kernels + the CKG update through `merge_grad_loss`
+    (gradient_discrepancy_loss, trainer.py:192-197) vs values captured from the reference modules."""
+    from e2e_util import run_product_box_predictor_step
+    from golden_util import close
+
+    out = run_product_box_predictor_step(tag, device="cuda:0")
+    z = out["z"]
+    assert set(out["losses"]) == set(out["ref"])
+    for k, v in out["losses"].items():
+        assert abs(v - out["ref"][k]) < 1e-4 * max(1.0, abs(out["ref"][k])), (k, v, out["ref"][k])
+    for n, g in out.get("merge_grads", {}).items():
+        close(g, z["mg::" + n], 2e-4, n)
+    close(out["gx"], z["gx"], 1e-4, "gx")
+    for k, g in out["grads"].items():
+        close(g, z["g::" + k], 1e-4, k)

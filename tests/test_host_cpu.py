@@ -18,7 +18,7 @@ from golden_util import GOLDEN, K, LOSS_W, T, close, load, load_weights
 torch.set_num_threads(4)
 
 
-from e2e_util import _inst, tiny_product_detector  # noqa: E402
+from e2e_util import _inst, run_product_box_predictor_step, tiny_product_detector  # noqa: E402
 
 
 def test_state_dict_keys_match_the_reference():
@@ -177,3 +177,108 @@ def test_oracle_reproduces_golden_at_parity_boundary():
         assert abs(float(losses[k]) - ref) < 1e-5, k
     for k, ref in case["ref_grads"].items():
         close(grads[k], ref, 1e-4, k)
+
+
+# ------------------------------------------------------------------------------------------ CoinTrainer: dual-teacher matching
+def _product_teacher_inst(z, case, who, size=(200, 300)):
+    from coin_amd.structures import Boxes, Instances
+
+    probs = torch.from_numpy(z[f"{case}::{who}_probs"])
+    inst = Instances(size)
+    inst.gt_boxes = Boxes(torch.from_numpy(z[f"{case}::{who}_boxes"]).reshape(-1, 4))
+    inst.gt_classes = torch.from_numpy(z[f"{case}::{who}_classes"]).long()
+    inst.probs = probs
+    inst.scores = probs[:, :-1].max(dim=1).values
+    return inst
+
+
+@pytest.mark.parametrize("case", ["normal", "online_empty", "offline_empty", "both_empty", "offline_duplicates", "online_self_overlap"])
+def test_product_match_dual_teacher_vs_reference(case):
+    """coin_amd.engine.matching (index-based) reproduces trainer.py:338-461 row for row, including the seeded tie-breaks."""
+    import random
+
+    from coin_amd.engine.matching import match_dual_teacher
+    from coin_amd.structures import Boxes
+
+    z = load("match_dual_teacher")
+    for wname, weight in (("w1", 1.0), ("w05", 0.5)):
+        for tag in ("RCNN", "RPN"):
+            online = {"RCNN": _product_teacher_inst(z, case, "on"), "RPN": _product_teacher_inst(z, case, "on")}
+            random.seed(1234)
+            a, b, c = match_dual_teacher(online, _product_teacher_inst(z, case, "off"), tag, 0.5, weight)
+            key = f"{case}::{wname}::{tag}"
+            assert [len(a), -1 if b is None else len(b), len(c)] == z[key + "::n"].tolist(), key
+            for name, inst in (("a", a), ("b", b), ("c", c)):
+                if inst is None:
+                    continue
+                fields = {k[len(key) + 3 + len(name):]: z[k] for k in z.files if k.startswith(f"{key}::{name}.")}
+                assert set(fields) == set(inst.get_fields()), (key, name)
+                for f, ref in fields.items():
+                    v = inst.get(f)
+                    v = v.tensor if isinstance(v, Boxes) else v
+                    np.testing.assert_allclose(v.numpy(), ref, rtol=1e-6, atol=1e-6, err_msg=f"{key} {name}.{f}")
+
+
+# ------------------------------------------------------------------------------------------ box predictor: step branches + CKG update
+@pytest.mark.parametrize("tag", ["one", "two", "two_nobg_noC", "two_noB", "one_noproto"])
+def test_product_box_predictor_step_and_ckg_update_on_cpu(tag):
+    with cpu_kernels():
+        out = run_product_box_predictor_step(tag)
+    z = out["z"]
+    assert set(out["losses"]) == set(out["ref"])
+    for k, v in out["losses"].items():
+        assert abs(v - out["ref"][k]) < 1e-4 * max(1.0, abs(out["ref"][k])), (k, v, out["ref"][k])
+    for n, g in out.get("merge_grads", {}).items():
+        close(g, z["mg::" + n], 2e-4, n)
+    close(out["gx"], z["gx"], 1e-5, "gx")
+    for k, g in out["grads"].items():
+        close(g, z["g::" + k], 1e-4, k)
+
+
+@pytest.mark.parametrize("burned_up", [False, True])
+def test_cointrainer_run_step_on_cpu_with_shimmed_kernels(burned_up):
+    """Whole CoinTrainer.run_step on a tiny model: teacher EMA + inference, A/B/C matching, step_one / step_two forward with the
+    CKG module, CKG update through merge_grad_loss, student update, schedulers."""
+    from coin_amd.config import get_cfg
+    from coin_amd.engine import CoinTrainer
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(os.path.dirname(GOLDEN), "..", "configs", "coin", "GDINO", "foggy_synthetic.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu", "AMD.COMPUTE_DTYPE", "fp32", "AMD.SYNTHETIC.HEIGHT", 96, "AMD.SYNTHETIC.WIDTH", 128,
+                         "AMD.SYNTHETIC.BOXES_PER_IMAGE", 6, "AMD.SYNTHETIC.NUM_IMAGES", 2, "SOLVER.IMG_PER_BATCH_UNLABEL", 2,
+                         "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 16, "MODEL.RPN.PRE_NMS_TOPK_TRAIN", 100, "MODEL.RPN.POST_NMS_TOPK_TRAIN", 30,
+                         "MODEL.RPN.PRE_NMS_TOPK_TEST", 60, "MODEL.RPN.POST_NMS_TOPK_TEST", 20, "AMD.TEXT_TEMPLATES", 1, "MODEL.MERGE_DIM", 32,
+                         "AMD.ARCH.LAYERS", [1, 1, 1, 1], "AMD.ARCH.WIDTH", 8, "AMD.ARCH.TEXT_WIDTH", 32, "AMD.ARCH.TEXT_LAYERS", 2,
+                         "AMD.ARCH.TEXT_HEADS", 2, "AMD.ARCH.TEXT_DIM", 32, "AMD.ARCH.CONTEXT_LENGTH", 16, "AMD.ARCH.VOCAB_SIZE", 64,
+                         "CLOUD.BURN_UP_STEP", 0 if burned_up else 100, "CLOUD.PROTOTYPE_UPDATE_START", 0, "CLOUD.CLS_B_THRESH", 0.2])
+    with cpu_kernels():
+        torch.manual_seed(0)
+        tr = CoinTrainer(cfg)
+        # a randomly initialised teacher detects nothing that overlaps the cloud boxes (no A boxes -> the reference's
+        # loss_merge_a is a mean over zero rows); keep its forward in the loop but hand the matcher CLIPDET-like detections
+        from coin_amd.data.synthetic import synthetic_offline_detections
+
+        real_forward, g_det = tr.offline_teacher.forward, torch.Generator().manual_seed(7)
+
+        def teacher(batched_inputs, branch=None, **kw):
+            out = real_forward(batched_inputs, branch=branch, **kw)
+            assert len(out) == len(batched_inputs) and all("instances" in o for o in out)
+            return [synthetic_offline_detections(tr.model_CLOUD.get_results()[d["file_name"]], g_det) for d in batched_inputs]
+
+        tr.offline_teacher.forward = teacher
+        teacher_before = {k: v.clone() for k, v in tr.offline_teacher.state_dict().items()}
+        before = [p.detach().clone() for p in tr.optimizer.params]
+        merge_before = [p.detach().clone() for p in tr.merge.parameters()]
+        rec1 = tr.run_step()
+        rec2 = tr.run_step()
+    for rec in (rec1, rec2):
+        assert {"loss_text_align", "loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc"} <= set(rec)
+        assert all(torch.isfinite(v) for v in rec.values()), rec
+    changed = sum(int(not torch.equal(a, b)) for a, b in zip(before, tr.optimizer.params))
+    assert changed > 0.5 * len(before)
+    if any("loss_merge_a" in r for r in (rec1, rec2)):
+        assert any(not torch.equal(a, b) for a, b in zip(merge_before, tr.merge.parameters())), "the CKG module was not updated"
+    moved = any(not torch.equal(v, teacher_before[k]) for k, v in tr.offline_teacher.state_dict().items() if v.dtype == torch.float32)
+    assert moved == burned_up  # the EMA teacher only moves after the burn-up phase
+    assert tr.iter == 2 and tr.scheduler.last_epoch == 2 and tr.scheduler_merge.last_epoch == 2
+    assert tr.WEIGHT_FOR_BOX_A == (0.5 if burned_up else 1.0)
