@@ -91,8 +91,8 @@ def compute_weight(param: Optional[torch.Tensor], dtype: torch.dtype) -> Optiona
 
 def compute_dtype_of(x: torch.Tensor) -> torch.dtype:
     """Dtype the weights should take for input x: the autocast dtype inside an autocast region, else x's own."""
-    if x.is_cuda and torch.is_autocast_enabled():
-        return torch.get_autocast_gpu_dtype()
+    if x.is_cuda and torch.is_autocast_enabled("cuda"):
+        return torch.get_autocast_dtype("cuda")
     return x.dtype
 
 
@@ -151,6 +151,24 @@ def _as_nhwc(t: torch.Tensor) -> torch.Tensor:
     return v if v.is_contiguous() else v.contiguous()
 
 
+# Leading rows of the batch that are real (the rest is shape padding, see OpenVocabularyRes5ROIHeads._pooled): train-mode
+# BatchNorm takes its statistics and its gradient sums over these rows only and gives the filler rows zero gradient.
+_VALID_ROWS = [None]
+
+
+class valid_rows:
+    def __init__(self, n: Optional[int]):
+        self.n = n
+
+    def __enter__(self):
+        self.prev = _VALID_ROWS[0]
+        _VALID_ROWS[0] = self.n
+
+    def __exit__(self, *a):
+        _VALID_ROWS[0] = self.prev
+        return False
+
+
 class _BNAct(Function):
     """nn.BatchNorm2d(train) -> (+ identity) -> ReLU -> nn.AvgPool2d(2) of the CLIP Bottleneck (coin/modeling/utils.py:77-90)
     as two HIP streams forward and two backward (coin_bn_stats / coin_bn_apply_fwd / coin_bn_bwd)."""
@@ -160,9 +178,11 @@ class _BNAct(Function):
         xn = _as_nhwc(x)
         rn = _as_nhwc(residual) if residual is not None else None
         g, b = gamma.float().contiguous(), beta.float().contiguous()
-        mean, rstd = K.bn_stats(xn, eps, momentum, running_mean, running_var)
+        nv = _VALID_ROWS[0]
+        nv = None if (nv is None or nv >= xn.shape[0]) else int(nv)
+        mean, rstd = K.bn_stats(xn if nv is None else xn[:nv], eps, momentum, running_mean, running_var)
         y = K.bn_apply_fwd(xn, mean, rstd, g, b, rn, relu, pool)
-        ctx.relu, ctx.pool, ctx.has_res = relu, pool, residual is not None
+        ctx.relu, ctx.pool, ctx.has_res, ctx.nv = relu, pool, residual is not None, nv
         # pool 1: the saved output is only needed for the ReLU mask when a residual was added (otherwise coin_bn_bwd recomputes
         # it from x).  pool 0 (global mean): the activation does not exist; the residual input is kept instead.
         if pool == 0:
@@ -179,7 +199,19 @@ class _BNAct(Function):
         dyn = _as_nhwc(dy)
         if dyn.dtype != xn.dtype:
             dyn = dyn.to(xn.dtype)
-        dx, dgamma, dbeta, dres = K.bn_bwd(xn, dyn, y, mean, rstd, g, b, ctx.relu, ctx.pool, ctx.has_res and ctx.needs_input_grad[3])
+        want_dres = ctx.has_res and ctx.needs_input_grad[3]
+        nv = ctx.nv
+        if nv is None:
+            dx, dgamma, dbeta, dres = K.bn_bwd(xn, dyn, y, mean, rstd, g, b, ctx.relu, ctx.pool, want_dres)
+        else:  # sums and dx over the real rows (leading, contiguous); the filler rows get zero gradient
+            dxv, dgamma, dbeta, dresv = K.bn_bwd(xn[:nv], dyn[:nv], y[:nv] if y is not None else None, mean, rstd, g, b, ctx.relu, ctx.pool,
+                                                 want_dres)
+            dx = torch.zeros_like(xn)
+            dx[:nv] = dxv
+            dres = None
+            if dresv is not None:
+                dres = torch.zeros_like(xn)
+                dres[:nv] = dresv
         return (dx.permute(0, 3, 1, 2), dgamma, dbeta, dres.permute(0, 3, 1, 2) if dres is not None else None,
                 None, None, None, None, None, None)
 
@@ -197,6 +229,14 @@ def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm2d, relu: bool, residual: Opti
         rv = bn.running_var if bn.track_running_stats else None
         return _BNAct.apply(x, bn.weight, bn.bias, residual, rm, rv, float(bn.momentum), float(bn.eps), bool(relu), int(pool))
     # eval mode (teacher inference): a per-channel affine map with the running statistics
+    if x.is_cuda and not (torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad)):
+        # no gradient wanted: the fused apply kernel with (running_mean, 1/sqrt(running_var + eps)) as the statistics
+        xn = _as_nhwc(x)
+        rn = _as_nhwc(residual) if residual is not None else None
+        rstd = (bn.running_var.float() + bn.eps).rsqrt()
+        y = K.bn_apply_fwd(xn, bn.running_mean.float().contiguous(), rstd, bn.weight.detach().float().contiguous(),
+                           bn.bias.detach().float().contiguous(), rn, relu, pool)
+        return y.permute(0, 3, 1, 2)
     scale = bn.weight * (bn.running_var + bn.eps).rsqrt()
     shift = bn.bias - bn.running_mean * scale
     y = x * scale.view(1, -1, 1, 1).to(x.dtype) + shift.view(1, -1, 1, 1).to(x.dtype)

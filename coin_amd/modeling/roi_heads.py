@@ -72,19 +72,52 @@ class OpenVocabularyRes5ROIHeads(nn.Module):
             num_classes=len(text_encoder.classes) - 1 if backgroud else len(text_encoder.classes),
             batch_size_per_image=cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE, positive_fraction=cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION,
             proposal_matcher=Matcher(cfg.MODEL.ROI_HEADS.IOU_THRESHOLDS, cfg.MODEL.ROI_HEADS.IOU_LABELS, allow_low_quality_matches=False),
-            proposal_append_gt=cfg.MODEL.ROI_HEADS.PROPOSAL_APPEND_GT, BG_TRAIN=cfg.CLOUD.BG_TRAIN)
+            proposal_append_gt=cfg.MODEL.ROI_HEADS.PROPOSAL_APPEND_GT, BG_TRAIN=cfg.CLOUD.BG_TRAIN)._set(
+                inference_rois_per_image=cfg.MODEL.RPN.POST_NMS_TOPK_TEST)
+
+    def _set(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+        return self
 
     def _shared_roi_transform(self, features, boxes, backbone_res5):
         return backbone_res5(self.pooler(features, boxes))
 
-    def _pooled(self, features, boxes, res5, attnpool):
+    ROI_BUCKET = 64
+
+    inference_rois_per_image = None  # MODEL.RPN.POST_NMS_TOPK_TEST: the teacher / evaluation pass is padded to exactly this many rows
+
+    def _pooled(self, features, boxes, res5, attnpool, fixed_shape: bool = False, pad_to: int = 0):
+        """RoIAlign -> res5 -> pooled features [R, C].
+
+        Passes whose RoI count changes from call to call (the C-box pass, the step_one/two proposal pass when an image yields
+        fewer candidates, inference) are padded to a multiple of ROI_BUCKET rows: MIOpen compiles / searches kernels per
+        convolution shape (seconds for every new batch size), so the shapes must repeat.  The padding is exact: the filler
+        rows are excluded from the train-mode BatchNorm statistics and receive zero gradient (`layers.valid_rows`), and
+        their outputs are dropped here."""
+        if isinstance(boxes, torch.Tensor):
+            rois = boxes
+        else:
+            rois = torch.cat([torch.cat([b.tensor.new_full((len(b), 1), float(i)), b.tensor], dim=1) for i, b in enumerate(boxes)], dim=0)
+        r = rois.shape[0]
+        bucket = self.ROI_BUCKET if r <= 16 * self.ROI_BUCKET else 4 * self.ROI_BUCKET
+        pad = 0 if (fixed_shape or r == 0 or not rois.is_cuda) else (-r) % bucket
+        if pad_to and rois.is_cuda and 0 < r <= pad_to:
+            pad = pad_to - r  # one shape for ever (the EMA teacher's proposal count changes every step)
+        if pad:
+            rois = torch.cat([rois, rois.new_zeros((pad, 5))], dim=0)
+        with L.valid_rows(r if pad else None):
+            out = self._pooled_rows(features, rois, res5, attnpool)
+        return out[:r] if pad else out
+
+    def _pooled_rows(self, features, rois, res5, attnpool):
         if self.pooling_type == "meanpool" and isinstance(res5, torch.nn.Sequential) and len(res5) > 0 and hasattr(res5[-1], "conv3"):
             # res5 (clip_roi_heads.py:172-176) with the spatial mean (:207-208) folded into the last block's epilogue
-            x = self.pooler([features[f] for f in self.in_features], boxes)
+            x = self.pooler([features[f] for f in self.in_features], rois)
             for block in list(res5)[:-1]:
                 x = block(x)
             return res5[-1](x, mean_pool=True).flatten(1).to(self.compute_dtype)
-        x = self._shared_roi_transform([features[f] for f in self.in_features], boxes, res5)
+        x = self._shared_roi_transform([features[f] for f in self.in_features], rois, res5)
         if self.pooling_type == "meanpool":
             return x.mean(dim=[2, 3]).to(self.compute_dtype)
         if self.pooling_type == "attnpool":
@@ -97,7 +130,7 @@ class OpenVocabularyRes5ROIHeads(nn.Module):
             ps = self.sample_packed(proposals, targets)
             n, r = len(proposals), ps.per_image
             bidx = torch.arange(n, device=ps.boxes.device, dtype=ps.boxes.dtype).repeat_interleave(r).unsqueeze(1)
-            predictions = self.box_predictor(self._pooled(features, torch.cat([bidx, ps.boxes], dim=1), res5, attnpool), branch=branch)
+            predictions = self.box_predictor(self._pooled(features, torch.cat([bidx, ps.boxes], dim=1), res5, attnpool, fixed_shape=True), branch=branch)
             return [], self.box_predictor.losses_packed(predictions, ps, update_prototype=update_prototype)
         if train:
             assert targets
@@ -112,7 +145,8 @@ class OpenVocabularyRes5ROIHeads(nn.Module):
                 raise NotImplementedError
         else:
             boxes = [p.proposal_boxes for p in proposals]
-        predictions = self.box_predictor(self._pooled(features, boxes, res5, attnpool), branch=branch)
+        pad_to = 0 if train or not self.inference_rois_per_image else self.inference_rois_per_image * len(boxes)
+        predictions = self.box_predictor(self._pooled(features, boxes, res5, attnpool, pad_to=pad_to), branch=branch)
         if not train:
             pred_instances, _ = self.box_predictor.inference(predictions, proposals)
             return pred_instances, {}

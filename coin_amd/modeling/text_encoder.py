@@ -141,10 +141,10 @@ class TEXT_ENCODER(nn.Module):
             x = self.token_embedding(text.long())
             eot = text.argmax(dim=-1)
         x = x.float() + self.positional_embedding
-        if x.is_cuda and torch.is_autocast_enabled():
+        if x.is_cuda and torch.is_autocast_enabled("cuda"):
             # bf16 throughput mode: keep the residual stream in the compute dtype, as the reference's fp16 encoder does
             # (clip_text.py:137,194 `x.type(self.dtype)`); an fp32 stream turns every residual add into a mixed-dtype kernel
-            x = x.to(torch.get_autocast_gpu_dtype())
+            x = x.to(torch.get_autocast_dtype("cuda"))
         x = self.ln_final(self.transformer(x))
         x = x[torch.arange(x.shape[0], device=x.device), eot.long()]
         x = x @ L.compute_weight(self.text_projection, L.compute_dtype_of(x))

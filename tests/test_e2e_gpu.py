@@ -99,3 +99,77 @@ def test_box_predictor_step_and_ckg_update_fp32_vs_reference_golden(tag):
     close(out["gx"], z["gx"], 1e-4, "gx")
     for k, g in out["grads"].items():
         close(g, z["g::" + k], 1e-4, k)
+
+
+@pytest.mark.parametrize("burned_up", [False, True])
+def test_cointrainer_full_size_steps(burned_up):
+    """BASELINE configs[2] shape (Foggy-Cityscapes-shaped 667x1333 views, RN50, 512 RoIs, teacher inference with 1000 RoIs):
+    CoinTrainer steps run in bf16 on the HIP kernels; losses finite; the CKG module, the student and (after burn-up) the EMA
+    teacher move."""
+    import os
+    import time
+
+    from coin_amd.config import get_cfg
+    from coin_amd.data.synthetic import synthetic_offline_detections
+    from coin_amd.engine import CoinTrainer
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(root, "configs", "coin", "GDINO", "foggy_synthetic.yaml"))
+    cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", 2, "AMD.SYNTHETIC.NUM_IMAGES", 2, "AMD.TEXT_TEMPLATES", 2, "MODEL.DEVICE", "cuda:0",
+                         "CLOUD.BURN_UP_STEP", 0 if burned_up else 100, "CLOUD.PROTOTYPE_UPDATE_START", 0, "CLOUD.CLS_B_THRESH", 0.2])
+    torch.manual_seed(11)
+    tr = CoinTrainer(cfg)
+    real_forward, g_det = tr.offline_teacher.forward, torch.Generator().manual_seed(7)
+
+    def teacher(batched_inputs, branch=None, **kw):  # the real inference runs; the matcher gets CLIPDET-like detections
+        out = real_forward(batched_inputs, branch=branch, **kw)
+        assert len(out) == len(batched_inputs)
+        return [synthetic_offline_detections(tr.model_CLOUD.get_results()[d["file_name"]], g_det, device="cuda:0") for d in batched_inputs]
+
+    tr.offline_teacher.forward = teacher
+    merge_before = [p.detach().clone() for p in tr.merge.parameters()]
+    teacher_w = tr.offline_teacher.roi_heads.box_predictor.cls_score.weight
+    tw_before = teacher_w.detach().clone()
+    recs = []
+    for i in range(3):
+        if i == 2:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        recs.append(tr.run_step())
+    torch.cuda.synchronize()
+    print(f"CoinTrainer step ({'step_two' if burned_up else 'step_one'}): {(time.perf_counter() - t0) * 1e3:.1f} ms for 2 views")
+    for rec in recs:
+        vals = {k: float(v) for k, v in rec.items()}
+        assert all(np.isfinite(v) for v in vals.values()), vals
+        assert {"loss_text_align", "loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc", "loss_rpn_distillation", "loss_distillation",
+                "loss_merge_a", "loss_merge_b", "loss_merge_base", "loss_merge_grad"} <= set(vals), sorted(vals)
+    assert any(not torch.equal(a, b) for a, b in zip(merge_before, tr.merge.parameters()))
+    assert (not torch.equal(tw_before, teacher_w)) == burned_up
+
+
+def test_inference_fp32_vs_reference_golden():
+    """Teacher / evaluation path (OpenVocabularyRCNN.inference, clip_rcnn.py:381-426; fast_rcnn_inference, fast_rcnn.py:116-175) on
+    the device: eval-mode BatchNorm through the fused apply kernel, RPN top-k + device NMS, RoIAlign, class-wise NMS, top-100."""
+    from e2e_util import tiny_product_detector
+    from golden_util import T, load, load_weights
+
+    z = load("inference")
+    model = tiny_product_detector()
+    load_weights(model, z)
+    model.to("cuda:0")
+    model.eval()
+    batch = [{"image": T(z[f"img{i}"]).cuda(), "height": int(z[f"hw{i}"][0]), "width": int(z[f"hw{i}"][1])} for i in range(2)]
+    res = model(batch, branch="test")
+    for i, r in enumerate(res):
+        inst = r["instances"].to("cpu")
+        assert len(inst) == z[f"det{i}.scores"].shape[0]
+        # canonical row order on both sides (scores tie when one box survives under several classes)
+        ours = torch.cat([inst.pred_classes.double().unsqueeze(1), inst.scores.double().unsqueeze(1), inst.pred_boxes.tensor.double()], dim=1).numpy()
+        ref = np.concatenate([z[f"det{i}.pred_classes"].astype(np.float64)[:, None], z[f"det{i}.scores"].astype(np.float64)[:, None],
+                              z[f"det{i}.pred_boxes"].astype(np.float64)], axis=1)
+        key = lambda m: np.lexsort((np.round(m[:, 2], 1), np.round(m[:, 1], 3), m[:, 0]))
+        ours, ref = ours[key(ours)], ref[key(ref)]
+        assert (ours[:, 0] == ref[:, 0]).all()
+        np.testing.assert_allclose(ours[:, 1], ref[:, 1], atol=1e-4)
+        np.testing.assert_allclose(ours[:, 2:], ref[:, 2:], atol=2e-2)

@@ -498,3 +498,29 @@ def test_nms_large_and_class_aware(K):
     got = box_ops.batched_nms(dev(b[:3000]), dev(s[:3000]), dev(idx[:3000]), 0.5).cpu()
     ref = d2.batched_nms(b[:3000], s[:3000], idx[:3000], 0.5)
     assert torch.equal(got, ref)
+
+
+def test_bn_act_valid_rows_padding_is_exact():
+    """Shape padding (layers.valid_rows): statistics, outputs and gradients of the real rows are those of the un-padded batch;
+    the filler rows get zero gradient."""
+    from coin_amd import layers as L
+
+    g = torch.Generator().manual_seed(21)
+    n, pad, c, h, w = 5, 3, 64, 7, 7
+    x = torch.randn(n, c, h, w, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    filler = (torch.randn(pad, c, h, w, generator=g) * 50 + 9).cuda().contiguous(memory_format=torch.channels_last)
+    r = torch.randn(n, c, h, w, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    for pool, res in ((1, True), (1, False), (2, False), (0, True)):
+        bn_a, bn_b = torch.nn.BatchNorm2d(c).cuda(), torch.nn.BatchNorm2d(c).cuda()
+        xa = x.clone().requires_grad_(True)
+        ya = L.bn_act(xa, bn_a, True, r if res else None, pool)
+        dy = torch.randn(ya.shape, generator=g).cuda()
+        ya.backward(dy)
+        xb = torch.cat([x, filler]).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        rb = torch.cat([r, filler]).contiguous(memory_format=torch.channels_last) if res else None
+        with L.valid_rows(n):
+            yb = L.bn_act(xb, bn_b, True, rb, pool)
+        yb[:n].backward(dy)
+        assert torch.equal(ya, yb[:n]) and torch.equal(xa.grad, xb.grad[:n])
+        assert float(xb.grad[n:].abs().max()) == 0.0
+        assert torch.equal(bn_a.weight.grad, bn_b.weight.grad) and torch.equal(bn_a.running_var, bn_b.running_var)

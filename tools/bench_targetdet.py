@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Timing of the targetDET distillation step (BASELINE.json configs[2] shape) on ONE GPU -- informational, not the bench.py metric.
+
+    python tools/bench_targetdet.py [--steps 8] [--warmup 4] [--images 2] [--step-two]
+
+Reports ms/step and student views/s (a step = teacher inference on the weak views + matching + student step on the strong views).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--images", type=int, default=2)
+    ap.add_argument("--step-two", action="store_true")
+    args = ap.parse_args()
+    import torch
+
+    from coin_amd.config import get_cfg
+    from coin_amd.data.synthetic import synthetic_offline_detections
+    from coin_amd.engine import CoinTrainer
+
+    torch.backends.cudnn.benchmark = True
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "coin", "GDINO", "foggy_synthetic.yaml"))
+    cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", args.images, "AMD.SYNTHETIC.NUM_IMAGES", args.images, "AMD.TEXT_TEMPLATES", 4,
+                         "MODEL.DEVICE", "cuda:0", "CLOUD.BURN_UP_STEP", 0 if args.step_two else 10 ** 9, "CLOUD.PROTOTYPE_UPDATE_START", 0])
+    torch.manual_seed(cfg.SEED)
+    tr = CoinTrainer(cfg)
+    real_forward, g = tr.offline_teacher.forward, torch.Generator().manual_seed(7)
+
+    def teacher(batched_inputs, branch=None, **kw):  # real teacher inference is executed and timed; its (random-init) detections
+        real_forward(batched_inputs, branch=branch, **kw)  # are replaced by CLIPDET-like ones so that A/B/C sets are populated
+        return [synthetic_offline_detections(tr.model_CLOUD.get_results()[d["file_name"]], g, device="cuda:0") for d in batched_inputs]
+
+    tr.offline_teacher.forward = teacher
+    for _ in range(args.warmup):
+        tr.run_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rec = tr.run_step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    print(json.dumps({"workload": "targetDET " + ("step_two" if args.step_two else "step_one"), "images_per_step": args.images, "ms_per_step": dt * 1e3,
+                      "student_views_per_s": args.images / dt, "losses": {k: round(float(v), 4) for k, v in rec.items()}}))
+
+
+if __name__ == "__main__":
+    main()
