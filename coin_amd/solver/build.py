@@ -84,6 +84,11 @@ class FusedSGD:
         if self._table is None:
             self._table = K.SgdTable(params, [g["lr"] for g in self.param_groups], [g["weight_decay"] for g in self.param_groups])
         grads = [p.grad for p in params]  # None -> the tensor is skipped this step, as torch.optim.SGD does
+        for i, (p, g) in enumerate(zip(params, grads)):
+            if g is not None and (g.stride() != p.stride() or g.dtype != p.dtype):
+                # the kernel is elementwise on storage: bring a gradient that autograd / DDP laid out differently to the
+                # parameter's (dense) layout -- normally never taken (both honour the "gradient layout contract")
+                p.grad = grads[i] = torch.empty_like(p).copy_(g)
         # lr_i(t) = base_lr_i * factor(t): the factor travels as a kernel argument, the table keeps the base rates
         factor, uniform = None, True
         for g in self.param_groups:
