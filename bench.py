@@ -154,8 +154,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("COIN_FORCE_DDP") == "1":  # COIN_FORCE_DDP: exercise the DDP / RCCL path with a single rank
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from coin_amd import kernels as K
@@ -228,7 +231,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = run_cpu_baseline(args.cpu_timeout)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -47,9 +47,11 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
 
 // grid: B; block: 256.  Thread t owns 64-bit word t of the running "removed" bitmap (n_max <= 256*64 = 16384).
 // Per 64-box block: wave 0 resolves the greedy order inside the block on the diagonal word with wave shuffles (registers
-// only); then every thread ORs the mask rows of the block's boxes into its word.  The 64 row reads are issued
-// unconditionally (masked by the kept bits afterwards): they do not depend on each other, are coalesced across threads
-// and together read the bit matrix exactly once.
+// only); then every thread ORs the mask rows of the block's boxes into its word.  The 64 row reads of a block do not depend
+// on the block's outcome (they are masked by the kept bits afterwards), so the rows -- and the diagonal word -- of block
+// b+1 are requested BEFORE block b is resolved and are in registers by the time they are needed: the serial chain per
+// block is two barriers, the 64-step shuffle loop and 64 ANDs/ORs, not a memory round trip.  One workgroup per image runs
+// alone on its CU, so the ~260 VGPRs of the double-buffered rows cost nothing.
 __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
                                                        const int* __restrict__ counts, int n_max, int col_blocks,
                                                        int max_keep, int* __restrict__ keep, int* __restrict__ num_keep) {
@@ -61,17 +63,40 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long*
   unsigned long long remv = 0ull;
   int nk = 0;
   const int nblk = (n + 63) >> 6;
+  const bool owner = t < col_blocks;
+
+  unsigned long long cur[64], nxt[64];
+  unsigned long long diag_cur = 0ull, diag_nxt = 0ull;
+  auto fetch = [&](int blk, unsigned long long (&rows)[64], unsigned long long& diag) {
+    if (blk < nblk && owner && t > blk) {
+#pragma unroll
+      for (int j = 0; j < 64; ++j) {
+        int row = blk * 64 + j;
+        row = row < n_max ? row : n_max - 1;
+        rows[j] = m[(size_t)row * col_blocks + t];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 64; ++j) rows[j] = 0ull;
+    }
+    const int drow = blk * 64 + lane;
+    diag = (blk < nblk && wave == 0 && drow < n) ? m[(size_t)drow * col_blocks + blk] : 0ull;
+  };
+  fetch(0, nxt, diag_nxt);
   for (int blk = 0; blk < nblk && nk < max_keep; ++blk) {
+#pragma unroll
+    for (int j = 0; j < 64; ++j) cur[j] = nxt[j];
+    diag_cur = diag_nxt;
+    fetch(blk + 1, nxt, diag_nxt);  // in flight while this block is resolved
     if (t == blk) s_rw = remv;
     __syncthreads();
     if (wave == 0) {
       unsigned long long rw = s_rw;
       const int row = blk * 64 + lane;
-      const unsigned long long diag = row < n ? m[(size_t)row * col_blocks + blk] : 0ull;
       unsigned long long kept = 0ull;
       const int lim = (n - blk * 64) < 64 ? (n - blk * 64) : 64;
       for (int j = 0; j < lim; ++j) {
-        const unsigned long long dj = __shfl(diag, j, 64);
+        const unsigned long long dj = __shfl(diag_cur, j, 64);
         if (!((rw >> j) & 1ull)) {
           kept |= 1ull << j;
           rw |= dj;
@@ -85,17 +110,10 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long*
     }
     __syncthreads();
     const unsigned long long kept = s_kept;
-    if (t > blk && t < col_blocks) {
-      unsigned long long acc = 0ull;
-#pragma unroll 16
-      for (int j = 0; j < 64; ++j) {
-        int row = blk * 64 + j;
-        row = row < n_max ? row : n_max - 1;
-        const unsigned long long v = m[(size_t)row * col_blocks + t];
-        acc |= v & (0ull - ((kept >> j) & 1ull));
-      }
-      remv |= acc;
-    }
+    unsigned long long acc = 0ull;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) acc |= cur[j] & (0ull - ((kept >> j) & 1ull));
+    remv |= acc;
     nk += __popcll(kept);
   }
   if (t == 0) num_keep[b] = nk < max_keep ? nk : max_keep;

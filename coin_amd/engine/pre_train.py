@@ -11,6 +11,7 @@ pre_train.py:59-62.
 """
 from __future__ import annotations
 
+import os
 import time
 from typing import Dict, List, Optional
 
@@ -34,7 +35,8 @@ class PRETrainer(BASE_Trainer):
         self.model.train()
         self.optimizer = build_optimizer(cfg, self.model, name="all")
         self.ddp_model = self.model
-        if self.world_size > 1:
+        force_ddp = os.environ.get("COIN_FORCE_DDP") == "1" and dist.is_available() and dist.is_initialized()  # 1-rank dry run of the DDP path
+        if self.world_size > 1 or force_ddp:
             self.ddp_model = torch.nn.parallel.DistributedDataParallel(
                 self.model, device_ids=[self.device.index] if self.device.type == "cuda" else None, broadcast_buffers=False,
                 gradient_as_bucket_view=True, bucket_cap_mb=32)
