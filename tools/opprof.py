@@ -27,6 +27,13 @@ def main():
     from coin_amd.engine import PRETrainer
 
     torch.backends.cudnn.benchmark = True
+    if os.environ.get("COIN_FORCE_DDP") == "1":  # profile the DDP path with a single rank
+        import torch.distributed as dist
+
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29512"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
     cfg = bench.build_cfg(1, "cuda:0", args.dtype)
     torch.manual_seed(cfg.SEED)
     tr = PRETrainer(cfg)
