@@ -1,0 +1,47 @@
+"""Optional: when the reference checkout is present (the build container), re-run golden generators against the reference's own
+modules and check that the committed fixtures are what they produce.  Skipped on the GPU box (no /root/reference there)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("COIN_REFERENCE_ROOT", "/root/reference")
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "coin")), reason="reference checkout not present")
+
+_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {golden!r})
+import gen_golden as G
+captured = {{}}
+def npz(name, **arrays):
+    captured[name] = {{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()}}
+G.npz = npz
+for case in {cases!r}:
+    getattr(G, case)()
+for name, arrays in captured.items():
+    np.savez(f"{out}/{{name}}.npz", **arrays)
+"""
+
+
+@pytest.mark.parametrize("cases,files", [
+    (["case_mil_losses"], ["mil_losses"]),
+    (["case_match_dual_teacher"], ["match_dual_teacher"]),
+    (["case_ckg", "case_ema"], ["ckg", "ema"]),
+])
+def test_committed_fixtures_are_reproduced_by_the_reference(tmp_path, cases, files):
+    golden = os.path.join(HERE, "golden")
+    script = _SCRIPT.format(golden=golden, cases=cases, out=str(tmp_path))
+    res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, cwd=golden)
+    assert res.returncode == 0, res.stderr[-2000:]
+    for f in files:
+        new, old = np.load(tmp_path / f"{f}.npz"), np.load(os.path.join(golden, f"{f}.npz"))
+        assert set(new.files) == set(old.files), f
+        for k in old.files:
+            if old[k].dtype.kind in "fc":
+                np.testing.assert_allclose(new[k], old[k], rtol=1e-6, atol=1e-7, err_msg=f"{f}:{k}")
+            else:
+                assert (new[k] == old[k]).all(), f"{f}:{k}"
