@@ -110,6 +110,10 @@ class CoinTrainer(BASE_Trainer):
         assert self.model.training, "[PTrainer] model was changed to eval mode!"
         strong, weak = next(self._data_loader_iter)
         burn = cfg.CLOUD.BURN_UP_STEP
+        # Under DDP every rank runs the merge module once at this fixed point of the step, whatever its batch contains: DDP's own
+        # collectives (bucket rebuild after the first step) and the gradient all-reduce are then entered in the same order
+        # everywhere.  The term is identically zero.
+        merge_zero = self._zero_merge_loss() if self.world_size > 1 else None
         if self.iter >= burn and (self.iter - burn) % cfg.CLOUD.OFFLINE_TEACHER_UPDATE_ITER == 0:
             self.update_teacher(cfg.CLOUD.EMA_KEEP_RATE_OFFLINE)
         with torch.no_grad():
@@ -123,10 +127,22 @@ class CoinTrainer(BASE_Trainer):
         record = self.ddp_model(strong, self.ddp_merge, dual_teacher_instances, branch=branch, update_prototype=update_prototype)
         self.optimizer.zero_grad()
         self.optimizer_merge.zero_grad()
-        if "loss_merge_a" in record:
+        has_merge = "loss_merge_a" in record
+        run_merge = has_merge
+        if self.world_size > 1:
+            # The merge module is data-parallel too (trainer.py:70-72), so its gradient all-reduce must be entered by every rank
+            # or by none.  Whether a rank's batch contains B boxes is data dependent: the ranks agree on one flag per step, and
+            # a rank without merge terms contributes a zero gradient (the reference would dead-lock in that mixed case).
+            flag = torch.tensor([float(has_merge)], device=self.device)
+            dist.all_reduce(flag)
+            run_merge = bool(flag.item() > 0)
+        if run_merge:
             # CKG update (trainer.py:192-197); gradients are formed for the merge parameters only
-            record["loss_merge_grad"] = self.model.roi_heads.box_predictor.merge_grad_loss()
-            (record["loss_merge_grad"] + record["loss_merge_base"]).backward(inputs=list(self.merge.parameters()), retain_graph=True)
+            ckg_loss = merge_zero if merge_zero is not None else 0.0
+            if has_merge:
+                record["loss_merge_grad"] = self.model.roi_heads.box_predictor.merge_grad_loss()
+                ckg_loss = ckg_loss + record["loss_merge_grad"] + record["loss_merge_base"]
+            ckg_loss.backward(inputs=list(self.merge.parameters()), retain_graph=has_merge)
             self.optimizer_merge.step()
         self.optimizer.zero_grad()
         self.optimizer_merge.zero_grad()
@@ -141,6 +157,15 @@ class CoinTrainer(BASE_Trainer):
             self.WEIGHT_FOR_BOX_A = 0.5
         self.iter += 1
         return record
+
+    def _zero_merge_loss(self) -> torch.Tensor:
+        """A loss that is identically zero but whose graph runs through the (DDP-wrapped) merge module: lets a rank without B
+        boxes take part in the merge module's gradient all-reduce."""
+        te = self.model.roi_heads.box_predictor.text_encoder
+        proto = te.prototype_b_offline.data
+        x = proto.new_zeros((0, proto.shape[1]))
+        probs = proto.new_zeros((0, proto.shape[0]))
+        return self.ddp_merge(x, proto, te.prototype_b_online.data, probs, probs).sum() * 0.0
 
     def train(self):
         for _ in range(self.start_iter, self.max_iter):

@@ -70,3 +70,67 @@ def test_two_rank_gloo_training_keeps_parameters_in_sync(tmp_path):
     assert params_equal > 50
     assert buffers_differ > 0  # BatchNorm running statistics are per rank: different images -> different statistics
     assert a["loss"] != b["loss"]  # each rank trained on its own shard
+
+
+def _coin_worker(rank, world, port, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cpu_shim import cpu_kernels
+    from coin_amd.config import get_cfg
+    from coin_amd.data.synthetic import synthetic_offline_detections
+    from coin_amd.engine import CoinTrainer
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(HERE, "..", "configs", "coin", "GDINO", "foggy_synthetic.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu", "AMD.COMPUTE_DTYPE", "fp32", "AMD.SYNTHETIC.HEIGHT", 96, "AMD.SYNTHETIC.WIDTH", 128,
+                         "AMD.SYNTHETIC.BOXES_PER_IMAGE", 6, "AMD.SYNTHETIC.NUM_IMAGES", 2, "SOLVER.IMG_PER_BATCH_UNLABEL", 2,
+                         "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 16, "MODEL.RPN.PRE_NMS_TOPK_TRAIN", 100, "MODEL.RPN.POST_NMS_TOPK_TRAIN", 30,
+                         "MODEL.RPN.PRE_NMS_TOPK_TEST", 60, "MODEL.RPN.POST_NMS_TOPK_TEST", 20, "AMD.TEXT_TEMPLATES", 1, "MODEL.MERGE_DIM", 32,
+                         "AMD.ARCH.LAYERS", [1, 1, 1, 1], "AMD.ARCH.WIDTH", 8, "AMD.ARCH.TEXT_WIDTH", 32, "AMD.ARCH.TEXT_LAYERS", 2,
+                         "AMD.ARCH.TEXT_HEADS", 2, "AMD.ARCH.TEXT_DIM", 32, "AMD.ARCH.CONTEXT_LENGTH", 16, "AMD.ARCH.VOCAB_SIZE", 64,
+                         "CLOUD.BURN_UP_STEP", 1, "CLOUD.PROTOTYPE_UPDATE_START", 0, "CLOUD.CLS_B_THRESH", 0.2])
+    with cpu_kernels():
+        torch.manual_seed(0)
+        tr = CoinTrainer(cfg)
+        torch.manual_seed(100 + rank)
+        g_det = torch.Generator().manual_seed(7 + rank)
+        real_forward = tr.offline_teacher.forward
+
+        def teacher(batched_inputs, branch=None, **kw):
+            real_forward(batched_inputs, branch=branch, **kw)
+            return [synthetic_offline_detections(tr.model_CLOUD.get_results()[d["file_name"]], g_det) for d in batched_inputs]
+
+        tr.offline_teacher.forward = teacher
+        with torch.no_grad():
+            for n, p in tr.model.named_parameters():
+                if n.endswith("bn3.weight"):
+                    p.fill_(0.5)
+        for _ in range(2):  # step_one, then step_two with the EMA teacher update
+            rec = tr.run_step()
+    torch.save({"sd": {k: v.clone() for k, v in tr.model.state_dict().items()}, "merge": {k: v.clone() for k, v in tr.merge.state_dict().items()},
+                "loss": {k: float(v) for k, v in rec.items()}}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_cointrainer_keeps_student_and_ckg_in_sync(tmp_path):
+    """targetDET step under DDP (trainer.py:66-72: student AND merge module are wrapped): after a step_one and a step_two step the
+    student's and the CKG module's parameters are identical on both ranks although each rank saw its own images."""
+    world, port = 2, _free_port()
+    mp.start_processes(_coin_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    a, b = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    n = 0
+    for k in a["sd"]:
+        if "running_" in k or "num_batches" in k or "per_class_feat" in k or "prototype" in k:
+            continue
+        assert torch.allclose(a["sd"][k], b["sd"][k], rtol=0, atol=1e-7), f"student {k} diverged across ranks"
+        n += 1
+    assert n > 50
+    for k in a["merge"]:
+        assert torch.allclose(a["merge"][k], b["merge"][k], rtol=0, atol=1e-7), f"CKG {k} diverged across ranks"
+    assert a["loss"] != b["loss"]
+    # the CKG update ran (at least one rank had B boxes; a rank without them joins the all-reduce with a zero gradient)
+    assert "loss_merge_grad" in a["loss"] or "loss_merge_grad" in b["loss"]
