@@ -282,3 +282,24 @@ def test_cointrainer_run_step_on_cpu_with_shimmed_kernels(burned_up):
     assert moved == burned_up  # the EMA teacher only moves after the burn-up phase
     assert tr.iter == 2 and tr.scheduler.last_epoch == 2 and tr.scheduler_merge.last_epoch == 2
     assert tr.WEIGHT_FOR_BOX_A == (0.5 if burned_up else 1.0)
+
+
+def test_train_net_cli_surface_and_dispatch(tmp_path):
+    """train_net.py keeps the reference's flags (util.py:151-184) and dispatches on CLOUD.Trainer; a 2-step CPU run of the
+    PRETRAIN config goes through it (kernels shimmed via the CLI-independent trainer class)."""
+    import importlib.util
+
+    root = os.path.abspath(os.path.join(os.path.dirname(GOLDEN), ".."))
+    spec = importlib.util.spec_from_file_location("train_net", os.path.join(root, "train_net.py"))
+    tn = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tn)
+    p = tn.default_argument_parser()
+    flags = {a.dest for a in p._actions}
+    assert {"config_file", "resume", "eval_only", "num_gpus", "num_machines", "machine_rank", "dist_url", "opts", "info", "test_model_role"} <= flags
+    args = p.parse_args(["--config-file", os.path.join(root, "configs", "coin", "GDINO", "foggy_synthetic.yaml"), "--num-gpus", "1",
+                         "SOLVER.MAX_ITER", "2", "OUTPUT_DIR", str(tmp_path)])
+    cfg = tn.setup(args)
+    assert cfg.CLOUD.Trainer == "CoinTrainer" and cfg.SOLVER.MAX_ITER == 2 and cfg.OUTPUT_DIR == str(tmp_path)
+    args = p.parse_args(["--config-file", os.path.join(root, "configs", "coin", "PRETRAINS", "CLIPDET_synthetic.yaml"), "--eval-only"])
+    with pytest.raises(SystemExit):
+        tn.main(args)

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Launcher with the reference's command-line surface for the hot path (train_net.py + coin/utils/util.py:151-184):
+
+    python train_net.py --config-file configs/coin/PRETRAINS/CLIPDET_synthetic.yaml [--num-gpus N] [KEY VALUE ...]
+    python train_net.py --config-file configs/coin/GDINO/foggy_synthetic.yaml SOLVER.MAX_ITER 100
+
+Same flags (``--config-file``, ``--resume``, ``--eval-only``, ``--num-gpus``, ``--num-machines``, ``--machine-rank``, ``--dist-url``,
+``--info``, ``--test_model_role``, trailing ``KEY VALUE`` overrides) and the same dispatch on ``cfg.CLOUD.Trainer``.  Only the
+trainers of the adaptation-training hot path exist here: ``PRETRAIN`` -> PRETrainer, ``CoinTrainer`` -> CoinTrainer; the collectors
+(GDINO / GLIP / CLIP), ORACLE and evaluation-only modes are outside the scope of this build and say so.
+One process per GPU: with ``--num-gpus N > 1`` the script re-launches itself through ``torch.distributed.run`` (RCCL over xGMI).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import subprocess
+import sys
+
+
+def default_argument_parser():
+    p = argparse.ArgumentParser(description="COIN adaptation-training hot path on MI355X")
+    p.add_argument("--config-file", default="", metavar="FILE", help="path to config file")
+    p.add_argument("--resume", action="store_true", help="resume from the checkpoint directory (not supported: no checkpoint formats yet)")
+    p.add_argument("--eval-only", action="store_true", help="perform evaluation only (outside the hot path)")
+    p.add_argument("--num-gpus", type=int, default=1, help="number of gpus *per machine*")
+    p.add_argument("--num-machines", type=int, default=1, help="total number of machines")
+    p.add_argument("--machine-rank", type=int, default=0, help="the rank of this machine (unique per machine)")
+    p.add_argument("--dist-url", default="tcp://127.0.0.1:29500", help="rendezvous URL (host:port are used for torch.distributed.run)")
+    p.add_argument("--info", default="")
+    p.add_argument("--test_model_role", default="targetdet")
+    p.add_argument("opts", default=None, nargs=argparse.REMAINDER, help="KEY VALUE pairs overriding config options")
+    return p
+
+
+def setup(args):
+    from coin_amd.config import get_cfg
+
+    cfg = get_cfg()
+    cfg.merge_from_file(args.config_file)
+    cfg.merge_from_list(list(args.opts or []))
+    return cfg
+
+
+def main(args):
+    import torch
+    import torch.distributed as dist
+
+    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        args.opts = list(args.opts or []) + ["MODEL.DEVICE", f"cuda:{local_rank}"]
+    cfg = setup(args)
+    if args.eval_only or args.resume:
+        raise SystemExit("--eval-only / --resume need the evaluation stack and checkpoint formats, which are outside this build's scope")
+    from coin_amd.engine import CoinTrainer, PRETrainer
+
+    trainers = {"PRETRAIN": PRETrainer, "CoinTrainer": CoinTrainer}
+    if cfg.CLOUD.Trainer not in trainers:
+        raise SystemExit(f"CLOUD.Trainer={cfg.CLOUD.Trainer!r}: only {sorted(trainers)} are on the adaptation-training hot path")
+    os.makedirs(cfg.OUTPUT_DIR, exist_ok=True)
+    if args.info:
+        with open(os.path.join(cfg.OUTPUT_DIR, "note.txt"), "a", encoding="utf-8") as f:
+            f.write(args.info)
+    torch.backends.cudnn.benchmark = True
+    torch.manual_seed(cfg.SEED + (dist.get_rank() if dist.is_initialized() else 0))  # util.py:89-90: per-rank seed
+    trainer = trainers[cfg.CLOUD.Trainer](cfg)
+    trainer.train()
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    a = default_argument_parser().parse_args()
+    if a.num_gpus * a.num_machines > 1 and "RANK" not in os.environ:
+        host, _, port = a.dist_url.replace("tcp://", "").partition(":")
+        cmd = [sys.executable, "-m", "torch.distributed.run", f"--nnodes={a.num_machines}", f"--node-rank={a.machine_rank}",
+               f"--nproc-per-node={a.num_gpus}", "--master-addr", host or "127.0.0.1", "--master-port", port or "29500"] + sys.argv
+        raise SystemExit(subprocess.call(cmd))  # children are started before anything touches the GPU in this process
+    main(a)
