@@ -50,6 +50,7 @@ class PRETrainer(BASE_Trainer):
                                                  num_images=max(per_gpu, cfg.AMD.SYNTHETIC.NUM_IMAGES // self.world_size))
             collect_model = data_loader.cache
         self._data_loader_iter = iter(data_loader)
+        self._next_batch = None  # one batch of look-ahead: the frozen stages of the next views run during this step
         self.collect_model = collect_model
         self.iter = self.start_iter = 0
         self.max_iter = cfg.SOLVER.MAX_ITER
@@ -73,10 +74,18 @@ class PRETrainer(BASE_Trainer):
 
     def run_step(self):
         assert self.model.training, "[PTrainer] model was changed to eval mode!"
-        strong, weak = next(self._data_loader_iter)
         thresh = 0.5 if tuple(self.cfg.DATASETS.TRAIN_UNLABEL) == ("cliparttrain",) else None
-        strong, weak = self.set_boxes([strong, weak], thresh=thresh)
-        strong.extend(weak)
+
+        def fetch():
+            strong, weak = next(self._data_loader_iter)
+            strong, weak = self.set_boxes([strong, weak], thresh=thresh)
+            strong.extend(weak)
+            return strong
+
+        strong = self._next_batch if self._next_batch is not None else fetch()
+        self._next_batch = fetch() if getattr(self.model, "overlap_streams", False) and self.device.type == "cuda" else None
+        if self._next_batch is not None:
+            self.model.set_lookahead(self._next_batch)
         start = self.cfg.CLOUD.PROTOTYPE_UPDATE_START
         update_prototype = start != -1 and self.iter >= start
         record = self.ddp_model(strong, branch="pre_train", update_prototype=update_prototype)

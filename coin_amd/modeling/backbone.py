@@ -186,17 +186,29 @@ class ModifiedResNet(nn.Module):
             x = _conv_bn(x, conv, bn, True)
         return self.avgpool(x)
 
-    def forward(self, x) -> Dict[str, torch.Tensor]:
+    def forward(self, x, frozen_done: bool = False) -> Dict[str, torch.Tensor]:
+        """frozen_done: `x` is already the output of `frozen_forward` (the stages without trainable parameters)."""
         assert x.dim() == 4
-        frozen_prefix = self.freeze_at  # stages [1, freeze_at] have no trainable parameter
+        frozen_prefix = min(self.freeze_at, 4)  # stages [1, freeze_at] have no trainable parameter
         stages = [self._stem, self.layer1, self.layer2, self.layer3]
         for i, stage in enumerate(stages, start=1):
+            if i <= frozen_prefix and frozen_done:
+                continue
             if i <= frozen_prefix and not x.requires_grad:
                 with torch.no_grad():
                     x = stage(x)
             else:
                 x = stage(x)
         return {"res4": x}
+
+    @torch.no_grad()
+    def frozen_forward(self, x) -> torch.Tensor:
+        """Stem + the frozen stages only.  Their result depends on the images alone (never on a weight update), so a trainer
+        may compute it for the NEXT batch while the current step is still running."""
+        stages = [self._stem, self.layer1, self.layer2, self.layer3]
+        for stage in stages[: min(self.freeze_at, 4)]:
+            x = stage(x)
+        return x
 
     def output_shape(self):
         return {n: ShapeSpec(channels=self._out_feature_channels[n], stride=self._out_feature_strides[n]) for n in self._out_features}
@@ -264,8 +276,11 @@ class CLIP_IMAGE(nn.Module):
         self.encoder.visual.layer4.train(mode)
         return self
 
-    def forward(self, image: torch.Tensor):
-        return self.encoder.visual(image)
+    def forward(self, image: torch.Tensor, frozen_done: bool = False):
+        return self.encoder.visual(image, frozen_done=frozen_done)
+
+    def frozen_forward(self, image: torch.Tensor) -> torch.Tensor:
+        return self.encoder.visual.frozen_forward(image)
 
 
 @BACKBONE_REGISTRY.register()

@@ -74,6 +74,46 @@ class OpenVocabularyRCNN(nn.Module):
 
     overlap_streams = True
 
+    # ---- look-ahead of the frozen stages -------------------------------------------------------------------------------
+    # The stem and the frozen stages (FREEZE_AT) see only the images: their output for the NEXT batch does not depend on
+    # this step's weight update.  A trainer announces the next batch with `set_lookahead`; this step's forward then issues
+    # that work on the side stream right after its own backbone, so it executes while the main stream is in the proposal
+    # chain (top-k, NMS scan, RoI sampling: a few workgroups on a 256-CU chip).  The next forward picks the result up.
+    _lookahead_batch = None
+    _lookahead_ready = None
+
+    def set_lookahead(self, batched_inputs):
+        self._lookahead_batch = batched_inputs
+
+    @staticmethod
+    def _batch_key(batched_inputs):
+        return tuple(x["image"].data_ptr() for x in batched_inputs)
+
+    def _launch_lookahead(self):
+        nxt, self._lookahead_batch = self._lookahead_batch, None
+        if nxt is None or not self.overlap_streams or not self.pixel_mean.is_cuda or not hasattr(self.backbone, "frozen_forward"):
+            return
+        if getattr(self, "_look_stream", None) is None:  # its own stream: the main stream later waits on `_side_stream`
+            self._look_stream = torch.cuda.Stream(device=self.pixel_mean.device)
+        side, cur = self._look_stream, torch.cuda.current_stream()
+        side.wait_stream(cur)  # starts once this step's backbone has run
+        with torch.cuda.stream(side), torch.no_grad():
+            imgs = self.preprocess_image(nxt)
+            with self._autocast():
+                x = self.backbone.frozen_forward(imgs.tensor)
+        self._lookahead_ready = (self._batch_key(nxt), imgs, x, side)
+
+    def _take_lookahead(self, batched_inputs):
+        ready, self._lookahead_ready = self._lookahead_ready, None
+        if ready is None or ready[0] != self._batch_key(batched_inputs):
+            return None, None
+        _, imgs, x, side = ready
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(side)
+        x.record_stream(cur)
+        imgs.tensor.record_stream(cur)
+        return imgs, x
+
     def _overlap_side_work(self, images, rpn_targets):
         """Work of the pre_train step that does not depend on the network's activations -- the prompt-conditioned text encoder
         (~300 small launches) and the anchor labelling / sampling (~150) -- is issued on a second HIP stream so that it runs
@@ -107,14 +147,17 @@ class OpenVocabularyRCNN(nn.Module):
         if not self.training or branch == "test":
             return self.inference(batched_inputs, branch=branch)
         dev = self.pixel_mean.device
-        images = self.preprocess_image(batched_inputs)
+        images, frozen_out = self._take_lookahead(batched_inputs)
+        if images is None:
+            images = self.preprocess_image(batched_inputs)
         with self._autocast():
             if branch == "pre_train":
                 rcnn = [x["RCNN"].to(dev) for x in batched_inputs]
                 rpn = [x["RPN"].to(dev) for x in batched_inputs]
                 merge_module = None
                 side = self._overlap_side_work(images, rpn)
-            features = self.backbone(images.tensor)
+            features = self.backbone(frozen_out, frozen_done=True) if frozen_out is not None else self.backbone(images.tensor)
+            self._launch_lookahead()
             if branch == "pre_train":
                 if side is not None:
                     torch.cuda.current_stream().wait_stream(side)
