@@ -105,22 +105,34 @@ class CoinTrainer(BASE_Trainer):
         return rcnn, rpn
 
     # ------------------------------------------------------------------ one step (trainer.py:160-218)
-    def run_step(self):
-        cfg = self.cfg
-        assert self.model.training, "[PTrainer] model was changed to eval mode!"
-        strong, weak = next(self._data_loader_iter)
-        burn = cfg.CLOUD.BURN_UP_STEP
-        # Under DDP every rank runs the merge module once at this fixed point of the step, whatever its batch contains: DDP's own
-        # collectives (bucket rebuild after the first step) and the gradient all-reduce are then entered in the same order
-        # everywhere.  The term is identically zero.
-        merge_zero = self._zero_merge_loss() if self.world_size > 1 else None
+    def _teacher_targets(self, weak):
+        """Steps 1-3 of the iteration `self.iter`: EMA of the teacher when due, teacher inference on the weak views, matching."""
+        cfg, burn = self.cfg, self.cfg.CLOUD.BURN_UP_STEP
         if self.iter >= burn and (self.iter - burn) % cfg.CLOUD.OFFLINE_TEACHER_UPDATE_ITER == 0:
             self.update_teacher(cfg.CLOUD.EMA_KEEP_RATE_OFFLINE)
         with torch.no_grad():
             self.offline_teacher.eval()
             offline_results = self.offline_teacher(weak, branch="test")
             self.offline_teacher.train()
-            dual_teacher_instances = self.match_boxes(weak, offline_results)
+            return self.match_boxes(weak, offline_results)
+
+    pipeline_teacher = True  # prepare the next iteration's targets right after this iteration's optimizer step (see run_step)
+    _pending = None
+
+    def run_step(self):
+        cfg = self.cfg
+        assert self.model.training, "[PTrainer] model was changed to eval mode!"
+        burn = cfg.CLOUD.BURN_UP_STEP
+        if self._pending is None:
+            strong, weak = next(self._data_loader_iter)
+            dual_teacher_instances = self._teacher_targets(weak)
+        else:
+            strong, dual_teacher_instances = self._pending
+            self._pending = None
+        # Under DDP every rank runs the merge module once at this fixed point of the step, whatever its batch contains: DDP's own
+        # collectives (bucket rebuild after the first step) and the gradient all-reduce are then entered in the same order
+        # everywhere.  The term is identically zero.
+        merge_zero = self._zero_merge_loss() if self.world_size > 1 else None
         start = cfg.CLOUD.PROTOTYPE_UPDATE_START
         update_prototype = start != -1 and self.iter >= start
         branch = "step_one" if self.iter < burn else "step_two"
@@ -156,6 +168,13 @@ class CoinTrainer(BASE_Trainer):
         if self.iter >= burn:  # trainer.py:150-157 (after_step): fused A boxes from the next step on
             self.WEIGHT_FOR_BOX_A = 0.5
         self.iter += 1
+        if self.pipeline_teacher and self.iter < self.max_iter:
+            # The next iteration begins with the teacher's EMA / inference / matching, which read nothing but the weights just
+            # updated -- doing them here is the same computation in the same order.  The difference is on the clock: the device
+            # is still executing this iteration's backward (enqueued asynchronously) while the host goes through the
+            # synchronising post-processing of the teacher's detections and the CPU matcher.
+            strong, weak = next(self._data_loader_iter)
+            self._pending = (strong, self._teacher_targets(weak))
         return record
 
     def _zero_merge_loss(self) -> torch.Tensor:
