@@ -303,3 +303,110 @@ def test_train_net_cli_surface_and_dispatch(tmp_path):
     args = p.parse_args(["--config-file", os.path.join(root, "configs", "coin", "PRETRAINS", "CLIPDET_synthetic.yaml"), "--eval-only"])
     with pytest.raises(SystemExit):
         tn.main(args)
+
+
+# ------------------------------------------------------------------------------------------ on-disk formats
+def _foreign_detectron2_file(path):
+    """A file as the reference writes it: objects of classes that live under detectron2's module paths (stand-ins with detectron2's
+    attribute layout: Instances = {_image_size, _fields}, Boxes = {tensor}); the stand-in modules are gone before it is read."""
+    import sys
+    import types
+
+    mods = {}
+    for name in ("detectron2", "detectron2.structures", "detectron2.structures.instances", "detectron2.structures.boxes"):
+        mods[name] = types.ModuleType(name)
+
+    class Boxes:  # noqa: N801
+        def __init__(self, tensor):
+            self.tensor = tensor
+
+    class Instances:  # noqa: N801
+        def __init__(self, image_size, fields):
+            self._image_size, self._fields = image_size, fields
+
+    Boxes.__module__, Boxes.__qualname__ = "detectron2.structures.boxes", "Boxes"
+    Instances.__module__, Instances.__qualname__ = "detectron2.structures.instances", "Instances"
+    mods["detectron2.structures.boxes"].Boxes = Boxes
+    mods["detectron2.structures.instances"].Instances = Instances
+    saved = {k: sys.modules.get(k) for k in mods}
+    sys.modules.update(mods)
+    try:
+        g = torch.Generator().manual_seed(5)
+        probs = torch.softmax(torch.randn(3, 9, generator=g), dim=1)
+        inst = lambda: Instances((1024, 2048), {"pred_boxes": Boxes(torch.tensor([[1.0, 2.0, 30.0, 40.0], [5.0, 5.0, 50.0, 60.0], [0.0, 0.0, 9.0, 9.0]])),
+                                                "scores": probs[:, :-1].max(1).values, "pred_classes": probs[:, :-1].argmax(1), "probs": probs})
+        entry = {"file_name": "a/b.png", "image_id": "b", "height": 1024, "width": 2048, "RCNN": {"instances": inst()}, "RPN": {"instances": inst()}}
+        torch.save({"results": {"foggytrain_0.02": {"a/b.png": entry}}}, path)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return probs
+
+
+def test_cloud_result_files_cross_the_boundary_in_both_directions(tmp_path):
+    from coin_amd.checkpoint import CloudResults, load_file
+    from coin_amd.structures import Boxes, Instances
+
+    path = str(tmp_path / "GDINO_collect.pth")
+    probs = _foreign_detectron2_file(path)
+    cache = CloudResults.load(path)                      # detectron2 classes inside are mapped onto coin_amd.structures
+    res = cache("a/b.png")
+    inst = res["RCNN"]["instances"]
+    assert isinstance(inst, Instances) and isinstance(inst.pred_boxes, Boxes) and inst.image_size == (1024, 2048)
+    assert torch.equal(inst.probs, probs) and res["height"] == 1024 and res["image_id"] == "b"
+    inst.pred_boxes.tensor.mul_(0)                        # a deep copy is handed out (gdino_collector.py:83-88)
+    assert float(cache("a/b.png")["RCNN"]["instances"].pred_boxes.tensor.abs().sum()) > 0
+    assert cache("missing.png") is None
+    out = str(tmp_path / "resaved.pth")
+    cache.save(out)                                       # written under detectron2's class paths again
+    raw = open(out, "rb").read()
+    assert b"detectron2.structures.instances" in raw and b"detectron2.structures.boxes" in raw and b"coin_amd" not in raw
+    assert Instances.__module__ == "coin_amd.structures" and Boxes.__name__ == "Boxes"
+    again = load_file(out)["results"]["foggytrain_0.02"]["a/b.png"]["RPN"]["instances"]
+    assert torch.equal(again.probs, probs) and torch.equal(again.pred_boxes.tensor[1], torch.tensor([5.0, 5.0, 50.0, 60.0]))
+
+
+def test_cointrainer_checkpoint_layout_roundtrip(tmp_path):
+    """DetectionTSCheckpointer layout (EnsembleTSModel prefixes, trainer.py:128-137) and the 'teacher.pth+results.pth' form of
+    MODEL.WEIGHTS (trainer.py:220-231)."""
+    from coin_amd.checkpoint import load_cointrainer_weights, load_file, save_cointrainer_checkpoint, save_file, split_ensemble_state_dict
+    from coin_amd.config import get_cfg
+    from coin_amd.engine import CoinTrainer
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(os.path.dirname(GOLDEN), "..", "configs", "coin", "GDINO", "foggy_synthetic.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu", "AMD.COMPUTE_DTYPE", "fp32", "AMD.SYNTHETIC.HEIGHT", 96, "AMD.SYNTHETIC.WIDTH", 128,
+                         "AMD.SYNTHETIC.BOXES_PER_IMAGE", 4, "AMD.SYNTHETIC.NUM_IMAGES", 1, "SOLVER.IMG_PER_BATCH_UNLABEL", 1, "AMD.TEXT_TEMPLATES", 1,
+                         "MODEL.MERGE_DIM", 32, "AMD.ARCH.LAYERS", [1, 1, 1, 1], "AMD.ARCH.WIDTH", 8, "AMD.ARCH.TEXT_WIDTH", 32, "AMD.ARCH.TEXT_LAYERS", 2,
+                         "AMD.ARCH.TEXT_HEADS", 2, "AMD.ARCH.TEXT_DIM", 32, "AMD.ARCH.CONTEXT_LENGTH", 16, "AMD.ARCH.VOCAB_SIZE", 64])
+    torch.manual_seed(1)
+    a = CoinTrainer(cfg)
+    a.iter = 7
+    ck = str(tmp_path / "model_0000006.pth")
+    save_cointrainer_checkpoint(a, ck)
+    blob = load_file(ck)
+    assert blob["iteration"] == 6 and {"model", "online_results", "ap_50_student", "ap_50_offline_teacher"} <= set(blob)
+    parts = split_ensemble_state_dict(blob["model"])
+    assert set(parts["student"]) == set(a.model.state_dict()) and set(parts["merge"]) == set(a.merge.state_dict())
+    assert all(k.startswith(("offline_teacher.", "model_student.", "merge_model.")) for k in blob["model"])
+    torch.manual_seed(2)
+    b = CoinTrainer(cfg)
+    load_cointrainer_weights(b, ck)
+    assert b.iter == 7
+    for k, v in a.model.state_dict().items():
+        assert torch.equal(v, b.model.state_dict()[k]), k
+    for k, v in a.merge.state_dict().items():
+        assert torch.equal(v, b.merge.state_dict()[k]), k
+    # two-file form: pre-train checkpoint ({"model": detector sd}) + cached cloud results
+    teacher_path, results_path = str(tmp_path / "pre_train_CLIP.pth"), str(tmp_path / "GDINO_collect.pth")
+    save_file({"model": {"module." + k: v for k, v in a.offline_teacher.state_dict().items()}, "iteration": 49999}, teacher_path)
+    _foreign_detectron2_file(results_path)
+    torch.manual_seed(3)
+    c = CoinTrainer(cfg)
+    load_cointrainer_weights(c, teacher_path + "+" + results_path)
+    for k, v in a.offline_teacher.state_dict().items():
+        assert torch.equal(v, c.offline_teacher.state_dict()[k]), k
+    assert c.model_CLOUD("a/b.png")["width"] == 2048
