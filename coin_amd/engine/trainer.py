@@ -177,6 +177,18 @@ class CoinTrainer(BASE_Trainer):
             self._pending = (strong, self._teacher_targets(weak))
         return record
 
+    def resume_or_load(self, resume: bool = False):
+        """trainer.py:220-262: ``MODEL.WEIGHTS`` = "offline_teacher.pth+cloud_results.pth" (start of adaptation) or one CoinTrainer
+        checkpoint.  Synthetic runs (no weights given) keep the random initialisation."""
+        from ..checkpoint import load_cointrainer_weights
+
+        if not self.cfg.MODEL.WEIGHTS:
+            assert self.cfg.AMD.SYNTHETIC.ENABLED, "pretrain models must be loaded!"
+            return
+        assert not (resume and "+" in self.cfg.MODEL.WEIGHTS), "resume need only one model."
+        load_cointrainer_weights(self, self.cfg.MODEL.WEIGHTS)
+        self._pending, self._ema = None, None
+
     def _zero_merge_loss(self) -> torch.Tensor:
         """A loss that is identically zero but whose graph runs through the (DDP-wrapped) merge module: lets a rank without B
         boxes take part in the merge module's gradient all-reduce."""

@@ -21,7 +21,7 @@ import sys
 def default_argument_parser():
     p = argparse.ArgumentParser(description="COIN adaptation-training hot path on MI355X")
     p.add_argument("--config-file", default="", metavar="FILE", help="path to config file")
-    p.add_argument("--resume", action="store_true", help="resume from the checkpoint directory (not supported: no checkpoint formats yet)")
+    p.add_argument("--resume", action="store_true", help="MODEL.WEIGHTS is one CoinTrainer checkpoint to continue from")
     p.add_argument("--eval-only", action="store_true", help="perform evaluation only (outside the hot path)")
     p.add_argument("--num-gpus", type=int, default=1, help="number of gpus *per machine*")
     p.add_argument("--num-machines", type=int, default=1, help="total number of machines")
@@ -52,8 +52,8 @@ def main(args):
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         args.opts = list(args.opts or []) + ["MODEL.DEVICE", f"cuda:{local_rank}"]
     cfg = setup(args)
-    if args.eval_only or args.resume:
-        raise SystemExit("--eval-only / --resume need the evaluation stack and checkpoint formats, which are outside this build's scope")
+    if args.eval_only:
+        raise SystemExit("--eval-only needs the evaluation stack, which is outside this build's scope")
     from coin_amd.engine import CoinTrainer, PRETrainer
 
     trainers = {"PRETRAIN": PRETrainer, "CoinTrainer": CoinTrainer}
@@ -66,6 +66,8 @@ def main(args):
     torch.backends.cudnn.benchmark = True
     torch.manual_seed(cfg.SEED + (dist.get_rank() if dist.is_initialized() else 0))  # util.py:89-90: per-rank seed
     trainer = trainers[cfg.CLOUD.Trainer](cfg)
+    if hasattr(trainer, "resume_or_load"):
+        trainer.resume_or_load(resume=args.resume)
     trainer.train()
     if dist.is_initialized():
         dist.barrier()
