@@ -410,3 +410,63 @@ def test_cointrainer_checkpoint_layout_roundtrip(tmp_path):
     for k, v in a.offline_teacher.state_dict().items():
         assert torch.equal(v, c.offline_teacher.state_dict()[k]), k
     assert c.model_CLOUD("a/b.png")["width"] == 2048
+
+
+def test_match_boxes_product_vs_oracle_with_rescale_and_flip():
+    """CoinTrainer.match_boxes (trainer.py:463-478): teacher detections in output-image pixels and cached cloud results in stored-image
+    pixels are brought to the weak view's network coordinates (rescale + the view's flip) and split into (A, B, C) -- product
+    (index-based matcher, coin_amd.structures) against the oracle (Instances-walking restatement pinned to the reference)."""
+    import copy
+    import random
+
+    from coin_amd.data.synthetic import synthetic_offline_detections, synthetic_teacher_result
+    from coin_amd.engine.trainer import CoinTrainer
+    from coin_amd.structures import Boxes
+    from oracle import d2
+    from oracle import trainer as OT
+
+    g = torch.Generator().manual_seed(33)
+    batch, offline, cache = [], [], {}
+    for i, flip in enumerate(("no", "horizontal")):
+        name = f"img{i}.png"
+        cloud = synthetic_teacher_result(name, f"id{i}", 200, 300, 10, 8, g)
+        cache[name] = cloud
+        offline.append(synthetic_offline_detections(cloud, g, extra=3))
+        batch.append({"file_name": name, "image_id": f"id{i}", "height": 200, "width": 300, "random_flip": flip,
+                      "image": torch.zeros(3, 160, 240, dtype=torch.uint8)})  # network input 0.8x the stored size
+
+    def to_oracle(inst):
+        out = OT.MyInstances(inst.image_size)
+        for k, v in inst.get_fields().items():
+            out.set(k, d2.Boxes(v.tensor.clone()) if isinstance(v, Boxes) else v.clone())
+        return out
+
+    def oracle_cache(name):
+        r = cache[name]
+        return {**{k: v for k, v in r.items() if k not in ("RCNN", "RPN")}, "RCNN": {"instances": to_oracle(r["RCNN"]["instances"])},
+                "RPN": {"instances": to_oracle(r["RPN"]["instances"])}}
+
+    def product_cache(name):
+        return copy.deepcopy(cache[name])
+
+    stub = type("T", (CoinTrainer,), {"__init__": lambda self: None})()
+    stub.cfg = type("C", (), {"CLOUD": type("CL", (), {"MATCHER": type("M", (), {"IOU_THRESHOLDS": 0.5})()})()})()
+    for weight in (1.0, 0.5):
+        stub.WEIGHT_FOR_BOX_A, stub.model_CLOUD = weight, product_cache
+        random.seed(99)
+        p_rcnn, p_rpn = stub.match_boxes(batch, copy.deepcopy(offline))
+        random.seed(99)
+        o_rcnn, o_rpn = OT.match_boxes(batch, [{"instances": to_oracle(o["instances"])} for o in offline], oracle_cache, 0.5, weight)
+        for prod, ora in ((p_rcnn, o_rcnn), (p_rpn, o_rpn)):
+            for (pa, pb, pc), (oa, ob, oc) in zip(prod, ora):
+                for pi, oi in ((pa, oa), (pb, ob), (pc, oc)):
+                    assert (pi is None) == (oi is None)
+                    if pi is None:
+                        continue
+                    assert set(pi.get_fields()) == set(oi.get_fields()) and len(pi) == len(oi)
+                    for k, v in pi.get_fields().items():
+                        a = v.tensor if isinstance(v, Boxes) else v
+                        b = oi.get(k)
+                        b = b.tensor if isinstance(b, d2.Boxes) else b
+                        torch.testing.assert_close(a.float(), b.float(), rtol=1e-6, atol=1e-5)
+        assert sum(len(t[0]) for t in p_rcnn) > 0 and sum(len(t[2]) for t in p_rcnn) > 0  # the case is not vacuous
