@@ -152,6 +152,8 @@ class FastRCNNOutputLayers(nn.Module):
         in the reference where theta are the only differentiation variables.  Call after `losses()` of a step_one / step_two
         forward that produced `loss_merge_a`."""
         assert self._merge_ctx is not None, "merge_grad_loss needs the context of a step_one/step_two losses() call with B boxes"
+        if self._merge_ctx[1].dtype == torch.bool:  # packed layout: (all rows, mask A, mask B, text, one-hot A, merged)
+            return self._merge_grad_loss_masked(*self._merge_ctx)
         x_a, x_b, text, oh_a, m_b = self._merge_ctx
         na = x_a.shape[0]
         with torch.autocast(x_a.device.type, enabled=False):
@@ -179,6 +181,31 @@ class FastRCNNOutputLayers(nn.Module):
         on a side stream so that its ~300 small launches overlap the backbone convolutions.  Consumed by the next forward."""
         self._text_prefetch = self.text_encoder(added=True)
         return self._text_prefetch
+
+    def _merge_grad_loss_masked(self, x, m_a, m_b, text, oh_a, merged) -> torch.Tensor:
+        """`merge_grad_loss` for the packed layout: the sub-graph is replayed on every row and the two MSE terms are masked
+        means (rows outside A / B contribute nothing to either gradient)."""
+        kc = self.num_classes + 1
+        with torch.autocast(x.device.type, enabled=False):
+            x = x.detach().float()
+            t = self.trans
+            h = F.leaky_relu(F.linear(x, t[0].weight, t[0].bias), 0.01)
+            h = F.leaky_relu(F.linear(h, t[2].weight, t[2].bias), 0.01)
+            h = F.linear(h, t[4].weight, t[4].bias)
+            cf = F.linear(h, self.cls_score.weight, self.cls_score.bias)
+            scores = F.normalize(cf, dim=1) @ F.normalize(text.detach().float(), dim=1).t() * self._inv_scale
+            p = F.softmax(scores, dim=1)
+            fa, fb = m_a.float(), m_b.float()
+            loss_a = (((p - oh_a.float()) ** 2).sum(1) * fa).sum() / (fa.sum().clamp(min=1) * kc)
+            loss_b = (((p - merged.float()) ** 2).sum(1) * fb).sum() / (fb.sum().clamp(min=1) * kc)
+            cos = []
+            for prm in t.parameters():
+                if not prm.requires_grad:
+                    continue
+                ga = torch.autograd.grad(loss_a, prm, retain_graph=True)[0]
+                gb = torch.autograd.grad(loss_b, prm, create_graph=True)[0]
+                cos.append(F.cosine_similarity(ga, gb, dim=1).mean() if prm.dim() > 1 else F.cosine_similarity(ga, gb, dim=0))
+            return (1.0 - torch.stack(cos)).mean()
 
     _text_prefetch = None
 
@@ -245,6 +272,65 @@ class FastRCNNOutputLayers(nn.Module):
         reg = L.box_reg_l1(ps.boxes, ps.gt_boxes, deltas, torch.where(is_fg, cls, torch.full_like(cls, -1)), self.num_classes,
                            self.box2box_transform.weights, 1.0)
         losses["loss_box_reg"] = reg / n_valid
+        return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
+
+    # ------------------------------------------------------------------ step_one / step_two losses on packed samples (sync-free)
+    def losses_packed_step(self, predictions, ps, cpred, inst_c, merge_module, branch, update_prototype=False):
+        """fast_rcnn.py:440-571 for the fixed-shape sample layout (`PackedStepSamples`: one role per row -- A, B, background,
+        filler).  The same terms as `losses(step_*)`, written with row masks and masked means instead of per-image index
+        ranges, so that no row count travels to the host.  The CKG module runs on every row (it is a per-row function) and the
+        masks select.  `ps.has_b` (host-known: the matcher produced B targets) decides whether the merge terms exist; if B
+        targets exist but none was sampled the terms evaluate to 0 (the reference omits them in that case)."""
+        assert branch in ("step_one", "step_two")
+        (scores, lta), deltas, feats = predictions
+        scores_c = cpred[0][0] if cpred is not None else None
+        kc, te = self.num_classes + 1, self.text_encoder
+        m_a, m_b, m_g = ps.role == 0, ps.role == 1, ps.role == 2
+        n_a, n_b, n_g = m_a.sum(), m_b.sum(), m_g.sum()
+        fa, fb = m_a.float(), m_b.float()
+        ag = m_a | m_g
+        losses = {"loss_text_align": lta}
+        if self.loss_type != "MILCrossEntropy":
+            raise NotImplementedError("MILFocalLoss is not on the HIP path")
+        labels = torch.where(ag, ps.gt_classes, torch.zeros_like(ps.gt_classes))
+        w = fa + m_g.float() * float(self.classes_weight[-1])
+        total = L.mil_cross_entropy(scores, labels=labels, weights=w, avg_positives=True, reduction="sum")
+        losses["loss_cls"] = total / (n_a + n_g).clamp(min=1).float()
+        oh_a = F.one_hot(labels, kc).float() * fa.unsqueeze(1)
+        if update_prototype:
+            with torch.no_grad():
+                fn = feats.detach().float()
+                fn = fn / fn.norm(dim=1, keepdim=True)
+                oh_ag = F.one_hot(labels, kc).float() * ag.float().unsqueeze(1)
+                rate = self.prototype_update_rate
+                te.per_class_feat.data = _prototype_ema(te.per_class_feat.data, fn, oh_ag, rate)
+            if ps.has_b:
+                any_b = n_b > 0
+                with torch.no_grad():
+                    zb = torch.zeros_like(ps.gt_classes_online)
+                    oh_on = oh_ag + F.one_hot(torch.where(m_b, ps.gt_classes_online, zb), kc).float() * fb.unsqueeze(1)
+                    oh_off = oh_ag + F.one_hot(torch.where(m_b, ps.gt_classes_offline, zb), kc).float() * fb.unsqueeze(1)
+                    te.prototype_b_online.data = torch.where(any_b, _prototype_ema(te.prototype_b_online.data, fn, oh_on, rate),
+                                                             te.prototype_b_online.data)
+                    te.prototype_b_offline.data = torch.where(any_b, _prototype_ema(te.prototype_b_offline.data, fn, oh_off, rate),
+                                                              te.prototype_b_offline.data)
+                merged = merge_module(fn, te.prototype_b_offline.data, te.prototype_b_online.data, ps.gt_probs_offline, ps.gt_probs_online)
+                losses["loss_merge_base"] = L.kl_div_from_probs(merged, oh_a, row_mask=m_a)
+                p_all = F.softmax(scores, dim=1)
+                losses["loss_merge_b"] = (((p_all - merged) ** 2).sum(1) * fb).sum() / (n_b.clamp(min=1).float() * kc)
+                losses["loss_merge_a"] = (((p_all - oh_a) ** 2).sum(1) * fa).sum() / (n_a.clamp(min=1).float() * kc)
+                self._merge_ctx = (self._last_input, m_a, m_b, self._last_text, oh_a, merged)
+                if branch == "step_two":
+                    keep = (merged.max(1)[0] >= self.cls_b_thresh).detach() & m_b
+                    losses["loss_cls_b"] = L.kl_div_from_logits(scores, merged.detach(), row_mask=keep)
+        if scores_c is not None:
+            losses["loss_distillation"] = L.kl_div_from_logits(scores_c, _cat([c.gt_probs for c in inst_c]))
+        neg = torch.full_like(ps.gt_classes, -1)
+        cls_on = torch.where(m_a, ps.gt_classes, torch.where(m_b, ps.gt_classes_online, torch.where(m_g, ps.gt_classes, neg)))
+        reg = L.box_reg_l1(ps.boxes, ps.gt_boxes, deltas, cls_on, self.num_classes, self.box2box_transform.weights, 1.0)
+        n_rows = (n_a + n_b + n_g).float()
+        norm = torch.where(n_g > 0, n_rows.clamp(min=1), torch.full_like(n_rows, float(self.batch_size_per_image * ps.num_images)))
+        losses["loss_box_reg"] = reg / norm
         return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
 
     # ------------------------------------------------------------------ losses (fast_rcnn.py:355-571)

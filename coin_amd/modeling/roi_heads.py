@@ -28,6 +28,20 @@ class PackedSamples:
         self.boxes, self.gt_classes, self.gt_boxes, self.gt_probs, self.per_image = boxes, gt_classes, gt_boxes, gt_probs, per_image
 
 
+class PackedStepSamples:
+    """Sampled RoIs of a sync-free step_one / step_two pass, fixed shape [N*R].  role: 0 = A (consistent), 1 = B (inconsistent),
+    2 = background, -1 = filler.  gt_classes: A -> class, background -> num_classes; gt_classes_online / _offline: B rows;
+    gt_boxes: matched teacher box (A, B) or the proposal itself; gt_probs_online / _offline [.., K+1]: A and B rows (0 elsewhere).
+    has_b: the matcher produced at least one B target in the batch (known on the host)."""
+
+    def __init__(self, boxes, role, gt_classes, gt_classes_online, gt_classes_offline, gt_boxes, gt_probs_online, gt_probs_offline,
+                 per_image, num_images, has_b):
+        self.boxes, self.role, self.gt_classes = boxes, role, gt_classes
+        self.gt_classes_online, self.gt_classes_offline, self.gt_boxes = gt_classes_online, gt_classes_offline, gt_boxes
+        self.gt_probs_online, self.gt_probs_offline = gt_probs_online, gt_probs_offline
+        self.per_image, self.num_images, self.has_b = per_image, num_images, has_b
+
+
 class ROIPooler(nn.Module):
     """Single-level detectron2 ROIPooler (ROIAlignV2 = aligned)."""
 

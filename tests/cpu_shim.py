@@ -41,12 +41,16 @@ def _mil(x, target=None, labels=None, weights=None, avg_positives=False, reducti
 def _kl_logits(scores, q, row_mask=None):
     if row_mask is not None:
         scores, q = scores[row_mask], q[row_mask]
+    if scores.shape[0] == 0:  # the kernel's masked mean over zero rows is 0
+        return scores.sum() * 0.0
     return OL.kl_div_mean(F.softmax(scores, dim=1), q)
 
 
 def _kl_probs(p, q, row_mask=None):
     if row_mask is not None:
         p, q = p[row_mask], q[row_mask]
+    if p.shape[0] == 0:
+        return p.sum() * 0.0
     return OL.kl_div_mean(p, q)
 
 

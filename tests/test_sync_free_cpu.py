@@ -117,3 +117,86 @@ def test_sync_free_detector_step_matches_counting_rules():
             m = pairwise_iou(batch[i]["RCNN"].gt_boxes, Boxes(b)).argmax(dim=0)
             assert torch.equal(c[fg], batch[i]["RCNN"].gt_classes_offline[m[fg]])
             close(ps.gt_boxes[i * 32:(i + 1) * 32][fg], batch[i]["RCNN"].gt_boxes.tensor[m[fg]], 0)
+
+
+@pytest.mark.parametrize("tag", ["one", "two", "two_nobg_noC", "two_noB", "one_noproto"])
+def test_losses_packed_step_equal_reference_losses_on_the_same_samples(tag):
+    """`losses_packed_step` (row roles + masks, no host-side row counts) == FastRCNNOutputLayers.losses(step_one / step_two) of
+    the reference on the same A / B / background rows, with filler rows interleaved; the masked `merge_grad_loss` reproduces
+    gradient_discrepancy_loss and the CKG gradients."""
+    from coin_amd.modeling.roi_heads import PackedStepSamples
+    from coin_amd.modeling.text_encoder import CKGNet
+    from e2e_util import _product_box_predictor
+
+    z = load(f"box_predictor_{tag}")
+    branch = str(z["branch"])
+    with cpu_kernels():
+        bp = _product_box_predictor()
+        load_weights(bp, z)
+        merge = CKGNet(32, 32, K + 1, head_num=4)
+        load_weights(merge, z, "m::")
+        bp.train()
+        n_img = int(z["n_img"])
+        size = (96, 128)
+        x_ref = T(z["x"])
+        rows, role, cls, con, coff, gtb, pon, poff, boxes = [], [], [], [], [], [], [], [], []
+        cursor = 0
+        zero_p = lambda n: torch.zeros(n, K + 1)
+        for i in range(n_img):
+            a, b, g = (_inst(z, f"p{i}.{t}", size) for t in ("a", "b", "bg"))
+            for inst, r in ((a, 0), (b, 1), (g, 2)):
+                n = len(inst)
+                rows.append(x_ref[cursor:cursor + n])
+                cursor += n
+                role.append(torch.full((n,), r))
+                boxes.append(inst.proposal_boxes.tensor)
+                if r == 0:
+                    cls.append(inst.gt_classes); con.append(torch.zeros(n, dtype=torch.long)); coff.append(torch.zeros(n, dtype=torch.long))
+                    gtb.append(inst.gt_boxes.tensor); pon.append(inst.gt_probs_online); poff.append(inst.gt_probs_offline)
+                elif r == 1:
+                    cls.append(torch.zeros(n, dtype=torch.long)); con.append(inst.gt_classes_online); coff.append(inst.gt_classes_offline)
+                    gtb.append(inst.gt_boxes.tensor); pon.append(inst.gt_probs_online); poff.append(inst.gt_probs_offline)
+                else:
+                    cls.append(inst.gt_classes); con.append(torch.zeros(n, dtype=torch.long)); coff.append(torch.zeros(n, dtype=torch.long))
+                    gtb.append(inst.proposal_boxes.tensor); pon.append(zero_p(n)); poff.append(zero_p(n))
+            # two filler rows after every image
+            rows.append(torch.randn(2, x_ref.shape[1])); role.append(torch.full((2,), -1)); boxes.append(torch.tensor([[1.0, 1, 20, 20]] * 2))
+            cls.append(torch.zeros(2, dtype=torch.long)); con.append(torch.zeros(2, dtype=torch.long)); coff.append(torch.zeros(2, dtype=torch.long))
+            gtb.append(torch.tensor([[1.0, 1, 20, 20]] * 2)); pon.append(zero_p(2)); poff.append(zero_p(2))
+        assert cursor == x_ref.shape[0]
+        x = torch.cat(rows).requires_grad_(True)
+        role_t = torch.cat(role)
+        has_b = bool((role_t == 1).any())
+        ps = PackedStepSamples(torch.cat(boxes), role_t, torch.cat(cls), torch.cat(con), torch.cat(coff), torch.cat(gtb), torch.cat(pon),
+                               torch.cat(poff), 0, n_img, has_b)
+        cs = [_inst(z, f"p{i}.c", size) for i in range(n_img)]
+        xc = T(z["xc"])
+        preds = bp(x, branch)
+        cpred = bp(xc, branch, return_feats=False) if xc.shape[0] else None
+        losses = bp.losses_packed_step(preds, ps, cpred, cs if xc.shape[0] else None, merge, branch, update_prototype=bool(z["update_prototype"]))
+        ref = {k[6:]: float(z[k]) for k in z.files if k.startswith("loss::")}
+        got = {k: float(v) for k, v in losses.items()}
+        if "loss_merge_a" in losses:
+            lg = bp.merge_grad_loss()
+            got["loss_merge_grad"] = float(lg)
+            (lg + losses["loss_merge_base"]).backward(inputs=list(merge.parameters()), retain_graph=True)
+            for n, p in merge.named_parameters():
+                close(p.grad, z["mg::" + n], 2e-4, n)
+        if "loss_cls_b" in got and "loss_cls_b" not in ref:  # no B row passed the threshold: the reference omits the (zero) term
+            assert got.pop("loss_cls_b") == 0.0
+        assert set(got) == set(ref), (sorted(got), sorted(ref))
+        for k, v in ref.items():
+            assert abs(got[k] - v) < 1e-4 * max(1.0, abs(v)), (tag, k, got[k], v)
+        skip = ["loss_merge_grad", "loss_merge_a", "loss_merge_b", "loss_merge_base"] + ([] if branch == "step_two" else ["loss_cls_b"])
+        sum(v for k, v in losses.items() if k not in skip).backward()
+        real = role_t >= 0
+        close(x.grad[real], z["gx"], 1e-5, "gx")
+        assert float(x.grad[~real].abs().max()) == 0.0
+        for name in ("prototype_after", "prototype_b_online_after", "prototype_b_offline_after"):
+            buf = {"prototype_after": bp.text_encoder.per_class_feat, "prototype_b_online_after": bp.text_encoder.prototype_b_online,
+                   "prototype_b_offline_after": bp.text_encoder.prototype_b_offline}[name]
+            close(buf, z[name], 1e-6, name)
+        params = dict(bp.named_parameters())
+        for k in z.files:
+            if k.startswith("g::"):
+                close(params[k[3:]].grad, z[k], 1e-4, k)
