@@ -43,6 +43,11 @@ class OpenVocabularyRCNN(nn.Module):
         if self.proposal_generator is not None:
             self.proposal_generator.sync_free = bool(flag)
 
+    def set_sync_free_step(self, flag: bool):
+        """Sync-free step_one / step_two (fixed-shape samplers, packed losses): see DualTeacherRPN.sync_free_step."""
+        if self.proposal_generator is not None:
+            self.proposal_generator.sync_free_step = bool(flag)
+
     def set_compute_dtype(self, dtype: torch.dtype):
         assert dtype in (torch.bfloat16, torch.float32)
         self.compute_dtype = dtype
@@ -57,10 +62,11 @@ class OpenVocabularyRCNN(nn.Module):
         return cls(backbone=backbone, roi_heads=roi_heads, pixel_mean=cfg.INPUT.TEACHER_OFFLINE.PIXEL_MEAN,
                    pixel_std=cfg.INPUT.TEACHER_OFFLINE.PIXEL_STD, device=cfg.MODEL.DEVICE, input_format=cfg.INPUT.FORMAT,
                    vis_period=cfg.VIS_PERIOD, proposal_generator=build_proposal_generator(cfg, backbone.output_shape()),
-                   compute_dtype=torch.bfloat16 if cfg.AMD.COMPUTE_DTYPE == "bf16" else torch.float32)._with_sync_free(cfg.AMD.SYNC_FREE)
+                   compute_dtype=torch.bfloat16 if cfg.AMD.COMPUTE_DTYPE == "bf16" else torch.float32)._with_sync_free(cfg.AMD.SYNC_FREE, cfg.AMD.SYNC_FREE_STEP)
 
-    def _with_sync_free(self, flag):
+    def _with_sync_free(self, flag, flag_step=False):
         self.set_sync_free(flag)
+        self.set_sync_free_step(flag_step)
         return self
 
     @property

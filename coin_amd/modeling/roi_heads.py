@@ -146,6 +146,17 @@ class OpenVocabularyRes5ROIHeads(nn.Module):
             bidx = torch.arange(n, device=ps.boxes.device, dtype=ps.boxes.dtype).repeat_interleave(r).unsqueeze(1)
             predictions = self.box_predictor(self._pooled(features, torch.cat([bidx, ps.boxes], dim=1), res5, attnpool, fixed_shape=True), branch=branch)
             return [], self.box_predictor.losses_packed(predictions, ps, update_prototype=update_prototype)
+        if train and branch in ("step_one", "step_two") and isinstance(proposals, PackedProposals):
+            ta, tb, tc = [t[0] for t in targets], [t[1] for t in targets], [t[2] for t in targets]
+            ps = self.sample_packed_step(proposals, ta, tb, tc)
+            n, r = len(proposals), ps.per_image
+            bidx = torch.arange(n, device=ps.boxes.device, dtype=ps.boxes.dtype).repeat_interleave(r).unsqueeze(1)
+            predictions = self.box_predictor(self._pooled(features, torch.cat([bidx, ps.boxes], dim=1), res5, attnpool, fixed_shape=True), branch=branch)
+            cpred = None
+            if sum(len(c) for c in tc) != 0:  # host integers
+                cpred = self.box_predictor(self._pooled(features, [c.gt_boxes for c in tc], res5, attnpool), branch=branch, return_feats=False)
+            return [], self.box_predictor.losses_packed_step(predictions, ps, cpred, tc if cpred is not None else None, merge_module, branch,
+                                                             update_prototype=update_prototype)
         if train:
             assert targets
             if branch == "pre_train":
@@ -224,6 +235,60 @@ class OpenVocabularyRes5ROIHeads(nn.Module):
         g4 = sel.unsqueeze(-1).expand(-1, -1, 4)
         return PackedSamples(boxes.gather(1, g4).reshape(-1, 4), out_cls.reshape(-1), gtb.gather(1, g4).reshape(-1, 4),
                              prs.gather(1, sel.unsqueeze(-1).expand(-1, -1, k + 1)).reshape(-1, k + 1), min(r, sel.shape[1]))
+
+    @torch.no_grad()
+    def sample_packed_step(self, proposals: PackedProposals, ta, tb, tc) -> PackedStepSamples:
+        """label_and_sample_proposals(step_one / step_two) (clip_roi_heads.py:341-399) with fixed shapes and no host round trip:
+        candidates = RPN proposals (+ validity) ++ A boxes ++ B boxes, the same Matcher against cat(A, B, C), candidates that match a
+        private (C) box with IoU >= thr are ignored, `sample_masks` instead of randperm.  The target counts are host integers (the
+        matcher ran on the host), only the candidates' roles are data dependent and they stay on the device."""
+        k, r = self.num_classes, self.batch_size_per_image
+        dev = proposals.boxes.device
+        extra = max(len(a) + len(b) for a, b in zip(ta, tb)) if self.proposal_append_gt else 0
+        rows = {n: [] for n in ("box", "cls", "role", "con", "coff", "gtb", "pon", "poff")}
+        for i, (a, b, c) in enumerate(zip(ta, tb, tc)):
+            la, lb, lc = len(a), len(b), len(c)
+            pb, pv = proposals.boxes[i], proposals.valid[i]
+            if self.proposal_append_gt:
+                pad = extra - la - lb
+                pb = torch.cat([pb, a.gt_boxes.tensor, b.gt_boxes.tensor, pb.new_zeros(pad, 4)])
+                pv = torch.cat([pv, torch.ones(la + lb, dtype=torch.bool, device=dev), torch.zeros(pad, dtype=torch.bool, device=dev)])
+            m = pb.shape[0]
+            if la + lb + lc > 0:
+                tboxes = Boxes.cat([a.gt_boxes, b.gt_boxes, c.gt_boxes])
+                idx, lab = self.proposal_matcher(pairwise_iou(tboxes, Boxes(pb)))
+                fg = lab == 1
+                in_a, in_b = idx < la, (idx >= la) & (idx < la + lb)
+                role = torch.where(fg & in_a, 0, torch.where(fg & in_b, 1, torch.where(fg, -1, 2)))  # fg on a C box -> ignored
+                z = lambda n, *shape: pb.new_zeros((n,) + shape)
+                zl = lambda n: torch.zeros(n, dtype=torch.int64, device=dev)
+                con_t = torch.cat([a.gt_classes, b.gt_classes_online, zl(lc)])[idx]
+                coff_t = torch.cat([a.gt_classes, b.gt_classes_offline, zl(lc)])[idx]
+                pon_t = torch.cat([a.gt_probs_online, b.gt_probs_online, z(lc, k + 1)])[idx]
+                poff_t = torch.cat([a.gt_probs_offline, b.gt_probs_offline, z(lc, k + 1)])[idx]
+                gtb = torch.where((role == 0).unsqueeze(1) | (role == 1).unsqueeze(1), tboxes.tensor[idx], pb)
+            else:
+                role = torch.full((m,), 2, dtype=torch.int64, device=dev)
+                con_t = coff_t = torch.zeros(m, dtype=torch.int64, device=dev)
+                pon_t = poff_t = pb.new_zeros(m, k + 1)
+                gtb = pb
+            role = torch.where(pv, role, torch.full_like(role, -1))
+            cls = torch.where(role == 0, con_t, torch.where(role == 1, con_t, torch.where(role == 2, torch.full_like(role, k), torch.full_like(role, -1))))
+            for n, v in (("box", pb), ("cls", cls), ("role", role), ("con", con_t), ("coff", coff_t), ("gtb", gtb), ("pon", pon_t), ("poff", poff_t)):
+                rows[n].append(v)
+        t = {n: torch.stack(v) for n, v in rows.items()}                     # [N, M, ...]
+        fg, bg = sample_masks(t["cls"], r, self.positive_fraction, k)          # positives = A or B rows (online class), negatives = bg
+        if not self.BG_TRAIN:
+            bg = torch.zeros_like(bg)
+        prio = torch.where(fg, 0, torch.where(bg, 1, 2))
+        sel = prio.argsort(dim=1, stable=True)[:, :r]
+        chosen = (fg | bg).gather(1, sel)
+        g1 = lambda x: x.gather(1, sel).reshape(-1)
+        gn = lambda x: x.gather(1, sel.unsqueeze(-1).expand(-1, -1, x.shape[-1])).reshape(-1, x.shape[-1])
+        role = torch.where(chosen, t["role"].gather(1, sel), torch.full_like(sel, -1)).reshape(-1)
+        gt_cls = torch.where(role == 2, torch.full_like(role, k), g1(t["con"]))   # A rows: their class; bg rows: num_classes
+        return PackedStepSamples(gn(t["box"]), role, gt_cls, g1(t["con"]), g1(t["coff"]), gn(t["gtb"]), gn(t["pon"]), gn(t["poff"]),
+                                 min(r, sel.shape[1]), len(ta), any(len(b) > 0 for b in tb))
 
     @torch.no_grad()
     def label_and_sample_proposals(self, proposals, targets, branch):

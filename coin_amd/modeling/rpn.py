@@ -81,6 +81,7 @@ class DualTeacherRPN(nn.Module):
         # sync-free mode (pre_train branch): anchor sampling by random keys + one sort, fixed-shape proposals; the host
         # never waits for the device inside the step.  Off = the reference's randperm stream (used by the golden tests).
         self.sync_free = False
+        self.sync_free_step = False  # the same for the step_one / step_two branches (cfg.AMD.SYNC_FREE_STEP)
         self._prefetched = None
 
     def prefetch_labels(self, feature_hw, device, gt_instances):
@@ -133,14 +134,17 @@ class DualTeacherRPN(nn.Module):
                 losses = self.losses(anchors, logits, labels, deltas, gt_boxes)
             elif branch in ("step_one", "step_two"):
                 ia, ic = [g[0] for g in gt_instances], [g[2] for g in gt_instances]
-                labels, gt_boxes, midx, dlabels = self.label_and_sample_anchors(anchors, [ia, ic], branch)
+                if self.sync_free_step:
+                    labels, gt_boxes, midx, dlabels = self.label_and_sample_anchors_step_sync_free(anchors, [ia, ic])
+                else:
+                    labels, gt_boxes, midx, dlabels = self.label_and_sample_anchors(anchors, [ia, ic], branch)
                 teacher = [c.gt_probs[:, :-1].sum(1)[m] if len(c) != 0 else torch.zeros_like(m, dtype=torch.float32)
                            for c, m in zip(ic, midx)]
                 losses = self.losses(anchors, logits, labels, deltas, gt_boxes, calc_bg=self.BG_TRAIN)
                 losses.update(self.losses(anchors, logits, dlabels, None, None, teacher_probs=teacher, only_distillation=True))
             else:
                 raise NotImplementedError
-        packed = self.sync_free and self.training and branch == "pre_train"
+        packed = self.training and ((self.sync_free and branch == "pre_train") or (self.sync_free_step and branch in ("step_one", "step_two")))
         proposals = self.predict_proposals(anchors, logits, deltas, images.image_sizes, packed=packed)
         return proposals, losses
 
@@ -216,6 +220,52 @@ class DualTeacherRPN(nn.Module):
             dist_out.append(dlab)
         return labels_out, boxes_out, midx_out, dist_out
 
+    @torch.no_grad()
+    def label_and_sample_anchors_step_sync_free(self, anchors: List[Boxes], gt_instances):
+        """step_one / step_two labelling (rpn.py:199-254) without host round trips: the same matcher and the same rules written
+        with `torch.where` (a boolean-mask assignment synchronises on the device), sampling via `sample_masks`.
+        -> (labels, matched A boxes, matched C index, distillation labels), one entry per image."""
+        a = Boxes.cat(anchors)
+        ga, gc = gt_instances
+        labs, boxes, midx, dlabs = [], [], [], []
+        for ta, tc in zip(ga, gc):
+            ba, bc = ta.gt_boxes, tc.gt_boxes
+            la, lc = len(ba), len(bc)
+            if la + lc == 0:
+                z = torch.zeros(len(a), dtype=torch.int64, device=a.tensor.device)
+                labs.append(torch.full((len(a),), -1, dtype=torch.int8, device=a.tensor.device))  # `lab[~(in_c & is_bg)] = -1` with in_c empty
+                boxes.append(torch.zeros_like(a.tensor))
+                midx.append(z)
+                dlabs.append(z.to(torch.int8))
+                continue
+            idx, lab = self.anchor_matcher(pairwise_iou(Boxes.cat([ba, bc]), a))
+            in_c = (idx >= la) & (idx < la + lc)
+            is_bg = lab == 0
+            fg_c = in_c & ~is_bg
+            didx = torch.where(fg_c, idx - la, torch.zeros_like(idx))
+            lab = torch.where(fg_c, torch.full_like(lab, -1), lab)
+            idx_a = torch.where(in_c, torch.zeros_like(idx), idx)
+            if la == 0:
+                mb = torch.zeros_like(a.tensor)
+                keep_mask = in_c & is_bg
+            else:
+                mb = ba.tensor[idx_a]
+                keep_mask = None
+            labs.append((lab, keep_mask))
+            boxes.append(mb)
+            midx.append(didx)
+            dlabs.append(fg_c.to(lab.dtype))
+        # one batched sampling call for the images that have targets
+        todo = [i for i, l in enumerate(labs) if isinstance(l, tuple)]
+        if todo:
+            stack = torch.stack([labs[i][0] for i in todo]).to(torch.int64)
+            pos, neg = sample_masks(stack, self.batch_size_per_image, self.positive_fraction, 0)
+            out = torch.where(pos, 1, torch.where(neg, 0, -1)).to(torch.int8)
+            for j, i in enumerate(todo):
+                keep_mask = labs[i][1]
+                labs[i] = out[j] if keep_mask is None else torch.where(keep_mask, out[j], torch.full_like(out[j], -1))
+        return labs, boxes, midx, dlabs
+
     # ------------------------------------------------------------------ losses
     def losses(self, anchors, logits, gt_labels, deltas, gt_boxes, teacher_probs=None, only_distillation=False, calc_bg=True):
         num_images = len(gt_labels)
@@ -235,7 +285,8 @@ class DualTeacherRPN(nn.Module):
             assert teacher_probs is not None, "distillation need teacher probs"
             valid = labels > 0
             out = {}
-            if bool(valid.any()):  # rpn.py:336-340: the term is dropped when no anchor matches a private box
+            if self.sync_free_step or bool(valid.any()):  # rpn.py:336-340: the term is dropped when no anchor matches a private box
+                # (sync-free: the masked mean over zero anchors is 0 and the term stays in the dict)
                 out["loss_rpn_distillation"] = L.kl_div_binary(lg.reshape(-1), torch.stack(teacher_probs).reshape(-1), valid.reshape(-1))
         return {k: v * self.loss_weight.get(k, 1.0) for k, v in out.items()}
 

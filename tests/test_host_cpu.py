@@ -235,8 +235,8 @@ def test_product_box_predictor_step_and_ckg_update_on_cpu(tag):
         close(g, z["g::" + k], 1e-4, k)
 
 
-@pytest.mark.parametrize("burned_up", [False, True])
-def test_cointrainer_run_step_on_cpu_with_shimmed_kernels(burned_up):
+@pytest.mark.parametrize("burned_up,sync_free_step", [(False, False), (True, False), (False, True), (True, True)])
+def test_cointrainer_run_step_on_cpu_with_shimmed_kernels(burned_up, sync_free_step):
     """Whole CoinTrainer.run_step on a tiny model: teacher EMA + inference, A/B/C matching, step_one / step_two forward with the
     CKG module, CKG update through merge_grad_loss, student update, schedulers."""
     from coin_amd.config import get_cfg
@@ -250,10 +250,12 @@ def test_cointrainer_run_step_on_cpu_with_shimmed_kernels(burned_up):
                          "MODEL.RPN.PRE_NMS_TOPK_TEST", 60, "MODEL.RPN.POST_NMS_TOPK_TEST", 20, "AMD.TEXT_TEMPLATES", 1, "MODEL.MERGE_DIM", 32,
                          "AMD.ARCH.LAYERS", [1, 1, 1, 1], "AMD.ARCH.WIDTH", 8, "AMD.ARCH.TEXT_WIDTH", 32, "AMD.ARCH.TEXT_LAYERS", 2,
                          "AMD.ARCH.TEXT_HEADS", 2, "AMD.ARCH.TEXT_DIM", 32, "AMD.ARCH.CONTEXT_LENGTH", 16, "AMD.ARCH.VOCAB_SIZE", 64,
-                         "CLOUD.BURN_UP_STEP", 0 if burned_up else 100, "CLOUD.PROTOTYPE_UPDATE_START", 0, "CLOUD.CLS_B_THRESH", 0.2])
+                         "CLOUD.BURN_UP_STEP", 0 if burned_up else 100, "CLOUD.PROTOTYPE_UPDATE_START", 0, "CLOUD.CLS_B_THRESH", 0.2,
+                         "AMD.SYNC_FREE_STEP", sync_free_step])
     with cpu_kernels():
         torch.manual_seed(0)
         tr = CoinTrainer(cfg)
+        assert tr.model.proposal_generator.sync_free_step == sync_free_step
         # a randomly initialised teacher detects nothing that overlaps the cloud boxes (no A boxes -> the reference's
         # loss_merge_a is a mean over zero rows); keep its forward in the loop but hand the matcher CLIPDET-like detections
         from coin_amd.data.synthetic import synthetic_offline_detections
