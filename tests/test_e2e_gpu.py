@@ -101,8 +101,8 @@ def test_box_predictor_step_and_ckg_update_fp32_vs_reference_golden(tag):
         close(g, z["g::" + k], 1e-4, k)
 
 
-@pytest.mark.parametrize("burned_up", [False, True])
-def test_cointrainer_full_size_steps(burned_up):
+@pytest.mark.parametrize("burned_up,sync_free_step", [(False, False), (True, False), (True, True)])
+def test_cointrainer_full_size_steps(burned_up, sync_free_step):
     """BASELINE configs[2] shape (Foggy-Cityscapes-shaped 667x1333 views, RN50, 512 RoIs, teacher inference with 1000 RoIs):
     CoinTrainer steps run in bf16 on the HIP kernels; losses finite; the CKG module, the student and (after burn-up) the EMA
     teacher move."""
@@ -117,7 +117,8 @@ def test_cointrainer_full_size_steps(burned_up):
     cfg = get_cfg()
     cfg.merge_from_file(os.path.join(root, "configs", "coin", "GDINO", "foggy_synthetic.yaml"))
     cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", 2, "AMD.SYNTHETIC.NUM_IMAGES", 2, "AMD.TEXT_TEMPLATES", 2, "MODEL.DEVICE", "cuda:0",
-                         "CLOUD.BURN_UP_STEP", 0 if burned_up else 100, "CLOUD.PROTOTYPE_UPDATE_START", 0, "CLOUD.CLS_B_THRESH", 0.2])
+                         "CLOUD.BURN_UP_STEP", 0 if burned_up else 100, "CLOUD.PROTOTYPE_UPDATE_START", 0, "CLOUD.CLS_B_THRESH", 0.2,
+                         "AMD.SYNC_FREE_STEP", sync_free_step])
     torch.manual_seed(11)
     tr = CoinTrainer(cfg)
     real_forward, g_det = tr.offline_teacher.forward, torch.Generator().manual_seed(7)

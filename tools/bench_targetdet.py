@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--images", type=int, default=2)
     ap.add_argument("--step-two", action="store_true")
+    ap.add_argument("--sync-free-step", action="store_true", help="cfg.AMD.SYNC_FREE_STEP: fixed-shape samplers + packed losses in the step branches")
     args = ap.parse_args()
     import torch
 
@@ -32,7 +33,8 @@ def main():
     cfg = get_cfg()
     cfg.merge_from_file(os.path.join(ROOT, "configs", "coin", "GDINO", "foggy_synthetic.yaml"))
     cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", args.images, "AMD.SYNTHETIC.NUM_IMAGES", args.images, "AMD.TEXT_TEMPLATES", 4,
-                         "MODEL.DEVICE", "cuda:0", "CLOUD.BURN_UP_STEP", 0 if args.step_two else 10 ** 9, "CLOUD.PROTOTYPE_UPDATE_START", 0])
+                         "MODEL.DEVICE", "cuda:0", "CLOUD.BURN_UP_STEP", 0 if args.step_two else 10 ** 9, "CLOUD.PROTOTYPE_UPDATE_START", 0,
+                         "AMD.SYNC_FREE_STEP", args.sync_free_step])
     torch.manual_seed(cfg.SEED)
     tr = CoinTrainer(cfg)
     real_forward, g = tr.offline_teacher.forward, torch.Generator().manual_seed(7)
@@ -50,7 +52,7 @@ def main():
         rec = tr.run_step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    print(json.dumps({"workload": "targetDET " + ("step_two" if args.step_two else "step_one"), "images_per_step": args.images, "ms_per_step": dt * 1e3,
+    print(json.dumps({"workload": "targetDET " + ("step_two" if args.step_two else "step_one") + (" sync-free" if args.sync_free_step else ""), "images_per_step": args.images, "ms_per_step": dt * 1e3,
                       "student_views_per_s": args.images / dt, "losses": {k: round(float(v), 4) for k, v in rec.items()}}))
 
 
