@@ -943,10 +943,116 @@ def case_match_dual_teacher():
                 out_all[key + "::n"] = np.array([len(a), -1 if b is None else len(b), len(c)])
     npz("match_dual_teacher", **out_all)
 
+def case_e2e_coin_step():
+    """One whole target-detector iteration (coin/engine/trainer.py:160-218) scripted line by line with the reference's own pieces:
+    teacher inference -> CoinTrainer.match_boxes -> student step_two forward with the CKG module -> gradient_discrepancy_loss +
+    CKG optimizer step -> student loss + optimizer step.  (The trainer class itself needs the whole detectron2 training stack.)"""
+    import random
+    tr = import_ref_trainer()
+    base = shim.ref("coin.engine.base")
+    Lref = shim.ref("coin.utils.losses")
+    sb = shim.ref("coin.solver.build")
+    student, teacher, merge = build_detector(seed=151), build_detector(seed=152), build_ckg(153)
+    with torch.no_grad():
+        teacher.roi_heads.box_predictor.cls_score.weight.normal_(std=0.3)
+    teacher.roi_heads.box_predictor.test_score_thresh = 0.05
+    batch = make_pretrain_batch(154)
+    for i, b in enumerate(batch):
+        b["image_id"], b["random_flip"] = f"id{i}", "no"
+        del b["RCNN"], b["RPN"]
+    before = {k: v.clone() for k, v in sd_arrays(student, "s::").items()}
+    before.update({k: v.clone() for k, v in sd_arrays(teacher, "t::").items()})
+    before.update({k: v.clone() for k, v in sd_arrays(merge, "m::").items()})
+    # 1. teacher inference on the weak views (trainer.py:174-178)
+    teacher.eval()
+    with torch.no_grad():
+        offline = teacher([{k: v for k, v in b.items() if k in ("image", "height", "width")} for b in batch], branch="test")
+    teacher.train()
+    # cached cloud-detector results derived from the teacher's detections so that A, B and both kinds of C are populated
+    g = torch.Generator().manual_seed(156)
+    cloud = {}
+    for b, o in zip(batch, offline):
+        det = o["instances"]
+        n = min(6, len(det))
+        boxes = det.pred_boxes.tensor[:n] + 1.5 * torch.randn(n, 4, generator=g)
+        probs = det.probs[:n].clone()
+        for j in range(n):
+            if j % 3 == 1:  # a different label than the teacher's -> B
+                probs[j, :K] = probs[j, :K].roll(1)
+        extra = rand_boxes(2, b["height"], b["width"], g)
+        pe = rand_probs(2, g)
+        boxes, probs = torch.cat([boxes, extra]), torch.cat([probs, pe])
+
+        def inst():
+            r = d2.Instances((b["height"], b["width"]))
+            r.pred_boxes = d2.Boxes(boxes.clone())
+            r.scores = probs[:, :-1].max(1).values
+            r.pred_classes = probs[:, :-1].argmax(1)
+            r.probs = probs.clone()
+            return r
+
+        cloud[b["file_name"]] = {"file_name": b["file_name"], "image_id": b["image_id"], "height": b["height"], "width": b["width"],
+                                 "RCNN": {"instances": inst()}, "RPN": {"instances": inst()}}
+    stub = type("Stub", (), {})()
+    stub.cfg = type("Cfg", (), {})()
+    stub.cfg.CLOUD = type("Cloud", (), {})()
+    stub.cfg.CLOUD.MATCHER = type("Matcher", (), {"IOU_THRESHOLDS": 0.5})()
+    stub.WEIGHT_FOR_BOX_A = 0.5
+    stub.model_CLOUD = lambda fn: copy.deepcopy(cloud[fn])
+    stub.process = lambda *a, **k: base.BASE_Trainer.process(stub, *a, **k)
+    stub.preprocess_results = lambda *a, **k: base.BASE_Trainer.preprocess_results(stub, *a, **k)
+    stub.merge_boxes = lambda *a: tr.CoinTrainer.merge_boxes(stub, *a)
+    stub.match_dual_teacher = lambda *a: tr.CoinTrainer.match_dual_teacher(stub, *a)
+    random.seed(77)
+    rcnn, rpn = tr.CoinTrainer.match_boxes(stub, batch, copy.deepcopy(offline))
+    # 2. student step (trainer.py:184-205) with plain SGD over the reference's parameter groups
+    overrides = [{"backbone.encoder.visual": 0.1, "backbone.encoder.visual.layer4": 0.1, "embedding_tmp": 1.0, "add_in_embedding": 1.0, "logit_scale": 0.0}]
+    groups = lambda m, ov: sb.get_default_optimizer_params(m, base_lr=0.01, weight_decay_norm=0.0, bias_lr_factor=1.0, weight_decay_bias=1e-4,
+                                                            overrides=ov, only_text_encoder=None)
+    opt_s = torch.optim.SGD(groups(student, overrides), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    opt_m = torch.optim.SGD(groups(merge, overrides), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    rec = _capture_sampling(student)
+    torch.manual_seed(155)
+    record = student(copy.deepcopy(batch), merge, (rcnn, rpn), branch="step_two", update_prototype=True)
+    opt_s.zero_grad()
+    opt_m.zero_grad()
+    assert "loss_merge_a" in record, sorted(record)
+    record["loss_merge_grad"] = Lref.gradient_discrepancy_loss(student, 1e4 * record["loss_merge_a"], 1e4 * record["loss_merge_b"])
+    (record["loss_merge_grad"] + record["loss_merge_base"]).backward(retain_graph=True)
+    opt_m.step()
+    opt_s.zero_grad()
+    opt_m.zero_grad()
+    skip = ["loss_merge_grad", "loss_merge_a", "loss_merge_b", "loss_merge_base"]
+    sum(v for k, v in record.items() if k not in skip).backward()
+    opt_s.step()
+    out = dict(**before, **{"loss::" + k: v for k, v in record.items()})
+    for i, (b, o) in enumerate(zip(batch, offline)):
+        out[f"img{i}"] = b["image"]
+        out.update(instances_arrays(f"det{i}", o["instances"]))
+        out.update(instances_arrays(f"cloud{i}", cloud[b["file_name"]]["RCNN"]["instances"]))
+        for name, t in (("a", rcnn[i][0]), ("b", rcnn[i][1]), ("c", rcnn[i][2]), ("rpn_a", rpn[i][0]), ("rpn_c", rpn[i][2])):
+            out.update(instances_arrays(f"{name}{i}", t))
+    for i, (a, b_, bg) in enumerate(rec["sampled"]):
+        out.update(instances_arrays(f"s{i}.a", a))
+        out.update(instances_arrays(f"s{i}.b", b_))
+        out.update(instances_arrays(f"s{i}.bg", bg))
+    lab, mb, idx, dl = rec["anchor_labels"]
+    out.update(anchor_labels=torch.stack(lab), anchor_matched_boxes=torch.stack(mb), anchor_matched_idxs=torch.stack(idx),
+               anchor_dist_labels=torch.stack(dl))
+    out.update({"m_after::" + k: v for k, v in merge.state_dict().items()})
+    names = ["roi_heads.box_predictor.trans.0.weight", "roi_heads.box_predictor.cls_score.weight", "roi_heads.box_predictor.bbox_pred.bias",
+             "backbone.encoder.visual.layer3.0.conv1.weight", "backbone.encoder.visual.layer4.1.bn2.weight",
+             "proposal_generator.rpn_head.conv.weight", "roi_heads.box_predictor.text_encoder.encoder.embedding_tmp"]
+    sd = student.state_dict()
+    out.update({"s_after::" + k: sd[k] for k in names})
+    out["n_abc"] = np.array([[len(t[0]), len(t[1]), len(t[2])] for t in rcnn])
+    npz("e2e_coin_step", **out)
+
+
 
 CASES = [case_mil_losses, case_bottleneck, case_resnet, case_box_predictor_pretrain, case_box_predictor_step,
          case_text_encoder, case_ckg, case_lr_and_fusion, case_optimizer_groups, case_rpn, case_roi_sampling,
-         case_e2e_pretrain, case_e2e_step_and_inference, case_ema, case_match_dual_teacher]
+         case_e2e_pretrain, case_e2e_step_and_inference, case_ema, case_match_dual_teacher, case_e2e_coin_step]
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])

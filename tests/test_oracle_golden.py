@@ -471,3 +471,92 @@ def test_match_dual_teacher_vs_reference(case):
                     v = inst.get(f)
                     v = v.tensor if isinstance(v, d2.Boxes) else v
                     np.testing.assert_allclose(v.numpy(), ref, rtol=1e-6, atol=1e-6, err_msg=f"{key} {name}.{f}")
+
+
+# ------------------------------------------------------------------------------------------ CoinTrainer: one whole iteration
+COIN_OVERRIDES = {"backbone.encoder.visual": 0.1, "backbone.encoder.visual.layer4": 0.1, "embedding_tmp": 1.0, "add_in_embedding": 1.0, "logit_scale": 0.0}
+
+
+def _coin_step_inputs(z):
+    from oracle import trainer as OT
+
+    batch, offline, cloud = [], [], {}
+    for i in range(2):
+        img = T(z[f"img{i}"])
+        h, w = img.shape[1], img.shape[2]
+        name = f"img{i}.png"
+        batch.append({"image": img, "height": h, "width": w, "file_name": name, "image_id": f"id{i}", "random_flip": "no"})
+        offline.append({"instances": instances(z, f"det{i}", (h, w))})
+        src = instances(z, f"cloud{i}", (h, w))
+        mk = lambda: d2.Instances((h, w), **{k: (d2.Boxes(v.tensor.clone()) if isinstance(v, d2.Boxes) else v.clone()) for k, v in src.get_fields().items()})
+        cloud[name] = {"file_name": name, "image_id": f"id{i}", "height": h, "width": w, "RCNN": {"instances": mk()}, "RPN": {"instances": mk()}}
+    import copy
+
+    return batch, offline, (lambda fn: copy.deepcopy(cloud[fn]))
+
+
+def test_e2e_coin_step_teacher_matching_ckg_and_student_updates():
+    """One CoinTrainer iteration scripted with the reference's own pieces (gen_golden.py:case_e2e_coin_step; trainer.py:160-218):
+    teacher inference -> match_boxes -> step_two forward with the CKG module -> CKG optimizer step through
+    gradient_discrepancy_loss -> student optimizer step.  The oracle reproduces every stage."""
+    import random
+
+    from oracle import trainer as OT
+
+    z = load("e2e_coin_step")
+    batch, offline, cloud = _coin_step_inputs(z)
+    # 1. teacher inference
+    teacher = tiny_detector()
+    load_weights(teacher, z, "t::")
+    teacher.eval()
+    teacher.roi_heads.box_predictor.test_score_thresh = 0.05
+    with torch.no_grad():
+        res = teacher([{k: b[k] for k in ("image", "height", "width")} for b in batch], branch="test")
+    for i, r in enumerate(res):
+        got, ref = r["instances"], offline[i]["instances"]
+        assert len(got) == len(ref)
+        close(torch.sort(got.scores, descending=True).values, torch.sort(ref.scores, descending=True).values, 1e-5, "teacher scores")
+    # 2. matching (on the stored detections, so that a tie in the detection order cannot leak into the comparison)
+    random.seed(77)
+    rcnn, rpn = OT.match_boxes(batch, offline, cloud, 0.5, 0.5)
+    assert [[len(t[0]), len(t[1]), len(t[2])] for t in rcnn] == z["n_abc"].tolist()
+    for i in range(2):
+        for name, inst in (("a", rcnn[i][0]), ("b", rcnn[i][1]), ("c", rcnn[i][2]), ("rpn_a", rpn[i][0]), ("rpn_c", rpn[i][2])):
+            for k, v in inst.get_fields().items():
+                v = v.tensor if isinstance(v, d2.Boxes) else v
+                close(v, z[f"{name}{i}.{k}"], 1e-6, f"{name}{i}.{k}")
+    # 3. student step_two forward with the CKG module (the oracle draws the reference's randperm stream)
+    student = tiny_detector()
+    load_weights(student, z, "s::")
+    student.train()
+    merge = OC.CKGNet(32, 32, K + 1, head_num=4)
+    load_weights(merge, z, "m::")
+    opt_s = torch.optim.SGD(OC.optimizer_param_groups(student, 0.01, COIN_OVERRIDES, weight_decay_norm=0.0, weight_decay_bias=1e-4), lr=0.01,
+                            momentum=0.9, weight_decay=1e-4)
+    opt_m = torch.optim.SGD(OC.optimizer_param_groups(merge, 0.01, COIN_OVERRIDES, weight_decay_norm=0.0, weight_decay_bias=1e-4), lr=0.01,
+                            momentum=0.9, weight_decay=1e-4)
+    torch.manual_seed(155)
+    record = student([{k: b[k] for k in ("image", "height", "width")} for b in batch], merge, (rcnn, rpn), branch="step_two", update_prototype=True)
+    ref = {k[6:]: float(z[k]) for k in z.files if k.startswith("loss::")}
+    assert set(record) | {"loss_merge_grad"} == set(ref)
+    for k, v in record.items():
+        assert abs(float(v) - ref[k]) < 1e-4 * max(1.0, abs(ref[k])), (k, float(v), ref[k])
+    # 4. CKG update, then student update (trainer.py:189-207)
+    opt_s.zero_grad()
+    opt_m.zero_grad()
+    lg = OC.gradient_discrepancy_loss(student.roi_heads.box_predictor, 1e4 * record["loss_merge_a"], 1e4 * record["loss_merge_b"])
+    assert abs(float(lg) - ref["loss_merge_grad"]) < 1e-4
+    (lg + record["loss_merge_base"]).backward(retain_graph=True)
+    opt_m.step()
+    opt_s.zero_grad()
+    opt_m.zero_grad()
+    skip = ["loss_merge_grad", "loss_merge_a", "loss_merge_b", "loss_merge_base"]
+    sum(v for k, v in record.items() if k not in skip).backward()
+    opt_s.step()
+    for k, v in merge.state_dict().items():
+        close(v, z["m_after::" + k], 1e-5, "merge " + k)
+    sd = student.state_dict()
+    for k in z.files:
+        if k.startswith("s_after::"):
+            close(sd[k[9:]], z[k], 1e-5, "student " + k[9:])
+            assert float((T(z[k]) - T(z["s::" + k[9:]])).abs().max()) > 0 or "logit_scale" in k, k  # the step moved it

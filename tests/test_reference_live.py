@@ -31,6 +31,7 @@ for name, arrays in captured.items():
     (["case_mil_losses"], ["mil_losses"]),
     (["case_match_dual_teacher"], ["match_dual_teacher"]),
     (["case_ckg", "case_ema"], ["ckg", "ema"]),
+    (["case_e2e_coin_step"], ["e2e_coin_step"]),
 ])
 def test_committed_fixtures_are_reproduced_by_the_reference(tmp_path, cases, files):
     golden = os.path.join(HERE, "golden")
