@@ -98,6 +98,30 @@ class PRETrainer(BASE_Trainer):
         self.iter += 1
         return record
 
+    # ------------------------------------------------------------------ files (pre_train.py:138-161, 176-177)
+    def save(self, path: str):
+        """Pre-train checkpoint in the reference's layout ({"model", "iteration", "results"}): what a CoinTrainer run takes as
+        the first half of ``MODEL.WEIGHTS`` ("pre_train_CLIP_xxx.pth+GDINO_collect.pth")."""
+        from ..checkpoint import save_file
+
+        results = self.collect_model.get_results() if hasattr(self.collect_model, "get_results") else None
+        save_file({"model": {k: v.detach().cpu() for k, v in self.model.state_dict().items()}, "iteration": self.iter - 1, "results": results}, path)
+
+    def resume_or_load(self, resume: bool = False):
+        """``MODEL.WEIGHTS`` of a PRETRAIN run is the file with the collected teacher results (pre_train.py:152-161) or, with
+        ``--resume``, a pre-train checkpoint.  Synthetic runs (no weights given) keep the generated cache."""
+        from ..checkpoint import CloudResults, detector_state_dict, load_file
+
+        if not self.cfg.MODEL.WEIGHTS:
+            return
+        blob = load_file(self.cfg.MODEL.WEIGHTS)
+        if resume:
+            self.model.load_state_dict(detector_state_dict(blob), strict=False)
+            self.iter = self.start_iter = blob.get("iteration", -1) + 1
+        if isinstance(blob, dict) and blob.get("results") is not None:
+            self.collect_model = CloudResults(blob["results"], device=self.device)
+        self._next_batch = None
+
     def train(self):
         for _ in range(self.start_iter, self.max_iter):
             rec = self.run_step()

@@ -563,3 +563,44 @@ def test_cointrainer_run_step_vs_reference_scripted_iteration():
         if k.startswith("s_after::"):
             close(sd[k[9:]], z[k], 1e-5, "student " + k[9:])
     assert tr.iter == 1 and tr.WEIGHT_FOR_BOX_A == 0.5
+
+
+def test_pretrain_checkpoint_feeds_cointrainer(tmp_path):
+    """The reference's workflow across the two trainers: PRETrainer writes {"model", "iteration", "results"}; a CoinTrainer started with
+    MODEL.WEIGHTS "pre_train.pth+GDINO_collect.pth" takes the detector as its offline teacher and the cached cloud results."""
+    from coin_amd.checkpoint import load_file
+    from coin_amd.config import get_cfg
+    from coin_amd.engine import CoinTrainer, PRETrainer
+
+    tiny = ["MODEL.DEVICE", "cpu", "AMD.COMPUTE_DTYPE", "fp32", "AMD.SYNTHETIC.HEIGHT", 96, "AMD.SYNTHETIC.WIDTH", 128, "AMD.SYNTHETIC.BOXES_PER_IMAGE", 4,
+            "AMD.SYNTHETIC.NUM_IMAGES", 1, "SOLVER.IMG_PER_BATCH_UNLABEL", 1, "AMD.TEXT_TEMPLATES", 1, "MODEL.MERGE_DIM", 32,
+            "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 16, "MODEL.RPN.PRE_NMS_TOPK_TRAIN", 100, "MODEL.RPN.POST_NMS_TOPK_TRAIN", 30,
+            "AMD.ARCH.LAYERS", [1, 1, 1, 1], "AMD.ARCH.WIDTH", 8, "AMD.ARCH.TEXT_WIDTH", 32, "AMD.ARCH.TEXT_LAYERS", 2, "AMD.ARCH.TEXT_HEADS", 2,
+            "AMD.ARCH.TEXT_DIM", 32, "AMD.ARCH.CONTEXT_LENGTH", 16, "AMD.ARCH.VOCAB_SIZE", 64]
+    root = os.path.join(os.path.dirname(GOLDEN), "..", "configs", "coin")
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(root, "PRETRAINS", "CLIPDET_synthetic.yaml"))
+    cfg.merge_from_list(tiny)
+    with cpu_kernels():
+        torch.manual_seed(0)
+        pre = PRETrainer(cfg)
+        pre.run_step()
+        ck = str(tmp_path / "pre_train_CLIP_0000000.pth")
+        pre.save(ck)
+        blob = load_file(ck)
+        assert blob["iteration"] == 0 and set(blob["model"]) == set(pre.model.state_dict())
+        # the synthetic cache is flat (file name -> result); the reference nests it per dataset
+        results = str(tmp_path / "GDINO_collect.pth")
+        from coin_amd.checkpoint import CloudResults
+
+        CloudResults({"synthetic_voc_train": pre.collect_model.get_results()}).save(results)
+        cfg2 = get_cfg()
+        cfg2.merge_from_file(os.path.join(root, "GDINO", "foggy_synthetic.yaml"))
+        cfg2.merge_from_list(tiny + ["MODEL.WEIGHTS", ck + "+" + results])
+        torch.manual_seed(1)
+        coin = CoinTrainer(cfg2)
+        coin.resume_or_load()
+    for k, v in pre.model.state_dict().items():
+        assert torch.equal(v, coin.offline_teacher.state_dict()[k]), k
+    name = next(iter(pre.collect_model.get_results()))
+    assert coin.model_CLOUD(name)["RCNN"]["instances"].pred_boxes.tensor.shape[1] == 4
