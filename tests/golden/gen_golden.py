@@ -1049,10 +1049,92 @@ def case_e2e_coin_step():
     npz("e2e_coin_step", **out)
 
 
+# --------------------------------------------------------------------------- #
+# Evaluation: Pascal-VOC AP as the reference computes it (coin/evaluation/cloud_pascal_voc_evaluation.py)
+# --------------------------------------------------------------------------- #
+def _write_voc(root, gts, split="val"):
+    os.makedirs(os.path.join(root, "Annotations"), exist_ok=True)
+    os.makedirs(os.path.join(root, "ImageSets", "Main"), exist_ok=True)
+    with open(os.path.join(root, "ImageSets", "Main", split + ".txt"), "w") as f:
+        f.write("\n".join(gts.keys()) + "\n")
+    for image_id, objs in gts.items():
+        parts = ["<annotation>", f"<filename>{image_id}.png</filename>", "<size><width>300</width><height>200</height><depth>3</depth></size>"]
+        for name, box, difficult, with_flags in objs:
+            flags = f"<pose>Unspecified</pose><truncated>0</truncated><difficult>{difficult}</difficult>" if with_flags else ""
+            parts.append(f"<object><name>{name}</name>{flags}<bndbox><xmin>{box[0]}</xmin><ymin>{box[1]}</ymin><xmax>{box[2]}</xmax><ymax>{box[3]}</ymax></bndbox></object>")
+        parts.append("</annotation>")
+        with open(os.path.join(root, "Annotations", image_id + ".xml"), "w") as f:
+            f.write("".join(parts))
+
+
+def case_voc_eval():
+    import tempfile
+    classes = ["car", "person", "bus"]
+    rng = np.random.default_rng(181)
+    # detectron2 pieces the evaluator touches: metadata, PathManager, comm.gather, the base class
+    root = tempfile.mkdtemp(prefix="voc_golden_")
+    meta = type("Meta", (), {"dirname": root, "split": "val", "thing_classes": classes, "year": 2007})()
+    sys.modules["detectron2.data"].MetadataCatalog = type("MC", (), {"get": staticmethod(lambda name: meta)})
+    sys.modules["detectron2.utils.comm"].gather = lambda data, dst=0: [data]
+    sys.modules["detectron2.utils.file_io"].PathManager = type("PM", (), {"open": staticmethod(lambda p, mode="r", **k: open(p, mode)),
+                                                                           "get_local_path": staticmethod(lambda p: p)})
+    sys.modules["detectron2.evaluation"].DatasetEvaluator = object
+    ev = shim.ref("coin.evaluation.cloud_pascal_voc_evaluation")
+    gts, dets = {}, {}
+    for i in range(12):
+        image_id = f"img_{i:03d}"
+        objs = []
+        for _ in range(int(rng.integers(0, 5))):
+            x0, y0 = int(rng.integers(0, 200)), int(rng.integers(0, 120))
+            w, h = int(rng.integers(15, 90)), int(rng.integers(15, 70))
+            objs.append((classes[int(rng.integers(0, 3))], (x0, y0, x0 + w, y0 + h), int(rng.random() < 0.2), bool(rng.random() < 0.8)))
+        gts[image_id] = objs
+        rows = []
+        for name, box, _, _ in objs:  # detections near the ground truth (some with the wrong label), duplicates, and clutter
+            if rng.random() < 0.85:
+                j = rng.normal(0, 4, 4)
+                cls = classes.index(name) if rng.random() < 0.8 else int(rng.integers(0, 3))
+                rows.append((box[0] + j[0], box[1] + j[1], box[2] + j[2], box[3] + j[3], float(rng.random() * 0.6 + 0.4), cls))
+                if rng.random() < 0.3:
+                    rows.append((box[0] + j[1], box[1] + j[0], box[2] + j[3], box[3] + j[2], float(rng.random() * 0.5 + 0.2), cls))
+        for _ in range(int(rng.integers(0, 4))):
+            x0, y0 = rng.random() * 220, rng.random() * 140
+            rows.append((x0, y0, x0 + 20 + rng.random() * 60, y0 + 20 + rng.random() * 40, float(rng.random() * 0.5), int(rng.integers(0, 3))))
+        dets[image_id] = np.array(rows, dtype=np.float64).reshape(-1, 6)
+    _write_voc(root, gts)
+    out = {"classes": np.array(classes), "image_ids": np.array(list(gts.keys()))}
+    for image_id, objs in gts.items():
+        out[f"gt::{image_id}::names"] = np.array([o[0] for o in objs], dtype="<U16")
+        out[f"gt::{image_id}::boxes"] = np.array([o[1] for o in objs], dtype=np.int64).reshape(-1, 4)
+        out[f"gt::{image_id}::difficult"] = np.array([o[2] for o in objs], dtype=np.int64)
+        out[f"gt::{image_id}::with_flags"] = np.array([o[3] for o in objs], dtype=bool)
+        out[f"det::{image_id}"] = dets[image_id]
+    for year in (2007, 2012):
+        meta.year = year
+        cfg = type("Cfg", (), {"OUTPUT_DIR": root, "TEST": type("T", (), {"SAVE_DETECTION_PKLS": False})()})()
+        e = ev.Cloud_PascalVOCDetectionEvaluator(cfg, "synthetic_voc_val")
+        e.reset()
+        for image_id, d in dets.items():
+            inst = d2.Instances((200, 300))
+            inst.pred_boxes = d2.Boxes(torch.from_numpy(d[:, :4]).float())
+            inst.scores = torch.from_numpy(d[:, 4]).float()
+            inst.pred_classes = torch.from_numpy(d[:, 5]).long()
+            e.process([{"image_id": image_id}], [{"instances": inst}])
+        res = e.evaluate()["bbox"]
+        out[f"res{year}::keys"] = np.array(list(res.keys()))
+        out[f"res{year}::values"] = np.array([float(v) for v in res.values()])
+    # voc_ap on hand-made curves, both metrics
+    rec = np.array([0.1, 0.2, 0.2, 0.4, 0.4, 0.7, 1.0])
+    prec = np.array([1.0, 1.0, 0.67, 0.75, 0.6, 0.55, 0.3])
+    out["ap_curve_rec"], out["ap_curve_prec"] = rec, prec
+    out["ap_curve"] = np.array([ev.voc_ap(rec, prec, True), ev.voc_ap(rec, prec, False)])
+    npz("voc_eval", **out)
+
+
 
 CASES = [case_mil_losses, case_bottleneck, case_resnet, case_box_predictor_pretrain, case_box_predictor_step,
          case_text_encoder, case_ckg, case_lr_and_fusion, case_optimizer_groups, case_rpn, case_roi_sampling,
-         case_e2e_pretrain, case_e2e_step_and_inference, case_ema, case_match_dual_teacher, case_e2e_coin_step]
+         case_e2e_pretrain, case_e2e_step_and_inference, case_ema, case_match_dual_teacher, case_e2e_coin_step, case_voc_eval]
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])

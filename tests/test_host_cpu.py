@@ -604,3 +604,47 @@ def test_pretrain_checkpoint_feeds_cointrainer(tmp_path):
         assert torch.equal(v, coin.offline_teacher.state_dict()[k]), k
     name = next(iter(pre.collect_model.get_results()))
     assert coin.model_CLOUD(name)["RCNN"]["instances"].pred_boxes.tensor.shape[1] == 4
+
+
+# ------------------------------------------------------------------------------------------ evaluation
+def test_pascal_voc_evaluator_vs_reference(tmp_path):
+    """coin_amd.evaluation.PascalVOCEvaluator against the reference's Cloud_PascalVOCDetectionEvaluator (values captured by
+    gen_golden.py:case_voc_eval on a synthetic VOC tree with difficult objects, missing flags, duplicates, wrong labels, clutter,
+    images without objects): every entry of the result dict, both AP conventions, and voc_ap on a hand-made curve."""
+    from coin_amd.evaluation import PascalVOCEvaluator, voc_ap
+    from coin_amd.structures import Boxes, Instances
+
+    z = load("voc_eval")
+    classes = [str(c) for c in z["classes"]]
+    root = str(tmp_path)
+    os.makedirs(os.path.join(root, "Annotations"))
+    os.makedirs(os.path.join(root, "ImageSets", "Main"))
+    ids = [str(i) for i in z["image_ids"]]
+    with open(os.path.join(root, "ImageSets", "Main", "val.txt"), "w") as f:
+        f.write("\n".join(ids) + "\n")
+    for image_id in ids:
+        parts = ["<annotation>"]
+        for name, box, diff, flags in zip(z[f"gt::{image_id}::names"], z[f"gt::{image_id}::boxes"], z[f"gt::{image_id}::difficult"],
+                                          z[f"gt::{image_id}::with_flags"]):
+            extra = f"<pose>Unspecified</pose><truncated>0</truncated><difficult>{int(diff)}</difficult>" if flags else ""
+            parts.append(f"<object><name>{name}</name>{extra}<bndbox><xmin>{box[0]}</xmin><ymin>{box[1]}</ymin><xmax>{box[2]}</xmax>"
+                         f"<ymax>{box[3]}</ymax></bndbox></object>")
+        parts.append("</annotation>")
+        with open(os.path.join(root, "Annotations", image_id + ".xml"), "w") as f:
+            f.write("".join(parts))
+    for year in (2007, 2012):
+        ev = PascalVOCEvaluator(root, "val", classes, year=year)
+        for image_id in ids:
+            d = z[f"det::{image_id}"]
+            inst = Instances((200, 300))
+            inst.pred_boxes = Boxes(torch.from_numpy(d[:, :4]).float())
+            inst.scores = torch.from_numpy(d[:, 4]).float()
+            inst.pred_classes = torch.from_numpy(d[:, 5]).long()
+            ev.process([{"image_id": image_id}], [{"instances": inst}])
+        res = ev.evaluate()["bbox"]
+        ref = dict(zip([str(k) for k in z[f"res{year}::keys"]], z[f"res{year}::values"]))
+        assert list(res) == [str(k) for k in z[f"res{year}::keys"]]
+        for k, v in ref.items():
+            assert abs(res[k] - v) < 1e-9, (year, k, res[k], v)
+    rec, prec = z["ap_curve_rec"], z["ap_curve_prec"]
+    assert abs(voc_ap(rec, prec, True) - z["ap_curve"][0]) < 1e-12 and abs(voc_ap(rec, prec, False) - z["ap_curve"][1]) < 1e-12

@@ -32,6 +32,7 @@ for name, arrays in captured.items():
     (["case_match_dual_teacher"], ["match_dual_teacher"]),
     (["case_ckg", "case_ema"], ["ckg", "ema"]),
     (["case_e2e_coin_step"], ["e2e_coin_step"]),
+    (["case_voc_eval"], ["voc_eval"]),
 ])
 def test_committed_fixtures_are_reproduced_by_the_reference(tmp_path, cases, files):
     golden = os.path.join(HERE, "golden")
