@@ -18,10 +18,12 @@ step_two), the inference path and the optimizer parameter groups.
 from __future__ import annotations
 
 import copy
+import importlib
 import json
 import logging
 import os
 import sys
+import types
 
 import numpy as np
 import torch
@@ -1131,10 +1133,36 @@ def case_voc_eval():
     npz("voc_eval", **out)
 
 
+def case_voc_dataset():
+    """coin/data/datasets/pascal_voc.py:25-83 on a synthetic tree (an unknown class, a difficult object, an image without objects)."""
+    import tempfile
+    root = tempfile.mkdtemp(prefix="voc_ds_")
+    gts = {"a_001": [("car", (1, 1, 300, 200), 0, True), ("tram", (10, 20, 50, 60), 0, True), ("person", (33, 44, 77, 99), 1, True)],
+           "a_002": [], "b_7": [("bus", (5, 6, 7, 8), 0, False)]}
+    _write_voc(root, gts, split="train")
+    sys.modules["detectron2.utils.file_io"].PathManager = type("PM", (), {"open": staticmethod(lambda p, mode="r", **k: open(p, mode)),
+                                                                           "get_local_path": staticmethod(lambda p: p)})
+    sys.modules["detectron2.structures"].BoxMode = type("BoxMode", (), {"XYXY_ABS": 0})
+    sys.modules["detectron2.data"].DatasetCatalog = None
+    if "coin.data" in sys.modules and not hasattr(sys.modules["coin.data"], "__path__"):
+        del sys.modules["coin.data"]
+    for n, rel in (("coin.data", "coin/data"), ("coin.data.datasets", "coin/data/datasets")):
+        m = types.ModuleType(n)
+        m.__path__ = [os.path.join(shim.REFERENCE_ROOT, rel)]
+        sys.modules[n] = m
+    pv = importlib.import_module("coin.data.datasets.pascal_voc")
+    dicts = pv.load_voc_instances(root, "train", ["car", "person", "bus"], "png")
+    for d in dicts:
+        d["file_name"] = os.path.relpath(d["file_name"], root)
+    with open(os.path.join(HERE, "voc_dataset.json"), "w") as f:
+        json.dump({"gts": {k: [[n, list(b), dif, fl] for n, b, dif, fl in v] for k, v in gts.items()}, "dicts": dicts}, f, indent=0)
+    print("  wrote voc_dataset.json")
+
+
 
 CASES = [case_mil_losses, case_bottleneck, case_resnet, case_box_predictor_pretrain, case_box_predictor_step,
          case_text_encoder, case_ckg, case_lr_and_fusion, case_optimizer_groups, case_rpn, case_roi_sampling,
-         case_e2e_pretrain, case_e2e_step_and_inference, case_ema, case_match_dual_teacher, case_e2e_coin_step, case_voc_eval]
+         case_e2e_pretrain, case_e2e_step_and_inference, case_ema, case_match_dual_teacher, case_e2e_coin_step, case_voc_eval, case_voc_dataset]
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])

@@ -648,3 +648,29 @@ def test_pascal_voc_evaluator_vs_reference(tmp_path):
             assert abs(res[k] - v) < 1e-9, (year, k, res[k], v)
     rec, prec = z["ap_curve_rec"], z["ap_curve_prec"]
     assert abs(voc_ap(rec, prec, True) - z["ap_curve"][0]) < 1e-12 and abs(voc_ap(rec, prec, False) - z["ap_curve"][1]) < 1e-12
+
+
+def test_load_voc_instances_vs_reference(tmp_path):
+    """coin_amd.data.voc.load_voc_instances against coin/data/datasets/pascal_voc.py:25-83 (dataset dicts of a synthetic VOC tree)."""
+    from coin_amd.data.voc import load_voc_instances
+
+    with open(os.path.join(GOLDEN, "voc_dataset.json")) as f:
+        ref = json.load(f)
+    root = str(tmp_path)
+    os.makedirs(os.path.join(root, "Annotations"))
+    os.makedirs(os.path.join(root, "ImageSets", "Main"))
+    with open(os.path.join(root, "ImageSets", "Main", "train.txt"), "w") as f:
+        f.write("\n".join(ref["gts"].keys()) + "\n")
+    for image_id, objs in ref["gts"].items():
+        parts = ["<annotation>", "<size><width>300</width><height>200</height><depth>3</depth></size>"]
+        for name, box, diff, flags in objs:
+            extra = f"<pose>Unspecified</pose><truncated>0</truncated><difficult>{diff}</difficult>" if flags else ""
+            parts.append(f"<object><name>{name}</name>{extra}<bndbox><xmin>{box[0]}</xmin><ymin>{box[1]}</ymin><xmax>{box[2]}</xmax>"
+                         f"<ymax>{box[3]}</ymax></bndbox></object>")
+        parts.append("</annotation>")
+        with open(os.path.join(root, "Annotations", image_id + ".xml"), "w") as f:
+            f.write("".join(parts))
+    got = load_voc_instances(root, "train", ["car", "person", "bus"], "png")
+    for d in got:
+        d["file_name"] = os.path.relpath(d["file_name"], root)
+    assert got == ref["dicts"]
