@@ -220,6 +220,33 @@ class ModifiedResNet(nn.Module):
         return f(int(h)), f(int(w))
 
 
+class AttentionPool2d(nn.Module):
+    """CLIP's attention pooling (coin/modeling/utils.py:93-125): the mean token queries the HW + 1 position-embedded tokens once
+    (multi-head attention with separate q / k / v projections); same parameter names as the reference.  Used by the CLIP teacher
+    that relabels the cloud detector's boxes (clip_rcnn.py:87-132); the mean-pool detectors delete it."""
+
+    def __init__(self, spacial_dim: int, embed_dim: int, num_heads: int, output_dim: int = None):
+        super().__init__()
+        self.positional_embedding = nn.Parameter(torch.randn(spacial_dim ** 2 + 1, embed_dim) / embed_dim ** 0.5)
+        self.k_proj = nn.Linear(embed_dim, embed_dim)
+        self.q_proj = nn.Linear(embed_dim, embed_dim)
+        self.v_proj = nn.Linear(embed_dim, embed_dim)
+        self.c_proj = nn.Linear(embed_dim, output_dim or embed_dim)
+        self.num_heads = num_heads
+
+    def forward(self, x):  # [N, C, H, W] (any memory format) -> [N, output_dim]
+        n, c = x.shape[:2]
+        tok = x.flatten(2).transpose(1, 2)
+        tok = torch.cat([tok.mean(dim=1, keepdim=True), tok], dim=1) + self.positional_embedding.to(x.dtype)
+        hd = c // self.num_heads
+        split = lambda t: t.view(n, -1, self.num_heads, hd).transpose(1, 2)
+        q = split(L.linear(tok[:, :1], self.q_proj.weight, self.q_proj.bias))
+        k = split(L.linear(tok, self.k_proj.weight, self.k_proj.bias))
+        v = split(L.linear(tok, self.v_proj.weight, self.v_proj.bias))
+        att = F.scaled_dot_product_attention(q, k, v)                        # [N, heads, 1, hd]
+        return L.linear(att.transpose(1, 2).reshape(n, c), self.c_proj.weight, self.c_proj.bias)
+
+
 class _ImageEncoder(nn.Module):
     def __init__(self, visual):
         super().__init__()
@@ -234,12 +261,15 @@ class CLIP_IMAGE(nn.Module):
     size_divisibility = 0
 
     def __init__(self, type: str = "RN50", out_features=("res4",), freeze_at: int = 2, update_backbone: bool = True,
-                 layers=None, width=None):
+                 layers=None, width=None, attnpool_dim: int = None, attnpool_heads: int = None):
         super().__init__()
         l, w, _ = _ARCH.get(type, _ARCH["RN50"])
         layers, width = layers or l, width or w
         self.type = type
         self.encoder = _ImageEncoder(ModifiedResNet(layers, width, out_features, freeze_at))
+        self._width = width
+        if attnpool_dim:
+            self.add_attnpool(attnpool_dim, attnpool_heads)
         for name, p in self.encoder.visual.named_parameters():  # clip_backbone.py:56-61
             if name.endswith("bn3.weight") and name.startswith("layer"):
                 nn.init.zeros_(p)
@@ -252,12 +282,23 @@ class CLIP_IMAGE(nn.Module):
     @classmethod
     def from_config(cls, cfg):
         a = cfg.AMD.ARCH
+        from .text_encoder import text_dim_of
+
+        keep_attnpool = cfg.MODEL.ROI_HEADS.POOLING_TYPE == "attnpool"
         return cls(type=cfg.MODEL.TEACHER_OFFLINE.TYPE or "RN50", out_features=cfg.MODEL.RESNETS.OUT_FEATURES,
                    freeze_at=cfg.MODEL.BACKBONE.FREEZE_AT, update_backbone=cfg.CLOUD.UPDATE_BACKBONE,
-                   layers=tuple(a.LAYERS) or None, width=a.WIDTH or None)
+                   layers=tuple(a.LAYERS) or None, width=a.WIDTH or None, attnpool_dim=text_dim_of(cfg) if keep_attnpool else None)
 
     layer4 = property(lambda self: self.encoder.visual.layer4)
     attnpool = property(lambda self: self.encoder.attnpool)
+
+    def add_attnpool(self, output_dim: int, heads: int = None):
+        """clip_backbone.py:52,62-67 (image_resolution 224 -> 7x7 tokens); only the CLIP relabelling teacher keeps it."""
+        c = self._width * 32
+        self.encoder.attnpool = AttentionPool2d(7, c, heads or max(c // 64, 1), output_dim)
+        for lin in (self.encoder.attnpool.q_proj, self.encoder.attnpool.k_proj, self.encoder.attnpool.v_proj, self.encoder.attnpool.c_proj):
+            nn.init.normal_(lin.weight, std=c ** -0.5)
+        return self
 
     def del_attnpool(self):
         self.encoder.attnpool = None

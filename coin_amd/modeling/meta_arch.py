@@ -16,7 +16,7 @@ from .. import kernels as K
 from .._lib import COIN_NHWC
 from ..box_ops import detector_postprocess
 from ..registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY
-from ..structures import ImageList, Instances
+from ..structures import Boxes, ImageList, Instances
 from .roi_heads import build_roi_heads
 from .rpn import build_proposal_generator
 
@@ -199,6 +199,76 @@ class OpenVocabularyRCNN(nn.Module):
         out = []
         for r, inp, size in zip(results, batched_inputs, images.image_sizes):
             out.append({"instances": detector_postprocess(r, inp.get("height", size[0]), inp.get("width", size[1]))})
+        return out
+
+
+@META_ARCH_REGISTRY.register()
+class CLIP(nn.Module):
+    """The CLIP teacher of the pre-training data collection (clip_rcnn.py:40-151): every box cached from the cloud detector is
+    re-scored by CLIP (RoIAlign -> res5 -> attention pooling -> cosine to the class embeddings, background included) and the
+    boxes CLIP calls background are dropped.  `forward(batched_inputs, pre_result)` with one image, as the reference."""
+
+    def __init__(self, *, backbone, roi_heads, pixel_mean, pixel_std, device="cuda", compute_dtype=torch.float32):
+        super().__init__()
+        self.backbone, self.roi_heads, self.target_device = backbone, roi_heads, device
+        self.register_buffer("pixel_mean", torch.tensor(pixel_mean), False)
+        self.register_buffer("pixel_std", torch.tensor(pixel_std), False)
+        self._mean, self._std = [float(v) for v in pixel_mean], [float(v) for v in pixel_std]
+        self.compute_dtype = compute_dtype
+
+    @classmethod
+    def from_config(cls, cfg):
+        from .text_encoder import text_dim_of
+
+        backbone = build_backbone(cfg)
+        if backbone.attnpool is None:
+            backbone.add_attnpool(text_dim_of(cfg))
+        roi_heads = build_roi_heads(cfg, backbone.output_shape(), backgroud=True, name=cfg.MODEL.ROI_HEADS.TEACHER_OFFLINE)
+        return cls(backbone=backbone, roi_heads=roi_heads, pixel_mean=cfg.INPUT.TEACHER_OFFLINE.PIXEL_MEAN,
+                   pixel_std=cfg.INPUT.TEACHER_OFFLINE.PIXEL_STD, device=cfg.MODEL.DEVICE,
+                   compute_dtype=torch.bfloat16 if cfg.AMD.COMPUTE_DTYPE == "bf16" else torch.float32)
+
+    @property
+    def device(self):
+        return self.target_device
+
+    @torch.no_grad()
+    def forward(self, batched_inputs, pre_result):
+        assert len(batched_inputs) == 1
+        b = batched_inputs[0]
+        for k in ("file_name", "height", "width", "image_id"):
+            assert pre_result[k] == b[k]
+        img = b["image"].to(self.pixel_mean.device).contiguous()
+        batch, _ = K.normalize_pad([img], self._mean, self._std, self.backbone.size_divisibility, COIN_NHWC, self.compute_dtype)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.compute_dtype == torch.bfloat16 and img.is_cuda):
+            features = self.backbone(batch.permute(0, 3, 1, 2))
+            return self.get_clip_result(features, batched_inputs, pre_result)
+
+    def preprocess_boxes(self, boxes: Boxes, batched_inputs) -> Boxes:
+        new = Boxes(boxes.tensor.clone())
+        net_h, net_w = batched_inputs[0]["image"].shape[1:]
+        new.scale(net_w / batched_inputs[0]["width"], net_h / batched_inputs[0]["height"])
+        return new
+
+    def get_clip_result(self, image_features, batched_inputs, pre_result):
+        assert self.backbone.attnpool is not None
+        dev = self.pixel_mean.device
+        out = {k: v for k, v in pre_result.items() if not isinstance(v, dict)}
+        for tag in ("RCNN", "RPN", "RPN_AUG"):
+            if tag not in pre_result:
+                continue
+            src = pre_result[tag]["instances"]
+            if len(src) == 0:
+                out[tag] = {"instances": src}
+                continue
+            inst = Instances(src.image_size)
+            inst.pred_boxes = Boxes(src.pred_boxes.tensor.clone().to(dev))
+            prop = Instances(src.image_size)
+            prop.proposal_boxes = self.preprocess_boxes(inst.pred_boxes, batched_inputs)
+            probs = self.roi_heads(image_features, [prop], self.backbone.layer4, self.backbone.attnpool)
+            inst.scores, inst.pred_classes = probs.max(1)
+            inst.probs = probs
+            out[tag] = {"instances": inst[inst.pred_classes != probs.size(1) - 1]}  # boxes CLIP calls background are dropped
         return out
 
 

@@ -337,5 +337,35 @@ class OpenVocabularyRes5ROIHeads(nn.Module):
         return out
 
 
+@ROI_HEADS_REGISTRY.register()
+class CLIPRes5ROIHeads(nn.Module):
+    """The CLIP teacher's head (clip_roi_heads.py:19-87): boxes from outside -> RoIAlign -> res5 -> attention (or mean) pooling ->
+    softmax(exp(logit_scale) * cosine) against the fixed class embeddings.  Inference only."""
+
+    def __init__(self, *, in_features, pooler, text_encoder):
+        super().__init__()
+        self.in_features, self.pooler, self.text_encoder = in_features, pooler, text_encoder
+
+    @classmethod
+    def from_config(cls, cfg, input_shape, backgroud):
+        in_features = cfg.MODEL.ROI_HEADS.IN_FEATURES
+        assert not cfg.MODEL.KEYPOINT_ON and len(in_features) == 1
+        return cls(in_features=in_features,
+                   pooler=ROIPooler(cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION, (1.0 / input_shape[in_features[0]].stride,),
+                                    cfg.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO, cfg.MODEL.ROI_BOX_HEAD.POOLER_TYPE),
+                   text_encoder=build_text_encoder(cfg, backgroud))
+
+    def forward(self, features, proposals, res5=None, attnpool=None):
+        x = res5(self.pooler([features[f] for f in self.in_features], [p.proposal_boxes for p in proposals]))
+        region = attnpool(x) if attnpool is not None else x.mean(dim=[2, 3])
+        return self.do_classify(region.float())
+
+    def do_classify(self, image_features):
+        text = self.text_encoder(added=False).float()
+        image_features = image_features / image_features.norm(dim=1, keepdim=True)
+        text = text / text.norm(dim=1, keepdim=True)
+        return (self.text_encoder.logit_scale.exp() * image_features @ text.t()).softmax(dim=-1)
+
+
 def build_roi_heads(cfg, input_shape, backgroud=False, name=None):
     return ROI_HEADS_REGISTRY.get(name or cfg.MODEL.ROI_HEADS.NAME).from_config(cfg, input_shape, backgroud)

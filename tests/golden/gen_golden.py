@@ -1159,10 +1159,83 @@ def case_voc_dataset():
     print("  wrote voc_dataset.json")
 
 
+def case_clip_relabel():
+    """CLIP-teacher relabelling of the cloud detector's boxes (pre-training data collection): AttentionPool2d (utils.py:93-125),
+    CLIPRes5ROIHeads (clip_roi_heads.py:19-87) and CLIP.get_clip_result / preprocess_boxes (clip_rcnn.py:87-151)."""
+    mu = shim.ref("coin.modeling.utils")
+    rh = shim.ref("coin.modeling.roi_heads.clip_roi_heads")
+    rcnn = shim.ref("coin.modeling.meta_arch.clip_rcnn")
+    torch.manual_seed(191)
+    backbone = TinyBackbone()
+    backbone.encoder.attnpool = mu.AttentionPool2d(7, WIDTH * 32, 4, TEXT_DIM)
+    with torch.no_grad():
+        for lin in (backbone.encoder.attnpool.q_proj, backbone.encoder.attnpool.k_proj, backbone.encoder.attnpool.v_proj, backbone.encoder.attnpool.c_proj):
+            lin.weight.normal_(std=(WIDTH * 32) ** -0.5)
+            lin.bias.normal_(std=0.02)
+    te = build_text_encoder()
+    with torch.no_grad():  # spread the class embeddings so that the boxes get different labels, background included
+        te.per_class_feat.copy_(F.normalize(torch.randn(K + 1, TEXT_DIM), dim=1))
+        te.encoder.logit_scale.fill_(float(np.log(100.0)))
+    heads = rh.CLIPRes5ROIHeads(in_features=["res4"], pooler=d2.ROIPooler(output_size=14, scales=(1.0 / 16,), sampling_ratio=0, pooler_type="ROIAlignV2"),
+                                text_encoder=te)
+    os.makedirs("/tmp/clip_labels_golden", exist_ok=True)
+    cwd = os.getcwd()
+    os.chdir("/tmp/clip_labels_golden")  # the constructor creates ./clip_labels
+    try:
+        model = rcnn.CLIP(backbone=backbone, roi_heads=heads, pixel_mean=[0.48145466, 0.4578275, 0.40821073],
+                          pixel_std=[0.26862954, 0.26130258, 0.27577711], device="cpu")
+    finally:
+        os.chdir(cwd)
+    model.eval()
+    g = torch.Generator().manual_seed(192)
+    # attention pooling alone
+    xa = torch.randn(5, WIDTH * 32, 7, 7, generator=g)
+    with torch.no_grad():
+        ya = backbone.encoder.attnpool(xa)
+    # one image stored at 2x the network input size, cloud boxes in stored-image pixels
+    img = torch.randint(0, 64, (3, 96, 128), generator=g, dtype=torch.uint8)
+    img[0, :48, :64] += 190   # four differently coloured quadrants so that boxes in different places get different features
+    img[1, :48, 64:] += 190
+    img[2, 48:, :64] += 190
+    img[:, 48:, 64:] += 120
+    h, w = 192, 256
+    boxes = torch.tensor([[8.0, 8, 100, 80], [140, 10, 250, 90], [10, 110, 120, 185], [150, 105, 250, 188], [60, 40, 200, 150],
+                          [5, 5, 60, 60], [180, 120, 255, 190]])
+    probs = rand_probs(7, g)
+
+    def inst():
+        r = d2.Instances((h, w))
+        r.pred_boxes = d2.Boxes(boxes.clone())
+        r.scores = probs[:, :-1].max(1).values
+        r.pred_classes = probs[:, :-1].argmax(1)
+        r.probs = probs.clone()
+        return r
+
+    pre = {"file_name": "x.png", "image_id": "x", "height": h, "width": w, "RCNN": {"instances": inst()}, "RPN": {"instances": inst()[:4]}}
+    out = model([{"image": img, "file_name": "x.png", "image_id": "x", "height": h, "width": w}], pre)
+    res = dict(**{k: v.clone() for k, v in sd_arrays(backbone, "bb::").items()}, **{k: v.clone() for k, v in sd_arrays(te, "te::").items()},
+               attn_x=xa, attn_y=ya, img=img, hw=np.array([h, w]), boxes=boxes, probs=probs)
+    for tag in ("RCNN", "RPN"):
+        res.update(instances_arrays("out_" + tag, out[tag]["instances"]))
+        res["n_" + tag] = np.array(len(out[tag]["instances"]))
+    # second run: the background embedding points at box 4's feature -> that box (and whatever else prefers it) is filtered out
+    with torch.no_grad():
+        feats = model.backbone(model.preprocess_image([{"image": img}]).tensor)
+        tmp = inst()
+        tmp.proposal_boxes = model.preprocess_boxes(tmp.pred_boxes, [{"image": img, "height": h, "width": w}])
+        region = backbone.encoder.attnpool(heads._shared_roi_transform([feats["res4"]], [tmp.proposal_boxes], backbone.layer4))
+        te.per_class_feat[K] = F.normalize(region[4], dim=0)
+    out2 = model([{"image": img, "file_name": "x.png", "image_id": "x", "height": h, "width": w}], pre)
+    res["bg_embedding_2"] = te.per_class_feat[K].clone()
+    res.update(instances_arrays("out2_RCNN", out2["RCNN"]["instances"]))
+    res["n2_RCNN"] = np.array(len(out2["RCNN"]["instances"]))
+    npz("clip_relabel", **res)
+
+
 
 CASES = [case_mil_losses, case_bottleneck, case_resnet, case_box_predictor_pretrain, case_box_predictor_step,
          case_text_encoder, case_ckg, case_lr_and_fusion, case_optimizer_groups, case_rpn, case_roi_sampling,
-         case_e2e_pretrain, case_e2e_step_and_inference, case_ema, case_match_dual_teacher, case_e2e_coin_step, case_voc_eval, case_voc_dataset]
+         case_e2e_pretrain, case_e2e_step_and_inference, case_ema, case_match_dual_teacher, case_e2e_coin_step, case_voc_eval, case_voc_dataset, case_clip_relabel]
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])

@@ -560,3 +560,49 @@ def test_e2e_coin_step_teacher_matching_ckg_and_student_updates():
         if k.startswith("s_after::"):
             close(sd[k[9:]], z[k], 1e-5, "student " + k[9:])
             assert float((T(z[k]) - T(z["s::" + k[9:]])).abs().max()) > 0 or "logit_scale" in k, k  # the step moved it
+
+
+# ------------------------------------------------------------------------------------------ CLIP-teacher relabelling (collection)
+def _clip_relabel_oracle(z):
+    from oracle import clip_collect as CC
+
+    bb = OC.ClipImageBackbone(layers=(1, 1, 2, 2), width=8, freeze_at=2, update_backbone=True, zero_init_bn3=False)
+    bb.encoder.attnpool = CC.AttentionPool2d(7, 8 * 32, 4, 32)
+    load_weights(bb, z, "bb::")
+    bb.eval()
+    return CC, bb
+
+
+def test_clip_relabel_attention_pool_and_filtering():
+    """utils.py:93-125 + clip_roi_heads.py:19-87 + clip_rcnn.py:87-151 on the reference's outputs: attention pooling alone, the
+    relabelled boxes (classes, scores, full probabilities) and the background filter."""
+    z = load("clip_relabel")
+    CC, bb = _clip_relabel_oracle(z)
+    with torch.no_grad():
+        close(bb.encoder.attnpool(T(z["attn_x"])), z["attn_y"], 1e-5, "attnpool")
+    h, w = (int(v) for v in z["hw"])
+    probs = T(z["probs"])
+
+    def inst(n=None):
+        r = d2.Instances((h, w))
+        r.pred_boxes = d2.Boxes(T(z["boxes"]))
+        r.scores, r.pred_classes, r.probs = probs[:, :-1].max(1).values, probs[:, :-1].argmax(1), probs
+        return r if n is None else r[:n]
+
+    pre = {"file_name": "x.png", "image_id": "x", "height": h, "width": w, "RCNN": {"instances": inst()}, "RPN": {"instances": inst(4)}}
+    text = T(z["te::per_class_feat"])
+    ls = T(z["te::encoder.logit_scale"])
+    mean, std = [0.48145466, 0.4578275, 0.40821073], [0.26862954, 0.26130258, 0.27577711]
+    binp = {"image": T(z["img"]), "height": h, "width": w, "file_name": "x.png", "image_id": "x"}
+    out = CC.clip_relabel(bb, bb.encoder.attnpool, text, ls, mean, std, binp, pre)
+    for tag in ("RCNN", "RPN"):
+        got = out[tag]["instances"]
+        assert len(got) == int(z["n_" + tag])
+        assert torch.equal(got.pred_classes, T(z[f"out_{tag}.pred_classes"]).long())
+        close(got.probs, z[f"out_{tag}.probs"], 1e-4, tag + " probs")
+        close(got.scores, z[f"out_{tag}.scores"], 1e-4, tag + " scores")
+        close(got.pred_boxes.tensor, z[f"out_{tag}.pred_boxes"], 0, tag + " boxes")  # stored-image coordinates are kept
+    text2 = text.clone()
+    text2[-1] = T(z["bg_embedding_2"])
+    out2 = CC.clip_relabel(bb, bb.encoder.attnpool, text2, ls, mean, std, binp, pre)
+    assert len(out2["RCNN"]["instances"]) == int(z["n2_RCNN"])

@@ -33,6 +33,7 @@ for name, arrays in captured.items():
     (["case_ckg", "case_ema"], ["ckg", "ema"]),
     (["case_e2e_coin_step"], ["e2e_coin_step"]),
     (["case_voc_eval"], ["voc_eval"]),
+    (["case_clip_relabel"], ["clip_relabel"]),
 ])
 def test_committed_fixtures_are_reproduced_by_the_reference(tmp_path, cases, files):
     golden = os.path.join(HERE, "golden")
