@@ -743,3 +743,42 @@ def test_clip_teacher_builds_from_config():
     assert isinstance(clip.backbone.attnpool, AttentionPool2d) and clip.backbone.attnpool.c_proj.out_features == 32
     assert {"backbone.encoder.attnpool.positional_embedding", "backbone.encoder.attnpool.q_proj.weight"} <= set(clip.state_dict())
     assert type(clip.roi_heads).__name__ == cfg.MODEL.ROI_HEADS.TEACHER_OFFLINE
+
+
+def test_collect_clip_results_then_pretrain_on_them():
+    """pre_train.py:148-161: cloud cache -> CLIP relabelling of every training image -> the relabelled cache drives PRETrainer."""
+    from coin_amd.config import get_cfg
+    from coin_amd.engine import PRETrainer
+    from coin_amd.engine.collect import collect_clip_results
+    from coin_amd.registry import META_ARCH_REGISTRY
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(os.path.dirname(GOLDEN), "..", "configs", "coin", "PRETRAINS", "CLIPDET_synthetic.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu", "AMD.COMPUTE_DTYPE", "fp32", "AMD.SYNTHETIC.HEIGHT", 96, "AMD.SYNTHETIC.WIDTH", 128,
+                         "AMD.SYNTHETIC.BOXES_PER_IMAGE", 5, "SOLVER.IMG_PER_BATCH_UNLABEL", 1, "AMD.SYNTHETIC.NUM_IMAGES", 2,
+                         "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 16, "MODEL.RPN.PRE_NMS_TOPK_TRAIN", 100, "MODEL.RPN.POST_NMS_TOPK_TRAIN", 30,
+                         "AMD.TEXT_TEMPLATES", 1, "AMD.ARCH.LAYERS", [1, 1, 1, 1], "AMD.ARCH.WIDTH", 8, "AMD.ARCH.TEXT_WIDTH", 32,
+                         "AMD.ARCH.TEXT_LAYERS", 2, "AMD.ARCH.TEXT_HEADS", 2, "AMD.ARCH.TEXT_DIM", 32, "AMD.ARCH.CONTEXT_LENGTH", 16,
+                         "AMD.ARCH.VOCAB_SIZE", 64])
+    with cpu_kernels():
+        torch.manual_seed(0)
+        tr = PRETrainer(cfg)
+        clip = META_ARCH_REGISTRY.get(cfg.MODEL.TEACHER_OFFLINE.META_ARCHITECTURE).from_config(cfg)
+        items = []
+        for _ in range(2):
+            strong, weak = next(tr._data_loader_iter)
+            items += [{k: v for k, v in d.items() if k in ("image", "file_name", "image_id", "height", "width")} for d in weak]
+        cloud = tr.collect_model
+        relabelled = collect_clip_results(clip, items, cloud, dataset_name="synthetic_voc_train")
+        names = {d["file_name"] for d in items}
+        assert set(relabelled.get_results()["synthetic_voc_train"]) == names
+        for n in names:
+            got, src = relabelled(n), cloud(n)
+            inst = got["RCNN"]["instances"]
+            assert len(inst) <= len(src["RCNN"]["instances"]) and inst.probs.shape[1] == len(cfg.AMD.CLASS_NAMES) + 1
+            assert bool((inst.pred_classes < len(cfg.AMD.CLASS_NAMES)).all())          # background-labelled boxes were dropped
+            assert torch.allclose(inst.probs.sum(1), torch.ones(len(inst)), atol=1e-5)
+        tr.collect_model = relabelled                                                  # and training runs on the relabelled cache
+        tr._next_batch = None
+        rec = tr.run_step()
+        assert all(torch.isfinite(v) for v in rec.values())
