@@ -56,6 +56,22 @@ class BASE_Trainer:
         results.pop("RPN_AUG", None)
         return results
 
+    # ---- evaluation (base.py:176-204 -> detectron2 inference_on_dataset)
+    @staticmethod
+    @torch.no_grad()
+    def test(model, items, evaluator, batch_size: int = 1) -> Dict:
+        """Run `model` in inference mode over `items` (dicts with image / height / width / image_id) and hand inputs + outputs to
+        `evaluator` (reset / process / evaluate, e.g. coin_amd.evaluation.PascalVOCEvaluator).  -> evaluator.evaluate()."""
+        was_training = model.training
+        model.eval()
+        evaluator.reset()
+        items = list(items)
+        for i in range(0, len(items), batch_size):
+            batch = items[i:i + batch_size]
+            evaluator.process(batch, model(batch, branch="test"))
+        model.train(was_training)
+        return evaluator.evaluate()
+
     # ---- metrics without a per-step host sync
     def _write_metrics(self, metrics_dict: Dict[str, torch.Tensor], iteration: int) -> Optional[Dict[str, float]]:
         self._last_metrics = metrics_dict

@@ -782,3 +782,44 @@ def test_collect_clip_results_then_pretrain_on_them():
         tr._next_batch = None
         rec = tr.run_step()
         assert all(torch.isfinite(v) for v in rec.values())
+
+
+def test_trainer_test_loop_with_voc_evaluator(tmp_path):
+    """BASE_Trainer.test: the detector's inference path feeds the Pascal-VOC evaluator (golden inference weights; the ground truth is
+    written from the best detection of each class per image, so every class that fires is found: recall reaches 1 and AP50 is
+    well above chance; lower-ranked detections of the other image in between keep it below 100)."""
+    from coin_amd.engine import BASE_Trainer
+    from coin_amd.evaluation import PascalVOCEvaluator
+
+    z = load("inference")
+    classes = ["car", "person", "bus"]
+    with cpu_kernels():
+        model = tiny_product_detector()
+        load_weights(model, z)
+        model.train()
+        items = [{"image": T(z[f"img{i}"]), "height": int(z[f"hw{i}"][0]), "width": int(z[f"hw{i}"][1]), "image_id": f"im{i}"} for i in range(2)]
+        model.eval()
+        dets = model(items, branch="test")
+        model.train()
+        root = str(tmp_path)
+        os.makedirs(os.path.join(root, "Annotations"))
+        os.makedirs(os.path.join(root, "ImageSets", "Main"))
+        with open(os.path.join(root, "ImageSets", "Main", "val.txt"), "w") as f:
+            f.write("im0\nim1\n")
+        fired = set()
+        for it, d in zip(items, dets):
+            inst = d["instances"]
+            top = {}
+            for b, s, c in zip(inst.pred_boxes.tensor.tolist(), inst.scores.tolist(), inst.pred_classes.tolist()):
+                if c not in top:  # the best detection of each class becomes the (only) ground-truth object of that class
+                    top[c] = b
+                    fired.add(c)
+            objs = "".join(f"<object><name>{classes[c]}</name><difficult>0</difficult><bndbox><xmin>{round(b[0])}</xmin><ymin>{round(b[1])}</ymin>"
+                           f"<xmax>{round(b[2])}</xmax><ymax>{round(b[3])}</ymax></bndbox></object>" for c, b in top.items())
+            with open(os.path.join(root, "Annotations", it["image_id"] + ".xml"), "w") as f:
+                f.write(f"<annotation>{objs}</annotation>")
+        res = BASE_Trainer.test(model, items, PascalVOCEvaluator(root, "val", classes, year=2012))["bbox"]
+    assert model.training and fired
+    assert set(res) == {"AP", "AP50", "AP75"} | {"AP50-" + c for c in classes}
+    for c in fired:
+        assert res["AP50-" + classes[c]] > 40.0, res
