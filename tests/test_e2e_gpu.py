@@ -174,3 +174,55 @@ def test_inference_fp32_vs_reference_golden():
         assert (ours[:, 0] == ref[:, 0]).all()
         np.testing.assert_allclose(ours[:, 1], ref[:, 1], atol=1e-4)
         np.testing.assert_allclose(ours[:, 2:], ref[:, 2:], atol=2e-2)
+
+
+# ------------------------------------------------------------------------------------------ written at the end of round 1 without GPU time left:
+# opt-in until they have run once on the MI355X (COIN_RUN_UNVALIDATED=1 python -m pytest tests -m gpu -k unvalidated)
+_unvalidated = pytest.mark.skipif(__import__("os").environ.get("COIN_RUN_UNVALIDATED") != "1", reason="not yet run on the GPU; set COIN_RUN_UNVALIDATED=1")
+
+
+@_unvalidated
+@pytest.mark.parametrize("tag", ["one", "two", "two_nobg_noC", "two_noB", "one_noproto"])
+def test_unvalidated_losses_packed_step_fp32_vs_reference_golden(tag):
+    """GPU twin of tests/test_sync_free_cpu.py::test_losses_packed_step_equal_reference_losses_on_the_same_samples."""
+    import test_sync_free_cpu as cpu_tests
+
+    class _NoShim:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    orig, orig_T = cpu_tests.cpu_kernels, cpu_tests.T
+    cpu_tests.cpu_kernels = lambda: _NoShim()
+    torch.set_default_device("cuda")
+    cpu_tests.T = lambda a: orig_T(a).cuda()
+    try:
+        cpu_tests.test_losses_packed_step_equal_reference_losses_on_the_same_samples(tag)
+    finally:
+        torch.set_default_device("cpu")
+        cpu_tests.cpu_kernels, cpu_tests.T = orig, orig_T
+
+
+@_unvalidated
+def test_unvalidated_clip_relabel_fp32_vs_reference_golden():
+    """GPU twin of tests/test_host_cpu.py::test_product_clip_relabel_vs_reference (RoIAlign + eval-mode BN kernels + attention pooling)."""
+    import test_host_cpu as cpu_tests
+
+    class _NoShim:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    orig, orig_T = cpu_tests.cpu_kernels, cpu_tests.T
+    cpu_tests.cpu_kernels = lambda: _NoShim()
+    torch.set_default_device("cuda")
+    cpu_tests.T = lambda a: orig_T(a).cuda()
+    try:
+        cpu_tests.test_product_clip_relabel_vs_reference()
+    finally:
+        torch.set_default_device("cpu")
+        cpu_tests.cpu_kernels, cpu_tests.T = orig, orig_T
