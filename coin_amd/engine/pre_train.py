@@ -122,9 +122,24 @@ class PRETrainer(BASE_Trainer):
             self.collect_model = CloudResults(blob["results"], device=self.device)
         self._next_batch = None
 
+    def after_step(self):
+        """pre_train.py:172-175 + MyPeriodicCheckpointer: the final model as ``pre_train_CLIP_<iter>.pth``, periodic ``model_<iter>.pth``.
+        `self.iter` has already advanced past the step that just finished."""
+        done = self.iter - 1
+        if self.rank != 0 or not self.cfg.OUTPUT_DIR:
+            return
+        period = self.cfg.SOLVER.CHECKPOINT_PERIOD
+        if done == self.max_iter - 1:
+            os.makedirs(self.cfg.OUTPUT_DIR, exist_ok=True)
+            self.save(os.path.join(self.cfg.OUTPUT_DIR, "pre_train_{}_{:07d}.pth".format(self.cfg.CLOUD.PRE_TRAIN_NAME, done)))
+        elif period > 0 and (done + 1) % period == 0:
+            os.makedirs(self.cfg.OUTPUT_DIR, exist_ok=True)
+            self.save(os.path.join(self.cfg.OUTPUT_DIR, "model_{:07d}.pth".format(done)))
+
     def train(self):
         for _ in range(self.start_iter, self.max_iter):
             rec = self.run_step()
+            self.after_step()
             m = self._write_metrics(rec, self.iter)
             if m is not None and self.rank == 0:
                 print(f"iter {self.iter}: " + "  ".join(f"{k} {v:.4f}" for k, v in m.items()), flush=True)

@@ -198,9 +198,30 @@ class CoinTrainer(BASE_Trainer):
         probs = proto.new_zeros((0, proto.shape[0]))
         return self.ddp_merge(x, proto, te.prototype_b_online.data, probs, probs).sum() * 0.0
 
+    def after_step(self):
+        """trainer.py:150-157 + MyPeriodicCheckpointer: ``burn_up_<iter>.pth`` at the end of the burn-up phase, periodic
+        ``model_<iter>.pth`` (DetectionTSCheckpointer layout).  `self.iter` has already advanced past the finished step."""
+        import os
+
+        from ..checkpoint import save_cointrainer_checkpoint
+
+        done = self.iter - 1
+        if self.rank != 0 or not self.cfg.OUTPUT_DIR:
+            return
+        period = self.cfg.SOLVER.CHECKPOINT_PERIOD
+        name = None
+        if done == self.cfg.CLOUD.BURN_UP_STEP - 1:
+            name = "burn_up_{:07d}.pth".format(done)
+        elif (period > 0 and (done + 1) % period == 0) or done == self.max_iter - 1:
+            name = "model_{:07d}.pth".format(done)
+        if name:
+            os.makedirs(self.cfg.OUTPUT_DIR, exist_ok=True)
+            save_cointrainer_checkpoint(self, os.path.join(self.cfg.OUTPUT_DIR, name))
+
     def train(self):
         for _ in range(self.start_iter, self.max_iter):
             rec = self.run_step()
+            self.after_step()
             m = self._write_metrics(rec, self.iter)
             if m is not None and self.rank == 0:
                 print(f"iter {self.iter}: " + "  ".join(f"{k} {v:.4f}" for k, v in m.items()), flush=True)

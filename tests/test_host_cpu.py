@@ -823,3 +823,40 @@ def test_trainer_test_loop_with_voc_evaluator(tmp_path):
     assert set(res) == {"AP", "AP50", "AP75"} | {"AP50-" + c for c in classes}
     for c in fired:
         assert res["AP50-" + classes[c]] > 40.0, res
+
+
+def test_trainers_write_the_reference_named_checkpoints(tmp_path):
+    """train(): PRETrainer leaves pre_train_CLIP_<last>.pth (+ periodic model_<iter>.pth), CoinTrainer burn_up_<iter>.pth / model_<iter>.pth."""
+    from coin_amd.checkpoint import load_file
+    from coin_amd.config import get_cfg
+    from coin_amd.data.synthetic import synthetic_offline_detections
+    from coin_amd.engine import CoinTrainer, PRETrainer
+
+    tiny = ["MODEL.DEVICE", "cpu", "AMD.COMPUTE_DTYPE", "fp32", "AMD.SYNTHETIC.HEIGHT", 96, "AMD.SYNTHETIC.WIDTH", 128, "AMD.SYNTHETIC.BOXES_PER_IMAGE", 6,
+            "AMD.SYNTHETIC.NUM_IMAGES", 1, "SOLVER.IMG_PER_BATCH_UNLABEL", 1, "AMD.TEXT_TEMPLATES", 1, "MODEL.MERGE_DIM", 32,
+            "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 16, "MODEL.RPN.PRE_NMS_TOPK_TRAIN", 100, "MODEL.RPN.POST_NMS_TOPK_TRAIN", 30,
+            "MODEL.RPN.PRE_NMS_TOPK_TEST", 60, "MODEL.RPN.POST_NMS_TOPK_TEST", 20, "AMD.ARCH.LAYERS", [1, 1, 1, 1], "AMD.ARCH.WIDTH", 8,
+            "AMD.ARCH.TEXT_WIDTH", 32, "AMD.ARCH.TEXT_LAYERS", 2, "AMD.ARCH.TEXT_HEADS", 2, "AMD.ARCH.TEXT_DIM", 32, "AMD.ARCH.CONTEXT_LENGTH", 16,
+            "AMD.ARCH.VOCAB_SIZE", 64, "SOLVER.MAX_ITER", 3, "SOLVER.CHECKPOINT_PERIOD", 2]
+    root = os.path.join(os.path.dirname(GOLDEN), "..", "configs", "coin")
+    with cpu_kernels():
+        cfg = get_cfg()
+        cfg.merge_from_file(os.path.join(root, "PRETRAINS", "CLIPDET_synthetic.yaml"))
+        cfg.merge_from_list(tiny + ["OUTPUT_DIR", str(tmp_path / "pre")])
+        torch.manual_seed(0)
+        PRETrainer(cfg).train()
+        assert sorted(os.listdir(tmp_path / "pre")) == ["model_0000001.pth", "pre_train_CLIP_0000002.pth"]
+        assert load_file(str(tmp_path / "pre" / "pre_train_CLIP_0000002.pth"))["iteration"] == 2
+        cfg = get_cfg()
+        cfg.merge_from_file(os.path.join(root, "GDINO", "foggy_synthetic.yaml"))
+        cfg.merge_from_list(tiny + ["OUTPUT_DIR", str(tmp_path / "coin"), "CLOUD.BURN_UP_STEP", 1, "CLOUD.PROTOTYPE_UPDATE_START", 0])
+        torch.manual_seed(0)
+        tr = CoinTrainer(cfg)
+        g = torch.Generator().manual_seed(7)
+        fwd = tr.offline_teacher.forward
+        tr.offline_teacher.forward = lambda bi, branch=None, **kw: (fwd(bi, branch=branch, **kw),
+                                                                    [synthetic_offline_detections(tr.model_CLOUD.get_results()[d["file_name"]], g) for d in bi])[1]
+        tr.train()
+        assert sorted(os.listdir(tmp_path / "coin")) == ["burn_up_0000000.pth", "model_0000001.pth", "model_0000002.pth"]
+        blob = load_file(str(tmp_path / "coin" / "model_0000002.pth"))
+        assert blob["iteration"] == 2 and any(k.startswith("model_student.") for k in blob["model"])
