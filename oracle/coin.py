@@ -184,7 +184,7 @@ class _Attn(nn.Module):
             return t.reshape(l, n * self.heads, hd).transpose(0, 1)  # [N*h, L, hd]
 
         q, k, v = split(q), split(k), split(v)
-        a = torch.baddbmm(mask, q * (hd ** -0.5), k.transpose(1, 2))
+        a = torch.baddbmm(mask.to(q.dtype), q * (hd ** -0.5), k.transpose(1, 2))
         a = torch.softmax(a, dim=-1)
         o = torch.bmm(a, v).transpose(0, 1).reshape(l, n, d)
         return self.out_proj(o)
@@ -363,10 +363,12 @@ def _xavier(m):
 
 def _prototype_ema(proto: torch.Tensor, feats: torch.Tensor, one_hot: torch.Tensor, rate: float) -> torch.Tensor:
     """fast_rcnn.py:405-412: per-class mean of unit features, lerp into the buffer for classes that occur."""
-    new = proto.clone().float()
+    dt = proto.dtype if proto.dtype == torch.float64 else torch.float32  # the reference computes this in fp32; fp64 only for the precision study
+    new = proto.clone().to(dt)
+    one_hot = one_hot.to(dt)
     cnt = one_hot.sum(0)
     present = cnt != 0
-    new[present] = (one_hot.T @ feats.float() / cnt.unsqueeze(1))[present]
+    new[present] = (one_hot.T @ feats.to(dt) / cnt.unsqueeze(1))[present]
     return proto * rate + (1 - rate) * new
 
 
@@ -508,12 +510,12 @@ class BoxPredictor(nn.Module):
                 pa_on = cat([p[0].gt_probs_online for p in proposals])
                 pa_off = cat([p[0].gt_probs_offline for p in proposals])
                 m_a = merge_module(f_a, te.prototype_b_offline.data, te.prototype_b_online.data, pa_off, pa_on)
-                losses["loss_merge_base"] = L.kl_div_mean(m_a, oh_a.float())
+                losses["loss_merge_base"] = L.kl_div_mean(m_a, oh_a.to(m_a.dtype))
                 m_b = merge_module(f_b, te.prototype_b_offline.data, te.prototype_b_online.data, pb_off, pb_on)
                 p_b = F.softmax(scores[ib], dim=1)
                 p_a = F.softmax(s_a, dim=1)
                 losses["loss_merge_b"] = F.mse_loss(p_b, m_b)
-                losses["loss_merge_a"] = F.mse_loss(p_a, oh_a.float())
+                losses["loss_merge_a"] = F.mse_loss(p_a, oh_a.to(p_a.dtype))
                 if branch == "step_two":
                     keep = (m_b.max(1)[0] >= self.cls_b_thresh).detach()
                     if keep.sum() > 0:
@@ -765,7 +767,7 @@ class OpenVocabularyRCNN(nn.Module):
     def preprocess_image(self, batched_inputs):
         """clip_rcnn.py:287-298: ToTensor (u8/255) -> Normalize -> zero-pad to the batch maximum."""
         m, s = self.pixel_mean.view(3, 1, 1), self.pixel_std.view(3, 1, 1)
-        imgs = [(x["image"].to(torch.float32).div(255) - m) / s for x in batched_inputs]
+        imgs = [(x["image"].to(m.dtype).div(255) - m) / s for x in batched_inputs]
         return d2.ImageList.from_tensors(imgs, self.backbone.size_divisibility)
 
     def forward(self, batched_inputs, merge_module=None, dual_teacher_instances=None, branch=None, update_prototype=False):

@@ -376,7 +376,7 @@ class Box2BoxTransform:
         return deltas
 
     def apply_deltas(self, deltas: torch.Tensor, boxes: torch.Tensor) -> torch.Tensor:
-        deltas = deltas.float()
+        deltas = deltas.float() if deltas.dtype != torch.float64 else deltas
         boxes = boxes.to(deltas.dtype)
         w = boxes[:, 2] - boxes[:, 0]
         h = boxes[:, 3] - boxes[:, 1]

@@ -67,7 +67,7 @@ def rpn_losses(anchors, logits, labels, deltas, matched_gt, batch_size_per_image
     gt_d = torch.stack([tf.get_deltas(anchors, k) for k in matched_gt])
     loc = d2.smooth_l1_loss(deltas[pos], gt_d[pos], 0.0, reduction="sum")
     valid = labels >= (0 if calc_bg else 1)
-    cls = F.binary_cross_entropy_with_logits(logits[valid], labels[valid].to(torch.float32), reduction="sum")
+    cls = F.binary_cross_entropy_with_logits(logits[valid], labels[valid].to(logits.dtype), reduction="sum")
     normalizer = batch_size_per_image * n
     return cls / (normalizer if calc_bg else max(int(valid.sum()), 1.0)), loc / normalizer
 

@@ -82,9 +82,10 @@ def _patch_samplers(model, sampled, labels, matched):
     model.proposal_generator.label_and_sample_anchors = lambda anchors, gt, branch: ([l for l in labels], [m for m in matched])
 
 
-def _grads(model, names):
+def _grads(model, names, keep_dtype=False):
     p = dict(model.named_parameters())
-    return {n: (p[n].grad.detach().float().cpu() if p[n].grad is not None else torch.zeros_like(p[n]).cpu()) for n in names}
+    cv = (lambda t: t.detach().cpu()) if keep_dtype else (lambda t: t.detach().float().cpu())
+    return {n: (cv(p[n].grad) if p[n].grad is not None else cv(torch.zeros_like(p[n]))) for n in names}
 
 
 def run_product_pretrain(case, device="cuda:0", dtype=torch.float32, update_prototype=True):
@@ -104,19 +105,63 @@ def run_product_pretrain(case, device="cuda:0", dtype=torch.float32, update_prot
     return {k: v.detach().float().cpu() for k, v in losses.items()}, _grads(model, case["ref_grads"].keys())
 
 
-def run_oracle_pretrain(case, update_prototype=True):
+def _to_dtype(inst, dtype):
+    """Float fields of an oracle Instances in `dtype` (fp64 runs of the oracle: tests/test_parity_gpu.py's precision reference)."""
+    from oracle import d2
+
+    if inst is None or dtype == torch.float32:
+        return inst
+    for k, v in list(inst.get_fields().items()):
+        if isinstance(v, d2.Boxes):
+            v.tensor = v.tensor.to(dtype)
+        elif torch.is_tensor(v) and v.is_floating_point():
+            inst.set(k, v.to(dtype))
+    return inst
+
+
+def run_oracle_pretrain(case, update_prototype=True, dtype=torch.float32):
     z = case["z"]
     model = tiny_detector()
     load_weights(model, z)
+    model.to(dtype)
     model.train()
-    sampled = [(instances(z, f"s{i}.fg", s), instances(z, f"s{i}.bg", s)) for i, s in enumerate(case["sizes"])]
-    _patch_samplers(model, sampled, case["anchor_labels"], case["anchor_matched_boxes"])
+    sampled = [(_to_dtype(instances(z, f"s{i}.fg", s), dtype), _to_dtype(instances(z, f"s{i}.bg", s), dtype)) for i, s in enumerate(case["sizes"])]
+    _patch_samplers(model, sampled, case["anchor_labels"], case["anchor_matched_boxes"].to(dtype))
     batch = []
     for i, (img, s) in enumerate(zip(case["images"], case["sizes"])):
-        batch.append({"image": img, "height": s[0], "width": s[1], "RCNN": instances(z, f"rcnn{i}", s), "RPN": instances(z, f"rpn{i}", s)})
+        batch.append({"image": img, "height": s[0], "width": s[1], "RCNN": _to_dtype(instances(z, f"rcnn{i}", s), dtype),
+                      "RPN": _to_dtype(instances(z, f"rpn{i}", s), dtype)})
     losses = model(batch, branch="pre_train", update_prototype=update_prototype)
     sum(losses.values()).backward()
-    return {k: v.detach() for k, v in losses.items()}, _grads(model, case["ref_grads"].keys())
+    return {k: v.detach() for k, v in losses.items()}, _grads(model, case["ref_grads"].keys(), keep_dtype=True)
+
+
+def run_oracle_step_two(case, dtype=torch.float32):
+    """The oracle's step_two forward + student backward at boundary P (the reference's sampled anchors / RoIs fed in)."""
+    from oracle import coin as OC
+
+    z = case["z"]
+    model = tiny_detector()
+    load_weights(model, z)
+    model.to(dtype)
+    model.train()
+    merge = OC.CKGNet(32, 32, K + 1, head_num=4)
+    load_weights(merge, z, "m::")
+    merge.to(dtype)
+    sampled = [tuple(_to_dtype(instances(z, f"s{i}.{t}", s), dtype) for t in ("a", "b", "bg")) for i, s in enumerate(case["sizes"])]
+    model.roi_heads.label_and_sample_proposals = lambda proposals, targets, branch: sampled
+    lab, mb = T(z["anchor_labels"]), T(z["anchor_matched_boxes"]).to(dtype)
+    idx, dl = T(z["anchor_matched_idxs"]), T(z["anchor_dist_labels"])
+    model.proposal_generator.label_and_sample_anchors = lambda anchors, gt, branch: (list(lab), list(mb), list(idx), list(dl))
+    batch, rc, rp = [], [], []
+    for i, (img, s) in enumerate(zip(case["images"], case["sizes"])):
+        batch.append({"image": img, "height": s[0], "width": s[1]})
+        rc.append(tuple(_to_dtype(instances(z, f"{t}{i}", s), dtype) for t in ("a", "b", "c")))
+        rp.append((_to_dtype(instances(z, f"rpn_a{i}", s), dtype), None, _to_dtype(instances(z, f"rpn_c{i}", s), dtype)))
+    losses = model(batch, merge, (rc, rp), branch="step_two", update_prototype=True)
+    skip = ["loss_merge_grad", "loss_merge_a", "loss_merge_b", "loss_merge_base"]
+    sum(v for k, v in losses.items() if k not in skip).backward()
+    return {k: v.detach() for k, v in losses.items()}, _grads(model, case["ref_grads"].keys(), keep_dtype=True)
 
 
 def golden_step_case():

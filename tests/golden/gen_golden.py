@@ -1232,10 +1232,118 @@ def case_clip_relabel():
     npz("clip_relabel", **res)
 
 
+# --------------------------------------------------------------------------- #
+# real-width cases (RN50 res5 on RoI tiles, predictor at D = 1024 / 9 classes): weights and inputs are SEEDED (tests/seeded.py),
+# the fixture holds the reference's outputs (sub-sampled where large)
+def _sub(t, *steps):
+    idx = tuple(slice(None, None, s) for s in steps)
+    return t[idx].clone()
+
+
+def case_real_width():
+    sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..")))
+    import seeded
+
+    mu = shim.ref("coin.modeling.utils")
+    # ---- res5 = ModifiedResNet.layer4 at RN50 width (utils.py:184-186): Bottleneck(1024, 512, stride 2) + 2 x Bottleneck(2048, 512)
+    torch.manual_seed(0)
+    net = nn.Sequential(mu.Bottleneck(1024, 512, stride=2), mu.Bottleneck(2048, 512), mu.Bottleneck(2048, 512))
+    seeded.fill_module(net, 501)
+    net.train()
+    x = seeded.randn((64, 1024, 14, 14), 502).requires_grad_(True)
+    gy = seeded.randn((64, 2048), 503)
+    y = net(x).mean(dim=[2, 3])
+    (y * gy).sum().backward()
+    p = dict(net.named_parameters())
+    out = {"x_checksum": np.array(seeded.checksum(x)), "w_checksum": np.array(seeded.checksum(p["0.conv2.weight"])), "y": y,
+           "gx_sub": _sub(x.grad, 8, 32, 1, 1), "g::0.conv1.weight_sub": _sub(p["0.conv1.weight"].grad, 4, 8, 1, 1),
+           "g::0.conv2.weight_sub": _sub(p["0.conv2.weight"].grad, 8, 8, 1, 1), "g::0.downsample.0.weight_sub": _sub(p["0.downsample.0.weight"].grad, 16, 8, 1, 1),
+           "g::1.conv3.weight_sub": _sub(p["1.conv3.weight"].grad, 16, 4, 1, 1), "g::2.conv1.weight_sub": _sub(p["2.conv1.weight"].grad, 4, 16, 1, 1)}
+    for n, v in p.items():
+        if v.dim() == 1:
+            out["g::" + n] = v.grad
+    out.update({"after::" + k: v for k, v in net.state_dict().items() if "running" in k})
+    npz("real_width_res5", **out)
+
+    # ---- FastRCNNOutputLayers at the benchmark's head sizes: 2048 -> trans -> cls_score 1024-d cosine logits vs 9 classes, bbox_pred
+    ct = shim.ref("coin.modeling.text_encoder.clip_text")
+    fr = shim.ref("coin.modeling.roi_heads.fast_rcnn")
+    k, dim = 8, 1024
+    classes = ["person", "rider", "car", "truck", "bus", "train", "motorcycle", "bicycle", "backgroud"]
+    toks = torch.zeros(k + 1, CTX, dtype=torch.int)
+    for i in range(k + 1):
+        seq = [62, 1, 2, 3, 1, 6, 6, 6, 6, 10 + i, 5, 63]
+        toks[i, : len(seq)] = torch.tensor(seq)
+    torch.manual_seed(0)
+    enc = ct.TEXT_ENCODER(dim, CTX, 64, 32, 2, 2, (toks, 4, 4))
+    enc.eval()
+    enc.load_embedding(32)
+    enc.float()
+    enc.freeze_encoder()
+    te = object.__new__(ct.CLIP_TEXT)
+    nn.Module.__init__(te)
+    te.type, te.target_device, te.classes = "tiny", "cpu", classes
+    te.encoder = enc
+    feat = F.normalize(seeded.randn((k + 1, dim), 511), dim=1)
+    te.register_buffer("per_class_feat", feat)
+    te.register_buffer("prototype_b_online", feat.clone())
+    te.register_buffer("prototype_b_offline", feat.clone())
+    bp = fr.FastRCNNOutputLayers(
+        d2.ShapeSpec(channels=2048, height=1, width=1), text_encoder=te, pooling_type="meanpool",
+        box2box_transform=d2.Box2BoxTransform((10.0, 10.0, 5.0, 5.0)), text_dim=dim, classes_weight=[1.0] * k + [0.9],
+        loss_type="MILCrossEntropy", test_score_thresh=0.05, test_nms_thresh=0.5, test_topk_per_image=100, cls_agnostic_bbox_reg=True,
+        smooth_l1_beta=0.0, box_reg_loss_type="smooth_l1",
+        loss_weight={"loss_box_reg": 1.0, "loss_box_reg_offline": 1.0, "loss_box_reg_online": 1.0, "loss_cls": 1.0, "loss_text_align": 10.0,
+                     "loss_distillation": 0.1, "loss_cls_b": 0.1},
+        batch_size_per_image=256, cls_b_thresh=0.3, dataset=("foggytrain_0.02",), prototype_update_rate=0.9996)
+    # the large matrices are seeded; the (small) text encoder keeps its own initialisation and is stored in the fixture
+    seeded.fill_module(bp.trans, 512), seeded.fill_module(bp.cls_score, 515), seeded.fill_module(bp.bbox_pred, 516)
+    with torch.no_grad():  # the seeded fill is He-scaled; the heads keep the reference's small initial scale (fast_rcnn.py:255-258)
+        bp.cls_score.weight.mul_(0.2)
+        bp.bbox_pred.weight.mul_(0.05)
+    te_before = {"w::text_encoder." + n: v.clone() for n, v in te.state_dict().items()}
+    bp.train()
+    g = torch.Generator().manual_seed(513)
+    size = (800, 1333)
+    props = []
+    for nf, nb in ((64, 192), (48, 208)):
+        fg = d2.Instances(size)
+        fg.proposal_boxes = d2.Boxes(rand_boxes(nf, size[0], size[1], g, 32.0, 400.0))
+        fg.objectness_logits = torch.randn(nf, generator=g)
+        fg.gt_boxes = d2.Boxes(fg.proposal_boxes.tensor + torch.randn(nf, 4, generator=g) * 4.0)
+        pr = torch.softmax(3.0 * torch.randn(nf, k + 1, generator=g), dim=1)
+        pr[:, -1] = pr.min(dim=1).values * 0.5
+        pr = pr / pr.sum(dim=1, keepdim=True)
+        fg.gt_classes_offline = pr[:, :-1].argmax(1)
+        fg.gt_probs_offline = pr
+        fg.gt_scores_offline = pr[:, :-1].max(1).values
+        bg = d2.Instances(size)
+        bg.proposal_boxes = d2.Boxes(rand_boxes(nb, size[0], size[1], g, 32.0, 400.0))
+        bg.objectness_logits = torch.randn(nb, generator=g)
+        bg.gt_classes = torch.full((nb,), k, dtype=torch.int64)
+        props.append((fg, bg))
+    xh = seeded.randn((512, 2048), 514).abs().requires_grad_(True)   # mean-pooled post-ReLU features are non-negative
+    preds = bp(xh, "pre_train")
+    (scores, lta), deltas, feats = preds
+    losses = bp.losses(preds, props, None, "pre_train", update_prototype=True)
+    sum(losses.values()).backward()
+    q = dict(bp.named_parameters())
+    out = {"x_checksum": np.array(seeded.checksum(xh)), "w_checksum": np.array(seeded.checksum(q["trans.2.weight"])), "scores": scores, "deltas": deltas,
+           "feats_sub": _sub(feats, 4, 8), "gx_sub": _sub(xh.grad, 4, 8), "prototype_after": te.per_class_feat,
+           "g::trans.0.weight_sub": _sub(q["trans.0.weight"].grad, 8, 16), "g::trans.2.weight_sub": _sub(q["trans.2.weight"].grad, 8, 8),
+           "g::trans.4.weight_sub": _sub(q["trans.4.weight"].grad, 16, 8), "g::cls_score.weight_sub": _sub(q["cls_score.weight"].grad, 8, 16),
+           "g::bbox_pred.weight": q["bbox_pred.weight"].grad, "g::trans.0.bias": q["trans.0.bias"].grad, "g::cls_score.bias": q["cls_score.bias"].grad,
+           "g::text_encoder.encoder.embedding_tmp": q["text_encoder.encoder.embedding_tmp"].grad,
+           "g::text_encoder.encoder.add_in_embedding": q["text_encoder.encoder.add_in_embedding"].grad,
+           **{"loss::" + n: v for n, v in losses.items()}, **_pack_pretrain_props(props), "n_img": np.array(2)}
+    out.update(te_before)
+    npz("real_width_box_predictor", **out)
+
+
 
 CASES = [case_mil_losses, case_bottleneck, case_resnet, case_box_predictor_pretrain, case_box_predictor_step,
          case_text_encoder, case_ckg, case_lr_and_fusion, case_optimizer_groups, case_rpn, case_roi_sampling,
-         case_e2e_pretrain, case_e2e_step_and_inference, case_ema, case_match_dual_teacher, case_e2e_coin_step, case_voc_eval, case_voc_dataset, case_clip_relabel]
+         case_e2e_pretrain, case_e2e_step_and_inference, case_ema, case_match_dual_teacher, case_e2e_coin_step, case_voc_eval, case_voc_dataset, case_clip_relabel, case_real_width]
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])

@@ -1,0 +1,272 @@
+"""Device-generic parity cases: the same comparison of the PRODUCT with the reference's golden vectors runs
+(a) on the GPU-less build container with the kernels shimmed (``tests/cpu_shim.py``; host logic only) and
+(b) on the MI355X through ``libcoin_hip.so`` (``-m gpu``), so that every integer / index decision the device
+path takes is checked bit for bit where the reference's arithmetic is integer, and to 1e-4 where it is fp32.
+
+The reference's samplers draw ``torch.randperm`` from the CPU generator (the goldens were captured on the CPU).
+A device permutation comes from a different stream, so on the GPU the product's ``randperm`` calls are served the
+SAME CPU permutation, moved to the device (``reference_randperm``): everything around the draw -- IoU matrix,
+Matcher, nonzero / index bookkeeping, label scatter -- runs on the device and must reproduce the reference exactly.
+"""
+import contextlib
+import copy
+import random
+
+import numpy as np
+import torch
+
+from e2e_util import _inst, tiny_product_detector
+from golden_util import K, T, close, load, load_weights
+
+
+@contextlib.contextmanager
+def reference_randperm():
+    real = torch.randperm
+
+    def randperm(n, *a, device=None, **kw):
+        out = real(n, *a, **kw)  # the CPU generator's stream (= the reference's)
+        return out.to(device) if device is not None else out
+
+    torch.randperm = randperm
+    try:
+        yield
+    finally:
+        torch.randperm = real
+
+
+@contextlib.contextmanager
+def kernels_for(device):
+    """CPU: oracle-backed stand-ins for the HIP kernels (host-logic check).  GPU: the real library, nothing patched but the
+    source of the random permutations."""
+    if str(device) == "cpu":
+        from cpu_shim import cpu_kernels
+
+        with cpu_kernels():
+            yield
+    else:
+        with reference_randperm():
+            yield
+
+
+def _eq(a, b, what):
+    a = a.detach().cpu()
+    b = torch.as_tensor(np.asarray(b))
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    assert torch.equal(a.to(b.dtype), b), f"{what}: {int((a.to(b.dtype) != b).sum())} of {b.numel()} entries differ"
+
+
+# ------------------------------------------------------------------------------------------ A3: anchor labelling (rpn.py:120-254)
+def rpn_labelling_losses_and_proposals(device):
+    from coin_amd.structures import Boxes, ImageList, Instances
+
+    z = load("rpn")
+    with kernels_for(device):
+        pg = tiny_product_detector().proposal_generator
+        load_weights(pg, z)
+        pg.to(device).train()
+        feats = {"res4": T(z["feat"]).to(device).contiguous(memory_format=torch.channels_last)}
+        sizes = [tuple(int(v) for v in s) for s in z["image_sizes"]]
+        images = ImageList(torch.zeros(2, 3, 96, 128, device=device), sizes)
+        gts = []
+        for i, s in enumerate(sizes):
+            t = Instances(s)
+            t.gt_boxes = Boxes(T(z[f"gt{i}.boxes"]).to(device))
+            gts.append(t)
+        anchors = pg.anchor_generator([feats["res4"]])
+        _eq(anchors[0].tensor, z["anchors"], "anchors")
+        torch.manual_seed(103)
+        labels, matched = pg.label_and_sample_anchors(anchors, gts, "pre_train")
+        _eq(torch.stack(labels), z["labels"], "sampled anchor labels (pre_train)")
+        _eq(torch.stack(matched), z["matched_boxes"], "matched boxes (pre_train)")
+        torch.manual_seed(103)
+        props, losses = pg(images, feats, gts, branch="pre_train")
+        for k in ("loss_rpn_cls", "loss_rpn_loc"):
+            assert abs(float(losses[k]) - float(z["loss::" + k])) < 1e-5 * max(1.0, abs(float(z["loss::" + k]))), (k, float(losses[k]))
+        for i, p in enumerate(props):
+            close(p.proposal_boxes.tensor, z[f"prop{i}.boxes"], 1e-5, f"proposals {i}")
+            close(p.objectness_logits, z[f"prop{i}.logits"], 1e-5, f"proposal logits {i}")
+        # step_two with (A, None, C) targets (rpn.py:199-254): image 1 has no A box
+        dual = []
+        for i, s in enumerate(sizes):
+            a, c = Instances(s), Instances(s)
+            a.gt_boxes = Boxes(T(z[f"s.a{i}.boxes"]).to(device))
+            c.gt_boxes = Boxes(T(z[f"s.c{i}.boxes"]).to(device))
+            c.gt_probs = T(z[f"s.c{i}.probs"]).to(device)
+            dual.append((a, None, c))
+        torch.manual_seed(104)
+        lab, mb, idx, dl = pg.label_and_sample_anchors(anchors, [[d[0] for d in dual], [d[2] for d in dual]], "step_two")
+        _eq(torch.stack(lab), z["s_labels"], "sampled anchor labels (step_two)")
+        _eq(torch.stack(idx), z["s_matched_idxs"], "matched C index (step_two)")
+        _eq(torch.stack(dl), z["s_dist_labels"], "distillation labels (step_two)")
+        _eq(torch.stack(mb), z["s_matched_boxes"], "matched A boxes (step_two)")
+        torch.manual_seed(104)
+        _, losses2 = pg(images, feats, dual, branch="step_two")
+        ref2 = {k[7:]: float(z[k]) for k in z.files if k.startswith("sloss::")}
+        assert set(losses2) == set(ref2)
+        for k, v in ref2.items():
+            assert abs(float(losses2[k]) - v) < 1e-5 * max(1.0, abs(v)), (k, float(losses2[k]), v)
+
+
+# ------------------------------------------------------------------------------------------ A4: RoI labelling + sampling (clip_roi_heads.py:283-399)
+def _cmp_inst_exact(got, z, prefix):
+    from coin_amd.structures import Boxes
+
+    names = [k[len(prefix) + 1:] for k in z.files if k.startswith(prefix + ".")]
+    assert names and set(names) == set(got.get_fields()), (prefix, names, sorted(got.get_fields()))
+    for name in names:
+        v = got.get(name)
+        _eq(v.tensor if isinstance(v, Boxes) else v, z[f"{prefix}.{name}"], f"{prefix}.{name}")  # copies of the inputs: bit-exact
+
+
+def roi_label_and_sample(device):
+    from coin_amd.structures import Boxes, Instances
+
+    z = load("roi_sampling")
+    size = (96, 128)
+    with kernels_for(device):
+        rh = tiny_product_detector().roi_heads
+        props, targets = [], []
+        for i in range(2):
+            p = Instances(size)
+            p.proposal_boxes = Boxes(T(z[f"in{i}.boxes"]).to(device))
+            p.objectness_logits = T(z[f"in{i}.logits"]).to(device)
+            props.append(p)
+            targets.append(_inst(z, f"t{i}", size).to(device))
+        torch.manual_seed(114)
+        out = rh.label_and_sample_proposals(props, targets, "pre_train")
+        for i, (fg, bg) in enumerate(out):
+            _cmp_inst_exact(fg, z, f"o{i}.fg")
+            _cmp_inst_exact(bg, z, f"o{i}.bg")
+        props, A, B, C = [], [], [], []
+        for i in range(2):
+            p = Instances(size)
+            p.proposal_boxes = Boxes(T(z[f"s.in{i}.boxes"]).to(device))
+            p.objectness_logits = T(z[f"s.in{i}.logits"]).to(device)
+            props.append(p)
+            A.append(_inst(z, f"s.a{i}", size).to(device))
+            B.append(_inst(z, f"s.b{i}", size).to(device))
+            C.append(_inst(z, f"s.c{i}", size).to(device))
+        torch.manual_seed(115)
+        out = rh.label_and_sample_proposals(props, [A, B, C], "step_two")
+        for i, (a, b, bg) in enumerate(out):
+            _cmp_inst_exact(a, z, f"s.o{i}.a")
+            _cmp_inst_exact(b, z, f"s.o{i}.b")
+            _cmp_inst_exact(bg, z, f"s.o{i}.bg")
+
+
+# ------------------------------------------------------------------------------------------ whole forward + backward WITH the samplers in the loop
+def e2e_pretrain_with_samplers(device, tol_loss=1e-4, tol_grad=1e-4):
+    """OpenVocabularyRCNN.forward('pre_train') with NOTHING fed in: RPN, NMS, anchor labelling, RoI matching + sampling all run and
+    must draw the reference's samples (e2e_pretrain.npz was captured with torch.manual_seed(123))."""
+    z = load("e2e_pretrain")
+    with kernels_for(device):
+        model = tiny_product_detector()
+        load_weights(model, z)
+        model.to(device)
+        model.train()
+        batch = []
+        for i in range(2):
+            img = T(z[f"img{i}"])
+            size = (img.shape[1], img.shape[2])
+            batch.append({"image": img.to(device), "height": size[0], "width": size[1], "RCNN": _inst(z, f"rcnn{i}", size), "RPN": _inst(z, f"rpn{i}", size)})
+        torch.manual_seed(123)
+        losses = model(batch, branch="pre_train", update_prototype=True)
+        ref = {k[6:]: float(z[k]) for k in z.files if k.startswith("loss::")}
+        assert set(losses) == set(ref)
+        for k, v in ref.items():
+            assert abs(float(losses[k]) - v) < tol_loss * max(1.0, abs(v)), (k, float(losses[k]), v)
+        sum(losses.values()).backward()
+        params = dict(model.named_parameters())
+        return {k[3:]: params[k[3:]].grad.detach().float().cpu() for k in z.files if k.startswith("g::")}, {k[3:]: T(z[k]) for k in z.files if k.startswith("g::")}, model, z
+
+
+# ------------------------------------------------------------------------------------------ A15: CoinTrainer.run_step (trainer.py:160-218)
+def cointrainer_scripted_iteration(device, tol=1e-5):
+    """`CoinTrainer.run_step` (product) against the iteration scripted with the reference's own pieces
+    (tests/golden/gen_golden.py:case_e2e_coin_step): A/B/C targets, every loss incl. loss_merge_grad, the CKG parameters after the
+    merge optimizer step and student parameters after the student optimizer step.  Boundary P: the reference's sampled anchors /
+    RoIs are fed in; the matcher gets the stored teacher detections (the product's own teacher inference is compared as a set)."""
+    from coin_amd.engine import CoinTrainer
+    from coin_amd.modeling.text_encoder import CKGNet
+    from coin_amd.solver import FusedSGD, get_default_optimizer_params
+    from coin_amd.structures import Boxes
+
+    z = load("e2e_coin_step")
+    dev = torch.device(device)
+    overrides = [{"backbone.encoder.visual": 0.1, "backbone.encoder.visual.layer4": 0.1, "embedding_tmp": 1.0, "add_in_embedding": 1.0, "logit_scale": 0.0}]
+    with kernels_for(device):
+        student, teacher = tiny_product_detector(), tiny_product_detector()
+        load_weights(student, z, "s::")
+        load_weights(teacher, z, "t::")
+        merge = CKGNet(32, 32, K + 1, head_num=4)
+        load_weights(merge, z, "m::")
+        student.to(dev), teacher.to(dev), merge.to(dev)
+        teacher.roi_heads.box_predictor.test_score_thresh = 0.05
+        for p in teacher.parameters():
+            p.requires_grad = False
+        batch, cloud, sizes = [], {}, []
+        for i in range(2):
+            img = T(z[f"img{i}"]).to(dev)
+            s = (img.shape[1], img.shape[2])
+            sizes.append(s)
+            name = f"img{i}.png"
+            batch.append({"image": img, "height": s[0], "width": s[1], "file_name": name, "image_id": f"id{i}", "random_flip": "no"})
+            cloud[name] = {"file_name": name, "image_id": f"id{i}", "height": s[0], "width": s[1], "RCNN": {"instances": _inst(z, f"cloud{i}", s)},
+                           "RPN": {"instances": _inst(z, f"cloud{i}", s)}}
+        stored = [{"instances": _inst(z, f"det{i}", s).to(dev)} for i, s in enumerate(sizes)]
+        # the product's own teacher inference finds the same detections
+        teacher.eval()
+        with torch.no_grad():
+            own = teacher([{k: b[k] for k in ("image", "height", "width")} for b in batch], branch="test")
+        teacher.train()
+        for o, st in zip(own, stored):
+            assert len(o["instances"]) == len(st["instances"])
+            close(torch.sort(o["instances"].scores, descending=True).values.cpu(), torch.sort(st["instances"].scores, descending=True).values.cpu(),
+                  max(tol, 1e-5), "teacher scores")
+        teacher_forward = teacher.forward
+        teacher.forward = lambda bi, branch=None, **kw: (teacher_forward(bi, branch=branch, **kw), copy.deepcopy(stored))[1]
+
+        tr = object.__new__(CoinTrainer)
+        ns = lambda **kw: type("NS", (), kw)()
+        tr.cfg = ns(CLOUD=ns(BURN_UP_STEP=0, OFFLINE_TEACHER_UPDATE_ITER=1, EMA_KEEP_RATE_OFFLINE=1.0, PROTOTYPE_UPDATE_START=0,
+                             MATCHER=ns(IOU_THRESHOLDS=0.5)))
+        tr.device, tr.world_size, tr.rank = dev, 1, 0
+        tr.model, tr.offline_teacher, tr.merge = student, teacher, merge
+        tr.ddp_model, tr.ddp_merge = student, merge
+        groups = lambda m: get_default_optimizer_params(m, base_lr=0.01, weight_decay_norm=0.0, bias_lr_factor=1.0, weight_decay_bias=1e-4,
+                                                        overrides=overrides, only_text_encoder=None)
+        tr.optimizer = FusedSGD(groups(student), lr=0.01, momentum=0.9, weight_decay=1e-4)
+        tr.optimizer_merge = FusedSGD(groups(merge), lr=0.01, momentum=0.9, weight_decay=1e-4)
+        tr.scheduler = tr.scheduler_merge = ns(step=lambda self=None: None)
+        tr._data_loader_iter = iter([(copy.deepcopy(batch), copy.deepcopy(batch))])
+        tr.model_CLOUD = lambda fn: copy.deepcopy(cloud[fn])
+        tr.iter, tr.max_iter, tr.WEIGHT_FOR_BOX_A, tr._ema, tr._pending, tr.last_losses = 0, 1, 0.5, None, None, None
+        student.train()
+        # boundary P: the samplers return what the reference's samplers drew
+        sampled = [(_inst(z, f"s{i}.a", s).to(dev), _inst(z, f"s{i}.b", s).to(dev), _inst(z, f"s{i}.bg", s).to(dev)) for i, s in enumerate(sizes)]
+        student.roi_heads.label_and_sample_proposals = lambda proposals, targets, branch: sampled
+        lab, mb = T(z["anchor_labels"]).to(dev), T(z["anchor_matched_boxes"]).to(dev)
+        idx, dl = T(z["anchor_matched_idxs"]).to(dev), T(z["anchor_dist_labels"]).to(dev)
+        student.proposal_generator.label_and_sample_anchors = lambda anchors, gt, branch: (list(lab), list(mb), list(idx), list(dl))
+        seen = {}
+        match = tr.match_boxes
+        tr.match_boxes = lambda b, o: seen.setdefault("targets", match(b, o))
+        random.seed(77)
+        record = tr.run_step()
+    rcnn, rpn = seen["targets"]
+    assert [[len(t[0]), len(t[1]), len(t[2])] for t in rcnn] == z["n_abc"].tolist()
+    for i in range(2):
+        for name, inst in (("a", rcnn[i][0]), ("b", rcnn[i][1]), ("c", rcnn[i][2]), ("rpn_a", rpn[i][0]), ("rpn_c", rpn[i][2])):
+            for k, v in inst.get_fields().items():
+                close((v.tensor if isinstance(v, Boxes) else v).cpu(), z[f"{name}{i}.{k}"], 1e-5, f"{name}{i}.{k}")
+    ref = {k[6:]: float(z[k]) for k in z.files if k.startswith("loss::")}
+    assert set(record) == set(ref)
+    for k, v in ref.items():
+        assert abs(float(record[k]) - v) < 1e-4 * max(1.0, abs(v)), (k, float(record[k]), v)
+    for k, v in merge.state_dict().items():
+        close(v.cpu(), z["m_after::" + k], tol, "merge " + k)
+    sd = student.state_dict()
+    for k in z.files:
+        if k.startswith("s_after::"):
+            close(sd[k[9:]].cpu(), z[k], tol, "student " + k[9:])
+    assert tr.iter == 1 and tr.WEIGHT_FOR_BOX_A == 0.5

@@ -1,0 +1,172 @@
+"""Parity cases at the benchmark's real layer widths (RN50 res5 on 14x14 RoI tiles, the box predictor at D = 1024 and 9 classes).
+
+The fixtures (tests/golden/real_width_*.npz, written by gen_golden.py:case_real_width from the REFERENCE's modules) hold the
+outputs; weights and inputs are re-created from seeds (tests/seeded.py) and fingerprinted against the fixture's checksums."""
+import numpy as np
+import torch
+
+import seeded
+from golden_util import T, close, load
+
+CLASSES9 = ["person", "rider", "car", "truck", "bus", "train", "motorcycle", "bicycle", "backgroud"]
+LOSS_W = {"loss_box_reg": 1.0, "loss_box_reg_offline": 1.0, "loss_box_reg_online": 1.0, "loss_cls": 1.0, "loss_text_align": 10.0,
+          "loss_distillation": 0.1, "loss_cls_b": 0.1}
+RES5_SUB = {"0.conv1.weight": (4, 8, 1, 1), "0.conv2.weight": (8, 8, 1, 1), "0.downsample.0.weight": (16, 8, 1, 1), "1.conv3.weight": (16, 4, 1, 1),
+            "2.conv1.weight": (4, 16, 1, 1)}
+HEAD_SUB = {"trans.0.weight": (8, 16), "trans.2.weight": (8, 8), "trans.4.weight": (16, 8), "cls_score.weight": (8, 16)}
+
+
+def sub(t, steps):
+    return t[tuple(slice(None, None, s) for s in steps)]
+
+
+def rel_err(a, b):
+    """max |a - b| relative to max |b| (row P of SURVEY §8a: gradients are compared relative to the tensor's scale)."""
+    a, b = torch.as_tensor(np.asarray(a)).double() if not torch.is_tensor(a) else a.detach().double().cpu(), \
+        torch.as_tensor(np.asarray(b)).double() if not torch.is_tensor(b) else b.detach().double().cpu()
+    assert a.shape == b.shape, (tuple(a.shape), tuple(b.shape))
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30)) if b.numel() else 0.0
+
+
+def res5_inputs():
+    z = load("real_width_res5")
+    x = seeded.randn((64, 1024, 14, 14), 502)
+    assert abs(seeded.checksum(x) - float(z["x_checksum"])) <= 1e-9 * abs(float(z["x_checksum"])), "seeded input drifted from the generator's"
+    return z, x, seeded.randn((64, 2048), 503)
+
+
+def run_res5(net, x, gy, device="cpu", dtype=torch.float32, mean_pool=None):
+    """net: Sequential of 3 bottlenecks (oracle or product) already filled; -> (y [64,2048], gx, {param grads}, state dict)."""
+    net.to(device=device)
+    if dtype == torch.float64:
+        net.double()
+    net.train()
+    xx = x.detach().clone().to(device=device, dtype=dtype if dtype == torch.float64 else torch.float32)
+    if str(device) != "cpu":
+        xx = xx.contiguous(memory_format=torch.channels_last)
+    xx.requires_grad_(True)
+    if mean_pool is not None:
+        y = mean_pool(net, xx)
+    else:
+        y = net(xx).mean(dim=[2, 3])
+    (y * gy.to(device=device, dtype=y.dtype)).sum().backward()
+    return y.detach(), xx.grad.detach(), {n: p.grad.detach() for n, p in net.named_parameters()}, net.state_dict()
+
+
+def check_res5(z, y, gx, grads, sd, tol_y, tol_g, exact=None, what=""):
+    """Against the reference's outputs.  `exact` = (y, gx, grads) of an fp64 run: when given, each bound is
+    max(tol, 2 x the reference's own fp32 error against fp64) and the candidate is measured against fp64 as well."""
+    rows = []
+
+    def one(name, got, ref, ex, tol):
+        e_ref = rel_err(got, ref)
+        if ex is None:
+            assert e_ref <= tol, f"{what}{name}: rel err {e_ref:.2e} > {tol:.0e} vs the reference"
+            rows.append((name, e_ref, None, None))
+            return
+        e_ref_exact, e_got_exact = rel_err(ref, ex), rel_err(got, ex)
+        bound = max(tol, 2.0 * e_ref_exact)
+        rows.append((name, e_ref, e_got_exact, e_ref_exact))
+        assert e_got_exact <= bound, f"{what}{name}: {e_got_exact:.2e} from fp64 (reference fp32 itself: {e_ref_exact:.2e}; bound {bound:.2e})"
+
+    ey, egx, eg = exact if exact is not None else (None, None, None)
+    one("y", y, z["y"], ey, tol_y)
+    one("gx", sub(gx, (8, 32, 1, 1)), z["gx_sub"], None if egx is None else sub(egx, (8, 32, 1, 1)), tol_g)
+    for n, steps in RES5_SUB.items():
+        one(n, sub(grads[n], steps), z[f"g::{n}_sub"], None if eg is None else sub(eg[n], steps), tol_g)
+    for k in z.files:
+        if k.startswith("g::") and not k.endswith("_sub"):
+            one(k[3:], grads[k[3:]], z[k], None if eg is None else eg[k[3:]], tol_g)
+    for k in z.files:
+        if k.startswith("after::"):
+            close(sd[k[7:]].float().cpu(), z[k], 1e-5, what + k)
+    return rows
+
+
+# ------------------------------------------------------------------------------------------ predictor at D = 1024
+def head_tokens(ctx=16):
+    toks = torch.zeros(9, ctx, dtype=torch.int)
+    for i in range(9):
+        seq = [62, 1, 2, 3, 1, 6, 6, 6, 6, 10 + i, 5, 63]
+        toks[i, : len(seq)] = torch.tensor(seq)
+    return toks
+
+
+def head_inputs():
+    z = load("real_width_box_predictor")
+    x = seeded.randn((512, 2048), 514).abs()
+    assert abs(seeded.checksum(x) - float(z["x_checksum"])) <= 1e-9 * abs(float(z["x_checksum"]))
+    return z, x
+
+
+def fill_head(bp, z):
+    """The generator's recipe (gen_golden.py:case_real_width): the three large blocks are seeded, the small text encoder (weights,
+    prompt vectors, fixed class embeddings, prototypes) comes from the fixture."""
+    seeded.fill_module(bp.trans, 512), seeded.fill_module(bp.cls_score, 515), seeded.fill_module(bp.bbox_pred, 516)
+    with torch.no_grad():
+        bp.cls_score.weight.mul_(0.2)
+        bp.bbox_pred.weight.mul_(0.05)
+    sd = {k[len("w::text_encoder."):]: T(z[k]) for k in z.files if k.startswith("w::text_encoder.")}
+    own = bp.text_encoder.state_dict()
+    assert set(sd) == set(own), (sorted(set(sd) ^ set(own)))
+    bp.text_encoder.load_state_dict(sd)
+    w = dict(bp.named_parameters())["trans.2.weight"]
+    assert abs(seeded.checksum(w) - float(z["w_checksum"])) <= 1e-9 * abs(float(z["w_checksum"])), "seeded weights drifted from the generator's"
+    return bp
+
+
+def check_head(z, scores, deltas, losses, gx, grads, proto, tol, tol_g, what=""):
+    close(scores, z["scores"], tol, what + "scores")
+    close(deltas, z["deltas"], tol, what + "deltas")
+    ref = {k[6:]: float(z[k]) for k in z.files if k.startswith("loss::")}
+    assert set(losses) == set(ref)
+    for k, v in ref.items():
+        assert abs(float(losses[k]) - v) < tol * max(1.0, abs(v)), (what, k, float(losses[k]), v)
+    e = rel_err(sub(gx, (4, 8)), z["gx_sub"])
+    assert e <= tol_g, f"{what}gx: {e:.2e}"
+    for k in z.files:
+        if k.startswith("g::"):
+            name = k[3:]
+            got = sub(grads[name[:-4]], HEAD_SUB[name[:-4]]) if name.endswith("_sub") else grads[name]
+            e = rel_err(got, z[k])
+            assert e <= tol_g, f"{what}{name}: rel err {e:.2e} > {tol_g:.0e}"
+    close(proto, z["prototype_after"], 1e-6, what + "prototype")
+
+
+def oracle_head():
+    from oracle import coin as OC
+
+    enc = OC.TextEncoder(1024, 16, 64, 32, 2, 2, head_tokens(), 4, 4)
+    te = OC.ClipText(enc, CLASSES9, torch.zeros(9, 1024))
+    return OC.BoxPredictor(2048, te, 1024, [1.0] * 8 + [0.9], LOSS_W, 256, cls_b_thresh=0.3, dataset=("foggytrain_0.02",))
+
+
+def product_head():
+    from coin_amd.box_ops import Box2BoxTransform
+    from coin_amd.modeling.fast_rcnn import FastRCNNOutputLayers
+    from coin_amd.modeling.text_encoder import CLIP_TEXT
+    from coin_amd.structures import ShapeSpec
+
+    te = CLIP_TEXT("RN50", CLASSES9, embed_dim=1024, context_length=16, vocab_size=64, width=32, heads=2, layers=2,
+                   tokenized_prompts=head_tokens(), n_templates=2)
+    return FastRCNNOutputLayers(ShapeSpec(channels=2048, height=1, width=1), text_encoder=te, pooling_type="meanpool",
+                                box2box_transform=Box2BoxTransform((10.0, 10.0, 5.0, 5.0)), text_dim=1024, classes_weight=[1.0] * 8 + [0.9],
+                                loss_type="MILCrossEntropy", test_score_thresh=0.05, test_nms_thresh=0.5, test_topk_per_image=100,
+                                cls_agnostic_bbox_reg=True, loss_weight=LOSS_W, batch_size_per_image=256, cls_b_thresh=0.3,
+                                dataset=("foggytrain_0.02",), prototype_update_rate=0.9996)
+
+
+def run_head(bp, z, x, make_inst, device="cpu"):
+    """pre_train forward + losses + backward of a filled predictor -> what check_head needs."""
+    bp.to(device).train()
+    props = [(make_inst(z, f"p{i}.fg", (800, 1333)), make_inst(z, f"p{i}.bg", (800, 1333))) for i in range(int(z["n_img"]))]
+    if str(device) != "cpu":
+        props = [(a.to(device), b.to(device)) for a, b in props]
+    xx = x.detach().clone().to(device).requires_grad_(True)
+    preds = bp(xx, "pre_train")
+    (scores, lta), deltas, feats = preds
+    losses = bp.losses(preds, props, None, "pre_train", update_prototype=True)
+    sum(losses.values()).backward()
+    grads = {n: (p.grad.detach().cpu() if p.grad is not None else torch.zeros_like(p).cpu()) for n, p in bp.named_parameters()}
+    return (scores.detach().cpu(), deltas.detach().cpu(), {k: float(v) for k, v in losses.items()}, xx.grad.detach().cpu(), grads,
+            bp.text_encoder.per_class_feat.detach().cpu())

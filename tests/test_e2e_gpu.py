@@ -12,34 +12,44 @@ from golden_util import close
 pytestmark = pytest.mark.gpu
 
 
-def _check(losses, grads, case, tol_loss, tol_grad):
+def _check(losses, grads, case, tol_loss, exact, what):
+    """Losses: 1e-4 against the reference's values.  Gradients (row P, relative to the tensor's scale): the reference's fp32 values
+    are themselves 1e-3..2e-3 away from the exact gradient on the backbone / res5 tensors of this tiny net (train-mode BatchNorm
+    over a few hundred samples; profiles/r2_grad_precision_study.md), so each tensor is held to
+    max(1e-4, 2 x the reference's own fp32 error) against an fp64 run of the oracle -- the heads get 1e-4."""
+    from real_width import rel_err
+
     assert set(losses) == set(case["ref_losses"])
     for k, ref in case["ref_losses"].items():
         assert abs(float(losses[k]) - ref) < tol_loss * max(1.0, abs(ref)), (k, float(losses[k]), ref)
+    _, g64 = exact
+    rows = []
     for k, ref in case["ref_grads"].items():
-        # heads: element-wise; backbone / res5: the tiny golden net runs train-mode BatchNorm over a few hundred samples,
-        # which amplifies conv summation-order differences (the SAME torch ops in NCHW vs channels-last on the CPU differ by
-        # ~2e-3 of the tensor norm, tests/cpu_shim.py) -> norm-wise bound there.
-        if k.startswith("backbone."):
-            rel = float((grads[k].double() - ref.double()).norm() / ref.double().norm())
-            assert rel < 10 * tol_grad, (k, rel)
-        else:
-            close(grads[k], ref, tol_grad, k)
+        e_ref, e_got = rel_err(ref, g64[k]), rel_err(grads[k], g64[k])
+        rows.append(f"{what} {k:62s} product vs fp64 {e_got:.2e}   reference vs fp64 {e_ref:.2e}   product vs reference {rel_err(grads[k], ref):.2e}")
+    print("\n".join(rows))
+    for k, ref in case["ref_grads"].items():
+        bound = max(1e-4, 2.0 * rel_err(ref, g64[k]))
+        assert rel_err(grads[k], g64[k]) <= bound, (k, rel_err(grads[k], g64[k]), bound)
 
 
 def test_pretrain_step_fp32_vs_reference_golden_and_oracle():
+    from e2e_util import run_oracle_pretrain
+
     case = golden_pretrain_case()
     losses, grads = run_product_pretrain(case, "cuda:0", torch.float32)
-    _check(losses, grads, case, 1e-4, 1e-3)  # grads: relative to the tensor's max (tiny net, train-mode BN amplifies rounding)
+    _check(losses, grads, case, 1e-4, run_oracle_pretrain(case, dtype=torch.float64), "pre_train")
     ora_losses, ora_grads = run_oracle_pretrain(case)
     for k in losses:
         assert abs(float(losses[k]) - float(ora_losses[k])) < 1e-4 * max(1.0, abs(float(ora_losses[k]))), k
 
 
 def test_step_two_fp32_vs_reference_golden():
+    from e2e_util import run_oracle_step_two
+
     case = golden_step_case()
     losses, grads = run_product_step_two(case, "cuda:0", torch.float32)
-    _check(losses, grads, case, 1e-4, 1e-3)
+    _check(losses, grads, case, 1e-4, run_oracle_step_two(case, dtype=torch.float64), "step_two")
 
 
 def test_pretrain_step_bf16_close_to_golden():
@@ -174,55 +184,3 @@ def test_inference_fp32_vs_reference_golden():
         assert (ours[:, 0] == ref[:, 0]).all()
         np.testing.assert_allclose(ours[:, 1], ref[:, 1], atol=1e-4)
         np.testing.assert_allclose(ours[:, 2:], ref[:, 2:], atol=2e-2)
-
-
-# ------------------------------------------------------------------------------------------ written at the end of round 1 without GPU time left:
-# opt-in until they have run once on the MI355X (COIN_RUN_UNVALIDATED=1 python -m pytest tests -m gpu -k unvalidated)
-_unvalidated = pytest.mark.skipif(__import__("os").environ.get("COIN_RUN_UNVALIDATED") != "1", reason="not yet run on the GPU; set COIN_RUN_UNVALIDATED=1")
-
-
-@_unvalidated
-@pytest.mark.parametrize("tag", ["one", "two", "two_nobg_noC", "two_noB", "one_noproto"])
-def test_unvalidated_losses_packed_step_fp32_vs_reference_golden(tag):
-    """GPU twin of tests/test_sync_free_cpu.py::test_losses_packed_step_equal_reference_losses_on_the_same_samples."""
-    import test_sync_free_cpu as cpu_tests
-
-    class _NoShim:
-        def __enter__(self):
-            return self
-
-        def __exit__(self, *a):
-            return False
-
-    orig, orig_T = cpu_tests.cpu_kernels, cpu_tests.T
-    cpu_tests.cpu_kernels = lambda: _NoShim()
-    torch.set_default_device("cuda")
-    cpu_tests.T = lambda a: orig_T(a).cuda()
-    try:
-        cpu_tests.test_losses_packed_step_equal_reference_losses_on_the_same_samples(tag)
-    finally:
-        torch.set_default_device("cpu")
-        cpu_tests.cpu_kernels, cpu_tests.T = orig, orig_T
-
-
-@_unvalidated
-def test_unvalidated_clip_relabel_fp32_vs_reference_golden():
-    """GPU twin of tests/test_host_cpu.py::test_product_clip_relabel_vs_reference (RoIAlign + eval-mode BN kernels + attention pooling)."""
-    import test_host_cpu as cpu_tests
-
-    class _NoShim:
-        def __enter__(self):
-            return self
-
-        def __exit__(self, *a):
-            return False
-
-    orig, orig_T = cpu_tests.cpu_kernels, cpu_tests.T
-    cpu_tests.cpu_kernels = lambda: _NoShim()
-    torch.set_default_device("cuda")
-    cpu_tests.T = lambda a: orig_T(a).cuda()
-    try:
-        cpu_tests.test_product_clip_relabel_vs_reference()
-    finally:
-        torch.set_default_device("cpu")
-        cpu_tests.cpu_kernels, cpu_tests.T = orig, orig_T

@@ -475,94 +475,27 @@ def test_match_boxes_product_vs_oracle_with_rescale_and_flip():
 
 
 def test_cointrainer_run_step_vs_reference_scripted_iteration():
-    """`CoinTrainer.run_step` (product, kernels shimmed) against the iteration scripted with the reference's own pieces
-    (tests/golden/gen_golden.py:case_e2e_coin_step): A/B/C targets, every loss incl. loss_merge_grad, the CKG parameters after the
-    merge optimizer step and student parameters after the student optimizer step.  Boundary P: the reference's sampled anchors /
-    RoIs are fed in; the matcher gets the stored teacher detections (the product's own teacher inference is compared as a set)."""
-    import copy
-    import random
+    """`CoinTrainer.run_step` (product, kernels shimmed) against the iteration scripted with the reference's own pieces; the same
+    case runs on the MI355X in tests/test_parity_gpu.py."""
+    from parity_cases import cointrainer_scripted_iteration
 
-    from coin_amd.engine import CoinTrainer
-    from coin_amd.modeling.text_encoder import CKGNet
-    from coin_amd.solver import FusedSGD, get_default_optimizer_params
-    from coin_amd.structures import Boxes, Instances
+    cointrainer_scripted_iteration("cpu")
 
-    z = load("e2e_coin_step")
-    overrides = [{"backbone.encoder.visual": 0.1, "backbone.encoder.visual.layer4": 0.1, "embedding_tmp": 1.0, "add_in_embedding": 1.0, "logit_scale": 0.0}]
-    with cpu_kernels():
-        student, teacher = tiny_product_detector(), tiny_product_detector()
-        load_weights(student, z, "s::")
-        load_weights(teacher, z, "t::")
-        merge = CKGNet(32, 32, K + 1, head_num=4)
-        load_weights(merge, z, "m::")
-        teacher.roi_heads.box_predictor.test_score_thresh = 0.05
-        for p in teacher.parameters():
-            p.requires_grad = False
-        batch, cloud, sizes = [], {}, []
-        for i in range(2):
-            img = T(z[f"img{i}"])
-            s = (img.shape[1], img.shape[2])
-            sizes.append(s)
-            name = f"img{i}.png"
-            batch.append({"image": img, "height": s[0], "width": s[1], "file_name": name, "image_id": f"id{i}", "random_flip": "no"})
-            cloud[name] = {"file_name": name, "image_id": f"id{i}", "height": s[0], "width": s[1], "RCNN": {"instances": _inst(z, f"cloud{i}", s)},
-                           "RPN": {"instances": _inst(z, f"cloud{i}", s)}}
-        stored = [{"instances": _inst(z, f"det{i}", s)} for i, s in enumerate(sizes)]
-        # the product's own teacher inference finds the same detections
-        teacher.eval()
-        with torch.no_grad():
-            own = teacher([{k: b[k] for k in ("image", "height", "width")} for b in batch], branch="test")
-        teacher.train()
-        for o, st in zip(own, stored):
-            assert len(o["instances"]) == len(st["instances"])
-            close(torch.sort(o["instances"].scores, descending=True).values, torch.sort(st["instances"].scores, descending=True).values, 1e-5)
-        teacher_forward = teacher.forward
-        teacher.forward = lambda bi, branch=None, **kw: (teacher_forward(bi, branch=branch, **kw), copy.deepcopy(stored))[1]
 
-        tr = object.__new__(CoinTrainer)
-        ns = lambda **kw: type("NS", (), kw)()
-        tr.cfg = ns(CLOUD=ns(BURN_UP_STEP=0, OFFLINE_TEACHER_UPDATE_ITER=1, EMA_KEEP_RATE_OFFLINE=1.0, PROTOTYPE_UPDATE_START=0,
-                             MATCHER=ns(IOU_THRESHOLDS=0.5)))
-        tr.device, tr.world_size, tr.rank = torch.device("cpu"), 1, 0
-        tr.model, tr.offline_teacher, tr.merge = student, teacher, merge
-        tr.ddp_model, tr.ddp_merge = student, merge
-        groups = lambda m: get_default_optimizer_params(m, base_lr=0.01, weight_decay_norm=0.0, bias_lr_factor=1.0, weight_decay_bias=1e-4,
-                                                        overrides=overrides, only_text_encoder=None)
-        tr.optimizer = FusedSGD(groups(student), lr=0.01, momentum=0.9, weight_decay=1e-4)
-        tr.optimizer_merge = FusedSGD(groups(merge), lr=0.01, momentum=0.9, weight_decay=1e-4)
-        tr.scheduler = tr.scheduler_merge = ns(step=lambda self=None: None)
-        tr._data_loader_iter = iter([(copy.deepcopy(batch), copy.deepcopy(batch))])
-        tr.model_CLOUD = lambda fn: copy.deepcopy(cloud[fn])
-        tr.iter, tr.max_iter, tr.WEIGHT_FOR_BOX_A, tr._ema, tr._pending, tr.last_losses = 0, 1, 0.5, None, None, None
-        student.train()
-        # boundary P: the samplers return what the reference's samplers drew
-        sampled = [(_inst(z, f"s{i}.a", s), _inst(z, f"s{i}.b", s), _inst(z, f"s{i}.bg", s)) for i, s in enumerate(sizes)]
-        student.roi_heads.label_and_sample_proposals = lambda proposals, targets, branch: sampled
-        lab, mb = T(z["anchor_labels"]), T(z["anchor_matched_boxes"])
-        idx, dl = T(z["anchor_matched_idxs"]), T(z["anchor_dist_labels"])
-        student.proposal_generator.label_and_sample_anchors = lambda anchors, gt, branch: (list(lab), list(mb), list(idx), list(dl))
-        seen = {}
-        match = tr.match_boxes
-        tr.match_boxes = lambda b, o: seen.setdefault("targets", match(b, o))
-        random.seed(77)
-        record = tr.run_step()
-    rcnn, rpn = seen["targets"]
-    assert [[len(t[0]), len(t[1]), len(t[2])] for t in rcnn] == z["n_abc"].tolist()
-    for i in range(2):
-        for name, inst in (("a", rcnn[i][0]), ("b", rcnn[i][1]), ("c", rcnn[i][2]), ("rpn_a", rpn[i][0]), ("rpn_c", rpn[i][2])):
-            for k, v in inst.get_fields().items():
-                close(v.tensor if isinstance(v, Boxes) else v, z[f"{name}{i}.{k}"], 1e-5, f"{name}{i}.{k}")
-    ref = {k[6:]: float(z[k]) for k in z.files if k.startswith("loss::")}
-    assert set(record) == set(ref)
-    for k, v in ref.items():
-        assert abs(float(record[k]) - v) < 1e-4 * max(1.0, abs(v)), (k, float(record[k]), v)
-    for k, v in merge.state_dict().items():
-        close(v, z["m_after::" + k], 1e-5, "merge " + k)
-    sd = student.state_dict()
-    for k in z.files:
-        if k.startswith("s_after::"):
-            close(sd[k[9:]], z[k], 1e-5, "student " + k[9:])
-    assert tr.iter == 1 and tr.WEIGHT_FOR_BOX_A == 0.5
+def test_product_rpn_labelling_losses_and_proposals_vs_reference():
+    """DualTeacherRPN.label_and_sample_anchors / losses / proposals (rpn.py:41-345) of the PRODUCT vs rpn.npz: sampled labels,
+    matched boxes and indices bit for bit (GPU twin in tests/test_parity_gpu.py)."""
+    from parity_cases import rpn_labelling_losses_and_proposals
+
+    rpn_labelling_losses_and_proposals("cpu")
+
+
+def test_product_roi_label_and_sample_vs_reference():
+    """OpenVocabularyRes5ROIHeads.label_and_sample_proposals (clip_roi_heads.py:283-399) of the PRODUCT vs roi_sampling.npz, both
+    branches, bit for bit (GPU twin in tests/test_parity_gpu.py)."""
+    from parity_cases import roi_label_and_sample
+
+    roi_label_and_sample("cpu")
 
 
 def test_pretrain_checkpoint_feeds_cointrainer(tmp_path):

@@ -562,6 +562,24 @@ def test_e2e_coin_step_teacher_matching_ckg_and_student_updates():
             assert float((T(z[k]) - T(z["s::" + k[9:]])).abs().max()) > 0 or "logit_scale" in k, k  # the step moved it
 
 
+# ------------------------------------------------------------------------------------------ real layer widths (RN50 res5, D = 1024 head)
+def test_real_width_res5_and_box_predictor_vs_reference():
+    """The oracle at the benchmark's widths against outputs captured from the reference's Bottleneck x3 (utils.py:77-90,184-186)
+    on a [64,1024,14,14] RoI batch and from its FastRCNNOutputLayers (2048 -> trans -> 1024-d cosine logits vs 9 classes,
+    512 RoIs): tests/golden/real_width_*.npz, weights / inputs re-created from seeds (tests/seeded.py)."""
+    import real_width as RW
+    import seeded
+
+    z, x, gy = RW.res5_inputs()
+    net = torch.nn.Sequential(OC.Bottleneck(1024, 512, 2), OC.Bottleneck(2048, 512, 1), OC.Bottleneck(2048, 512, 1))
+    seeded.fill_module(net, 501)
+    y, gx, grads, sd = RW.run_res5(net, x, gy)
+    RW.check_res5(z, y, gx, grads, sd, 1e-5, 1e-5)   # same torch CPU ops as the reference: agreement to rounding of the last bit
+    zh, xh = RW.head_inputs()
+    bp = RW.fill_head(RW.oracle_head(), zh)
+    RW.check_head(zh, *RW.run_head(bp, zh, xh, instances), tol=1e-5, tol_g=1e-5)
+
+
 # ------------------------------------------------------------------------------------------ CLIP-teacher relabelling (collection)
 def _clip_relabel_oracle(z):
     from oracle import clip_collect as CC

@@ -34,6 +34,7 @@ for name, arrays in captured.items():
     (["case_e2e_coin_step"], ["e2e_coin_step"]),
     (["case_voc_eval"], ["voc_eval"]),
     (["case_clip_relabel"], ["clip_relabel"]),
+    (["case_real_width"], ["real_width_res5", "real_width_box_predictor"]),
 ])
 def test_committed_fixtures_are_reproduced_by_the_reference(tmp_path, cases, files):
     golden = os.path.join(HERE, "golden")
