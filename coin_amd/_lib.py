@@ -51,6 +51,7 @@ SIGNATURES = {
     "coin_cosine_logits_fwd": [_P, _I, _P, _I, _I, _I, _F, _P, _P, _I, _P],
     "coin_cosine_logits_bwd": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _F, _P, _P, _I, _P],
     "coin_mil_ce_fwd_bwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "coin_mil_focal_fwd_bwd": [_P, _I, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P, _P, _P],
     "coin_kl_div_fwd_bwd": [_P, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P, _P],
     "coin_box_reg_l1_fwd_bwd": [_P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P],
     "coin_l1_mean_fwd_bwd": [_P, _P, _L, _P, _P, _P],

@@ -127,16 +127,20 @@ class CloudResults:
     def set_results(self, results):
         self._results = results
 
-    def __call__(self, file_name: str) -> Optional[Dict]:
+    def entry(self, file_name: str) -> Dict:
+        """The stored record itself (no copy); KeyError names the file when no dataset holds it."""
         for results in self._results.values():
-            if file_name in results:
-                src = results[file_name]
-                out = {k: v for k, v in src.items() if not isinstance(v, dict)}
-                for tag, entry in src.items():
-                    if isinstance(entry, dict):
-                        out[tag] = {k: (_copy_instances(v, self.device) if isinstance(v, Instances) else v) for k, v in entry.items()}
-                return out
-        return None
+            if isinstance(results, dict) and file_name in results:
+                return results[file_name]
+        raise KeyError(f"no cached teacher result for {file_name!r} (datasets: {list(self._results)[:4]})")
+
+    def __call__(self, file_name: str) -> Dict:
+        src = self.entry(file_name)
+        out = {k: v for k, v in src.items() if not isinstance(v, dict)}
+        for tag, entry in src.items():
+            if isinstance(entry, dict):
+                out[tag] = {k: (_copy_instances(v, self.device) if isinstance(v, Instances) else v) for k, v in entry.items()}
+        return out
 
 
 def _copy_instances(inst: Instances, device) -> Instances:
@@ -168,9 +172,46 @@ def detector_state_dict(blob: Any) -> Dict[str, torch.Tensor]:
     return {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
 
 
-def load_cointrainer_weights(trainer, weights: str) -> None:
+def optimizer_state(opt) -> Dict[str, Any]:
+    """``torch.optim.SGD.state_dict()`` layout of a FusedSGD (one parameter per group, so parameter index == group index): what the
+    reference's checkpointer writes under "optimizer" / "optimizer_merge" (fvcore Checkpointer.save: every checkpointable's
+    state_dict()) and what its ``optimizer.load_state_dict`` accepts."""
+    sd = opt.state_dict()
+    bufs = sd.get("momentum_buffers")
+    state = {}
+    if bufs is not None and not sd.get("first", True):
+        state = {i: {"momentum_buffer": b.detach().cpu().clone()} for i, b in enumerate(bufs)}
+    groups = []
+    for i, g in enumerate(opt.param_groups):
+        groups.append({"lr": g["lr"], "momentum": g["momentum"], "dampening": 0, "weight_decay": g["weight_decay"], "nesterov": False,
+                       "initial_lr": g["base_lr"], "name": g.get("name"), "params": [i]})
+    return {"state": state, "param_groups": groups}
+
+
+def load_optimizer_state(opt, sd: Dict[str, Any]) -> None:
+    """Inverse of `optimizer_state` (also takes a reference-written torch SGD state dict with one parameter per group)."""
+    groups = sd["param_groups"]
+    assert len(groups) == len(opt.param_groups), "optimizer state has a different number of parameter groups"
+    for g, s in zip(opt.param_groups, groups):
+        g["lr"], g["weight_decay"] = s["lr"], s["weight_decay"]
+        g["base_lr"] = s.get("initial_lr", g["base_lr"])
+    state = sd.get("state", {})
+    bufs = [state[i]["momentum_buffer"] if i in state and state[i].get("momentum_buffer") is not None else None for i in range(len(groups))]
+    opt.load_momentum(bufs)
+
+
+def scheduler_state(sched) -> Dict[str, Any]:
+    """torch ``_LRScheduler.state_dict()`` of WarmupTwoStageMultiStepLR (lr_scheduler.py:22-66): every attribute but the optimizer."""
+    return {"milestones": list(sched.milestones), "factor_list": list(sched.factor_list), "gamma": sched.gamma, "warmup_factor": sched.warmup_factor,
+            "warmup_iters": sched.warmup_iters, "warmup_method": sched.warmup_method, "base_lrs": list(sched.base_lrs),
+            "last_epoch": sched.last_epoch, "_step_count": sched.last_epoch + 1, "_last_lr": [g["lr"] for g in sched.optimizer.param_groups]}
+
+
+def load_cointrainer_weights(trainer, weights: str, resume: bool = False) -> None:
     """``CoinTrainer.resume_or_load`` (trainer.py:220-262) for ``MODEL.WEIGHTS``:
-    "offline.pth+cloud_results.pth" -> teacher weights + cached cloud results; a single path -> a CoinTrainer checkpoint."""
+    "offline.pth+cloud_results.pth" -> teacher weights + cached cloud results; a single path -> a CoinTrainer checkpoint, with
+    ``resume`` also both optimizers and both schedulers (trainer.py:237-241), without it only `scheduler(.merge).last_epoch` is
+    set to the stored iteration (trainer.py:246-247: the rate itself is re-derived at the next scheduler step, as there)."""
     paths = weights.split("+")
     if len(paths) == 2:
         trainer.offline_teacher.load_state_dict(detector_state_dict(load_file(paths[0])), strict=False)
@@ -181,6 +222,15 @@ def load_cointrainer_weights(trainer, weights: str) -> None:
         trainer.offline_teacher.load_state_dict(parts["offline_teacher"], strict=False)
         trainer.model.load_state_dict(parts["student"], strict=False)
         trainer.merge.load_state_dict(parts["merge"], strict=False)
+        if resume:
+            for name in ("optimizer", "optimizer_merge"):
+                if blob.get(name) is not None:
+                    load_optimizer_state(getattr(trainer, name), blob[name])
+            for name in ("scheduler", "scheduler_merge"):
+                if blob.get(name) is not None:
+                    getattr(trainer, name).load_state_dict(blob[name])
+        else:
+            trainer.scheduler.last_epoch = trainer.scheduler_merge.last_epoch = blob.get("iteration", -1)
         trainer.start_iter = trainer.iter = blob.get("iteration", -1) + 1
         if blob.get("online_results") is not None:
             trainer.model_CLOUD = CloudResults(blob["online_results"], device=trainer.device)
@@ -188,11 +238,13 @@ def load_cointrainer_weights(trainer, weights: str) -> None:
         raise AssertionError("pretrain models path should be two paths split by '+'. ")
 
 
-def save_cointrainer_checkpoint(trainer, path: str) -> None:
+def save_cointrainer_checkpoint(trainer, path: str, iteration: Optional[int] = None) -> None:
     """DetectionTSCheckpointer.save layout (trainer.py:128-137)."""
     model = {}
     for part, module in (("offline_teacher", trainer.offline_teacher), ("student", trainer.model), ("merge", trainer.merge)):
         model.update({_PREFIXES[part] + k: v.detach().cpu() for k, v in module.state_dict().items()})
-    blob = {"model": model, "iteration": trainer.iter - 1, "ap_50_student": {}, "ap_50_offline_teacher": {},
+    blob = {"model": model, "optimizer": optimizer_state(trainer.optimizer), "optimizer_merge": optimizer_state(trainer.optimizer_merge),
+            "scheduler": scheduler_state(trainer.scheduler), "scheduler_merge": scheduler_state(trainer.scheduler_merge),
+            "iteration": trainer.iter - 1 if iteration is None else iteration, "ap_50_student": {}, "ap_50_offline_teacher": {},
             "online_results": trainer.model_CLOUD.get_results() if hasattr(trainer.model_CLOUD, "get_results") else None}
     save_file(blob, path)

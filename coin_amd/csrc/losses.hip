@@ -51,6 +51,49 @@ __global__ __launch_bounds__(LOSS_THREADS) void mil_ce_kernel(
   if (threadIdx.x == 0) *loss = tot * gscale;
 }
 
+// MILFocalLoss (coin/utils/losses.py:36-73): alpha_r = sum_c t*alpha_c / (T + 1e-6);  P = sum_c t*p / (avg ? T + 1e-6 : 1);
+// l_r = -alpha_r (1 - P)^gamma log P [* w_r];  loss = mean_r l_r (R == 0 -> NaN, as torch's mean of an empty tensor) or the sum.
+__global__ __launch_bounds__(LOSS_THREADS) void mil_focal_kernel(
+    const float* __restrict__ x, int ldx, const float* __restrict__ target, const int64_t* __restrict__ labels,
+    const float* __restrict__ weights, const float* __restrict__ alpha, float gamma, int R, int C, int avg_positives,
+    int reduction_mean, float* __restrict__ loss, float* __restrict__ grad_x) {
+  __shared__ float red[16];
+  const float gscale = reduction_mean ? 1.0f / (float)R : 1.0f;
+  float local = 0.f;
+  for (int r = threadIdx.x; r < R; r += LOSS_THREADS) {
+    const float* __restrict__ xr = x + (size_t)r * ldx;
+    float se = 0.f, S = 0.f, T = 0.f, A = 0.f;
+    const int lab = labels ? (int)labels[r] : -1;
+    for (int c = 0; c < C; ++c) {
+      const float e = expf(xr[c]);  // no max-subtraction (losses.py:54-57)
+      const float t = labels ? (c == lab ? 1.f : 0.f) : target[(size_t)r * C + c];
+      se += e;
+      S += t * e;
+      T += t;
+      A += t * alpha[c];
+    }
+    S = S / se;
+    const float k = avg_positives ? 1.0f / (T + 1e-6f) : 1.0f;
+    const float a = A / (T + 1e-6f);
+    const float P = S * k;
+    const float om = 1.0f - P;
+    const float pw = powf(om, gamma);
+    const float w = weights ? weights[r] : 1.f;
+    local += -a * pw * logf(P) * w;
+    if (grad_x) {
+      // dl/dP = -a [ -gamma (1-P)^(gamma-1) log P + (1-P)^gamma / P ];  dP/dx_c = k p_c (t_c - S)
+      const float dldp = -a * (-gamma * powf(om, gamma - 1.0f) * logf(P) + pw / P) * w;
+      for (int c = 0; c < C; ++c) {
+        const float p = expf(xr[c]) / se;
+        const float t = labels ? (c == lab ? 1.f : 0.f) : target[(size_t)r * C + c];
+        grad_x[(size_t)r * C + c] = dldp * k * p * (t - S) * gscale;
+      }
+    }
+  }
+  const float tot = block_reduce_sum(local, red);
+  if (threadIdx.x == 0) *loss = tot * gscale;
+}
+
 // mode 0: logits -> softmax; mode 1: probabilities; mode 2: binary sigmoid
 __global__ __launch_bounds__(LOSS_THREADS) void kl_div_kernel(
     const float* __restrict__ x, int ldx, const float* __restrict__ q, int ldq, const uint8_t* __restrict__ mask,
@@ -228,6 +271,16 @@ extern "C" int coin_mil_ce_fwd_bwd(const float* x, int ldx, const float* target,
   if (R > 0 && ((target == nullptr) == (labels == nullptr))) return COIN_EINVAL;
   mil_ce_kernel<<<1, LOSS_THREADS, 0, (hipStream_t)stream>>>(x, ldx, target, labels, weights, R, C, avg_positives,
                                                            reduction_mean, loss, grad_x);
+  return coin_launch_status();
+}
+
+extern "C" int coin_mil_focal_fwd_bwd(const float* x, int ldx, const float* target, const int64_t* labels,
+                                      const float* weights, const float* alpha, float gamma, int R, int C, int avg_positives,
+                                      int reduction_mean, float* loss, float* grad_x, void* stream) {
+  if (!loss || !alpha || R < 0 || C <= 0 || C > MAX_C) return C > MAX_C ? COIN_ESHAPE : COIN_EINVAL;
+  if (R > 0 && (!x || ldx < C)) return COIN_EINVAL;
+  if (R > 0 && ((target == nullptr) == (labels == nullptr))) return COIN_EINVAL;
+  mil_focal_kernel<<<1, LOSS_THREADS, 0, (hipStream_t)stream>>>(x, ldx, target, labels, weights, alpha, gamma, R, C, avg_positives, reduction_mean, loss, grad_x);
   return coin_launch_status();
 }
 

@@ -47,16 +47,26 @@ def synthetic_teacher_result(file_name: str, image_id: str, h: int, w: int, num_
 
 
 class SyntheticTeacherCache:
-    """Stands in for CLIP_COLLECTOR.__call__ (coin/modeling/meta_arch/clip_collector.py:69-74): file name -> deep copy."""
+    """Stands in for CLIP_COLLECTOR.__call__ (coin/modeling/meta_arch/clip_collector.py:69-74): file name -> deep copy.
+    The store has the reference's layout ``{dataset_name: {file_name: result}}`` (gdino_collector.py:51-75), which is what the
+    trainers write into their checkpoints ("results" / "online_results") and ``CloudResults`` reads back."""
 
-    def __init__(self):
-        self._results: Dict[str, Dict] = {}
+    def __init__(self, dataset_name: str = "synthetic_voc_train"):
+        self.dataset_name = dataset_name
+        self._results: Dict[str, Dict[str, Dict]] = {dataset_name: {}}
 
     def add(self, result: Dict):
-        self._results[result["file_name"]] = result
+        self._results.setdefault(self.dataset_name, {})[result["file_name"]] = result
+
+    def entry(self, file_name: str) -> Dict:
+        """The stored record itself (no copy)."""
+        for per_dataset in self._results.values():
+            if file_name in per_dataset:
+                return per_dataset[file_name]
+        raise KeyError(f"no cached teacher result for {file_name!r}")
 
     def __call__(self, file_name: str) -> Dict:
-        r = self._results[file_name]
+        r = self.entry(file_name)
         out = {k: v for k, v in r.items() if k not in ("RCNN", "RPN")}
         for tag in ("RCNN", "RPN"):
             src = r[tag]["instances"]

@@ -98,43 +98,64 @@ class PRETrainer(BASE_Trainer):
         self.iter += 1
         return record
 
-    # ------------------------------------------------------------------ files (pre_train.py:138-161, 176-177)
-    def save(self, path: str):
-        """Pre-train checkpoint in the reference's layout ({"model", "iteration", "results"}): what a CoinTrainer run takes as
-        the first half of ``MODEL.WEIGHTS`` ("pre_train_CLIP_xxx.pth+GDINO_collect.pth")."""
-        from ..checkpoint import save_file
+    # ------------------------------------------------------------------ files (pre_train.py:138-146, 172-175, 238-279)
+    def save(self, path: str, iteration: Optional[int] = None, load_models: bool = True):
+        """Pre-train checkpoint in the reference's layout (DetectionTSCheckpointer(model, optimizer=, scheduler=).save + pre_train.py:138-146):
+        {"model", "optimizer", "scheduler", "iteration", "results"[, "load_models": False]} -- what a CoinTrainer run takes as the
+        first half of ``MODEL.WEIGHTS`` ("pre_train_CLIP_xxx.pth+GDINO_collect.pth")."""
+        from ..checkpoint import optimizer_state, save_file, scheduler_state
 
         results = self.collect_model.get_results() if hasattr(self.collect_model, "get_results") else None
-        save_file({"model": {k: v.detach().cpu() for k, v in self.model.state_dict().items()}, "iteration": self.iter - 1, "results": results}, path)
+        blob = {"model": {k: v.detach().cpu() for k, v in self.model.state_dict().items()}, "optimizer": optimizer_state(self.optimizer),
+                "scheduler": scheduler_state(self.scheduler), "iteration": self.iter - 1 if iteration is None else iteration, "results": results}
+        if not load_models:  # pre_train.py:142: the key exists only when False (the collection run's CLIP_-0000001.pth)
+            blob["load_models"] = False
+        save_file(blob, path)
 
     def resume_or_load(self, resume: bool = False):
-        """``MODEL.WEIGHTS`` of a PRETRAIN run is the file with the collected teacher results (pre_train.py:152-161) or, with
-        ``--resume``, a pre-train checkpoint.  Synthetic runs (no weights given) keep the generated cache."""
-        from ..checkpoint import CloudResults, detector_state_dict, load_file
+        """pre_train.py:238-279.  ``MODEL.WEIGHTS`` = a pre-train checkpoint or the file written by the collection run: the detector
+        weights are loaded in both modes (fvcore Checkpointer.load always loads "model") unless the file says ``load_models: False``
+        (then the fresh initialisation is kept, :265-268); ``start_iter`` = stored iteration + 1; the cached teacher results are
+        taken from "results"; with ``--resume`` the optimizer and the scheduler are restored too.  Synthetic runs (no weights given)
+        keep the generated cache."""
+        from ..checkpoint import CloudResults, detector_state_dict, load_file, load_optimizer_state
 
         if not self.cfg.MODEL.WEIGHTS:
             return
         blob = load_file(self.cfg.MODEL.WEIGHTS)
-        if resume:
+        is_ckpt = isinstance(blob, dict) and "model" in blob
+        if not (is_ckpt and blob.get("load_models", True) is False):
             self.model.load_state_dict(detector_state_dict(blob), strict=False)
+        if resume and is_ckpt:
+            if blob.get("optimizer") is not None:
+                load_optimizer_state(self.optimizer, blob["optimizer"])
+            if blob.get("scheduler") is not None:
+                self.scheduler.load_state_dict(blob["scheduler"])
+        if is_ckpt:
             self.iter = self.start_iter = blob.get("iteration", -1) + 1
-        if isinstance(blob, dict) and blob.get("results") is not None:
-            self.collect_model = CloudResults(blob["results"], device=self.device)
+            if blob.get("results") is not None:
+                self.collect_model = CloudResults(blob["results"], device=self.device)
         self._next_batch = None
 
     def after_step(self):
-        """pre_train.py:172-175 + MyPeriodicCheckpointer: the final model as ``pre_train_CLIP_<iter>.pth``, periodic ``model_<iter>.pth``.
-        `self.iter` has already advanced past the step that just finished."""
+        """pre_train.py:172-175 + MyPeriodicCheckpointer(file_prefix=CLOUD.PRE_TRAIN_NAME) (hooks.py:60-84): the final model as
+        ``pre_train_CLIP_<iter>.pth``, periodic ``CLIP_<iter>.pth`` and ``CLIP_final.pth`` after the last iteration -- independent
+        conditions, as in the reference.  `self.iter` has already advanced past the step that just finished."""
         done = self.iter - 1
         if self.rank != 0 or not self.cfg.OUTPUT_DIR:
             return
-        period = self.cfg.SOLVER.CHECKPOINT_PERIOD
+        period, prefix, out = self.cfg.SOLVER.CHECKPOINT_PERIOD, self.cfg.CLOUD.PRE_TRAIN_NAME, self.cfg.OUTPUT_DIR
+        names = []
         if done == self.max_iter - 1:
-            os.makedirs(self.cfg.OUTPUT_DIR, exist_ok=True)
-            self.save(os.path.join(self.cfg.OUTPUT_DIR, "pre_train_{}_{:07d}.pth".format(self.cfg.CLOUD.PRE_TRAIN_NAME, done)))
-        elif period > 0 and (done + 1) % period == 0:
-            os.makedirs(self.cfg.OUTPUT_DIR, exist_ok=True)
-            self.save(os.path.join(self.cfg.OUTPUT_DIR, "model_{:07d}.pth".format(done)))
+            names.append("pre_train_{}_{:07d}.pth".format(prefix, done))
+        if period > 0 and (done + 1) % period == 0:
+            names.append("{}_{:07d}.pth".format(prefix, done))
+        if done >= self.max_iter - 1:
+            names.append("{}_final.pth".format(prefix))
+        if names:
+            os.makedirs(out, exist_ok=True)
+        for n in names:
+            self.save(os.path.join(out, n), iteration=done)
 
     def train(self):
         for _ in range(self.start_iter, self.max_iter):

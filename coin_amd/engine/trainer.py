@@ -116,7 +116,6 @@ class CoinTrainer(BASE_Trainer):
             self.offline_teacher.train()
             return self.match_boxes(weak, offline_results)
 
-    pipeline_teacher = True  # prepare the next iteration's targets right after this iteration's optimizer step (see run_step)
     _pending = None
 
     def run_step(self):
@@ -168,14 +167,18 @@ class CoinTrainer(BASE_Trainer):
         if self.iter >= burn:  # trainer.py:150-157 (after_step): fused A boxes from the next step on
             self.WEIGHT_FOR_BOX_A = 0.5
         self.iter += 1
-        if self.pipeline_teacher and self.iter < self.max_iter:
-            # The next iteration begins with the teacher's EMA / inference / matching, which read nothing but the weights just
-            # updated -- doing them here is the same computation in the same order.  The difference is on the clock: the device
-            # is still executing this iteration's backward (enqueued asynchronously) while the host goes through the
-            # synchronising post-processing of the teacher's detections and the CPU matcher.
+        return record
+
+    def prepare_next(self):
+        """The next iteration begins with the teacher's EMA / inference / matching, which read nothing but the weights just
+        updated: doing them right after this iteration's optimizer step is the same computation in the same order.  The
+        difference is on the clock: the device is still executing this iteration's backward (enqueued asynchronously) while
+        the host goes through the synchronising post-processing of the teacher's detections and the matcher.  Called by
+        `train()` AFTER `after_step()`, so a checkpoint written for iteration i holds the teacher as iteration i left it
+        (the reference saves in after_step, before the next iteration's EMA: trainer.py:149-172)."""
+        if self._pending is None and self.iter < self.max_iter:
             strong, weak = next(self._data_loader_iter)
             self._pending = (strong, self._teacher_targets(weak))
-        return record
 
     def resume_or_load(self, resume: bool = False):
         """trainer.py:220-262: ``MODEL.WEIGHTS`` = "offline_teacher.pth+cloud_results.pth" (start of adaptation) or one CoinTrainer
@@ -186,7 +189,7 @@ class CoinTrainer(BASE_Trainer):
             assert self.cfg.AMD.SYNTHETIC.ENABLED, "pretrain models must be loaded!"
             return
         assert not (resume and "+" in self.cfg.MODEL.WEIGHTS), "resume need only one model."
-        load_cointrainer_weights(self, self.cfg.MODEL.WEIGHTS)
+        load_cointrainer_weights(self, self.cfg.MODEL.WEIGHTS, resume=resume)
         self._pending, self._ema = None, None
 
     def _zero_merge_loss(self) -> torch.Tensor:
@@ -199,8 +202,9 @@ class CoinTrainer(BASE_Trainer):
         return self.ddp_merge(x, proto, te.prototype_b_online.data, probs, probs).sum() * 0.0
 
     def after_step(self):
-        """trainer.py:150-157 + MyPeriodicCheckpointer: ``burn_up_<iter>.pth`` at the end of the burn-up phase, periodic
-        ``model_<iter>.pth`` (DetectionTSCheckpointer layout).  `self.iter` has already advanced past the finished step."""
+        """trainer.py:149-157 + MyPeriodicCheckpointer (hooks.py:60-84): ``burn_up_<iter>.pth`` at the end of the burn-up phase,
+        periodic ``model_<iter>.pth``, ``model_final.pth`` after the last iteration (DetectionTSCheckpointer layout) -- independent
+        conditions, as in the reference.  `self.iter` has already advanced past the finished step."""
         import os
 
         from ..checkpoint import save_cointrainer_checkpoint
@@ -209,19 +213,23 @@ class CoinTrainer(BASE_Trainer):
         if self.rank != 0 or not self.cfg.OUTPUT_DIR:
             return
         period = self.cfg.SOLVER.CHECKPOINT_PERIOD
-        name = None
+        names = []
         if done == self.cfg.CLOUD.BURN_UP_STEP - 1:
-            name = "burn_up_{:07d}.pth".format(done)
-        elif (period > 0 and (done + 1) % period == 0) or done == self.max_iter - 1:
-            name = "model_{:07d}.pth".format(done)
-        if name:
+            names.append("burn_up_{:07d}.pth".format(done))
+        if period > 0 and (done + 1) % period == 0:
+            names.append("model_{:07d}.pth".format(done))
+        if done >= self.max_iter - 1:
+            names.append("model_final.pth")
+        if names:
             os.makedirs(self.cfg.OUTPUT_DIR, exist_ok=True)
-            save_cointrainer_checkpoint(self, os.path.join(self.cfg.OUTPUT_DIR, name))
+        for n in names:
+            save_cointrainer_checkpoint(self, os.path.join(self.cfg.OUTPUT_DIR, n), iteration=done)
 
     def train(self):
         for _ in range(self.start_iter, self.max_iter):
             rec = self.run_step()
             self.after_step()
+            self.prepare_next()
             m = self._write_metrics(rec, self.iter)
             if m is not None and self.rank == 0:
                 print(f"iter {self.iter}: " + "  ".join(f"{k} {v:.4f}" for k, v in m.items()), flush=True)

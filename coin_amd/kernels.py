@@ -16,7 +16,7 @@ from ._lib import ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, COIN_BF16, COIN_F32, COIN_
 
 __all__ = [
     "roi_align_fwd", "roi_align_bwd", "gemm_nt", "transpose2d", "bias_act_bwd", "cosine_logits_fwd",
-    "cosine_logits_bwd", "bn_stats", "bn_apply_fwd", "bn_bwd", "avgpool2_fwd", "avgpool2_bwd", "nms_batched", "mil_ce", "kl_div", "box_reg_l1", "l1_mean", "rpn_losses", "normalize_pad",
+    "cosine_logits_bwd", "bn_stats", "bn_apply_fwd", "bn_bwd", "avgpool2_fwd", "avgpool2_bwd", "nms_batched", "mil_ce", "mil_focal", "kl_div", "box_reg_l1", "l1_mean", "rpn_losses", "normalize_pad",
     "SgdTable", "EmaTable",
 ]
 
@@ -250,6 +250,30 @@ def mil_ce(x: torch.Tensor, target: Optional[torch.Tensor] = None, labels: Optio
     check(_lib.lib().coin_mil_ce_fwd_bwd(_p(x), x.stride(0) if r else c, _p(target), _p(labels), _p(weights), r, c,
                                          int(avg_positives), int(reduction == "mean"), _p(loss), _p(grad), _stream()),
           "coin_mil_ce_fwd_bwd")
+    return loss, grad
+
+
+def mil_focal(x: torch.Tensor, alpha: torch.Tensor, target: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
+              gamma: float = 1.5, avg_positives: bool = True, weights: Optional[torch.Tensor] = None, reduction: str = "mean",
+              want_grad: bool = True):
+    """MILFocalLoss (coin/utils/losses.py:36-73): alpha [C] = the class weights; the reference takes the mean over rows without row
+    weights (`weights` / reduction 'sum' serve the fixed-shape sampler's validity mask)."""
+    _dev(x, alpha, target, labels, weights)
+    if weights is not None:
+        weights = _f32c(weights, "weights")
+    x, alpha = _f32c(x, "x"), _f32c(alpha, "alpha")
+    r, c = x.shape
+    if alpha.numel() != c:
+        raise CoinHipError("mil_focal: alpha must hold one weight per class")
+    if target is not None:
+        target = _f32c(target, "target")
+    if labels is not None and (labels.dtype != torch.int64 or not labels.is_contiguous()):
+        raise CoinHipError("labels must be contiguous int64")
+    loss = _scalar(x.device)
+    grad = torch.empty_like(x) if want_grad else None
+    check(_lib.lib().coin_mil_focal_fwd_bwd(_p(x), x.stride(0) if r else c, _p(target), _p(labels), _p(weights), _p(alpha), float(gamma),
+                                            r, c, int(avg_positives), int(reduction == "mean"), _p(loss), _p(grad), _stream()),
+          "coin_mil_focal_fwd_bwd")
     return loss, grad
 
 

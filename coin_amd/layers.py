@@ -372,6 +372,14 @@ def mil_cross_entropy(x, target=None, labels=None, weights=None, avg_positives=F
                                                    avg_positives=avg_positives, reduction=reduction))
 
 
+def mil_focal_loss(x, alpha, target=None, labels=None, gamma=1.5, avg_positives=True, weights=None, reduction="mean"):
+    """coin/utils/losses.py:36-73 (MILFocalLoss(class_num, alpha=classes_weight), gamma 1.5)."""
+    x = x.float().contiguous()
+    a = alpha.to(device=x.device, dtype=torch.float32).contiguous()
+    return _ScalarLoss.apply(x, lambda t: K.mil_focal(t, a, target=target, labels=labels, gamma=gamma, avg_positives=avg_positives,
+                                                      weights=weights, reduction=reduction))
+
+
 def kl_div_from_logits(scores, q, row_mask=None):
     """KLDivLoss('mean')(log(softmax(scores)+1e-7), q)  (fast_rcnn.py:538,544)."""
     return _ScalarLoss.apply(scores.float().contiguous(), lambda t: K.kl_div(t, q.float().contiguous(), 0, row_mask))

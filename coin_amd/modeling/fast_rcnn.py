@@ -227,8 +227,12 @@ class FastRCNNOutputLayers(nn.Module):
 
     # ------------------------------------------------------------------ helpers
     def _mil(self, scores, labels_or_target, n_fg, n_bg, avg_positives=True, soft=False):
+        if self.loss_type == "MILFocalLoss":  # fast_rcnn.py:468-472,581-582,595-596: always avg_positives, no row weights
+            a = torch.tensor(self.classes_weight, dtype=torch.float32, device=scores.device)
+            kw = {"target": labels_or_target} if soft else {"labels": labels_or_target}
+            return L.mil_focal_loss(scores, a, gamma=1.5, avg_positives=True, **kw)
         if self.loss_type != "MILCrossEntropy":
-            raise NotImplementedError("MILFocalLoss is not on the HIP path (CLOUD.LOSS_TYPE MILCrossEntropy is the shipped config)")
+            raise NotImplementedError(self.loss_type)
         w = torch.cat([torch.ones(n_fg, device=scores.device), torch.full((n_bg,), float(self.classes_weight[-1]), device=scores.device)])
         if soft:
             return L.mil_cross_entropy(scores, target=labels_or_target, weights=w, avg_positives=avg_positives)
@@ -252,13 +256,19 @@ class FastRCNNOutputLayers(nn.Module):
         any_fg = is_fg.any()
         labels = cls.clamp(min=0)
         w = torch.where(is_fg, 1.0, float(self.classes_weight[-1])) * valid.float()
-        if self.loss_type != "MILCrossEntropy":
-            raise NotImplementedError("MILFocalLoss is not on the HIP path")
+        if self.loss_type not in ("MILCrossEntropy", "MILFocalLoss"):
+            raise NotImplementedError(self.loss_type)
+        focal = self.loss_type == "MILFocalLoss"
+        if focal:  # no row weights in the reference (fast_rcnn.py:581-582): the mask only removes the filler rows
+            w = valid.float()
+            alpha = torch.tensor(self.classes_weight, dtype=torch.float32, device=scores.device)
         if self.dataset != ("cliparttrain",):
-            total = L.mil_cross_entropy(scores, labels=labels, weights=w, avg_positives=True, reduction="sum")
+            total = (L.mil_focal_loss(scores, alpha, labels=labels, weights=w, reduction="sum") if focal else
+                     L.mil_cross_entropy(scores, labels=labels, weights=w, avg_positives=True, reduction="sum"))
         else:
             tgt = F.one_hot(labels, kc).float() * torch.where(is_fg, ps.gt_probs.max(1)[0], torch.ones_like(w)).unsqueeze(1)
-            total = L.mil_cross_entropy(scores, target=tgt, weights=w, avg_positives=False, reduction="sum")
+            total = (L.mil_focal_loss(scores, alpha, target=tgt, weights=w, reduction="sum") if focal else
+                     L.mil_cross_entropy(scores, target=tgt, weights=w, avg_positives=False, reduction="sum"))
         losses = {"loss_text_align": lta, "loss_cls": torch.where(any_fg, total / n_valid, torch.zeros_like(total))}
         if update_prototype:
             with torch.no_grad():
@@ -290,11 +300,15 @@ class FastRCNNOutputLayers(nn.Module):
         fa, fb = m_a.float(), m_b.float()
         ag = m_a | m_g
         losses = {"loss_text_align": lta}
-        if self.loss_type != "MILCrossEntropy":
-            raise NotImplementedError("MILFocalLoss is not on the HIP path")
+        if self.loss_type not in ("MILCrossEntropy", "MILFocalLoss"):
+            raise NotImplementedError(self.loss_type)
         labels = torch.where(ag, ps.gt_classes, torch.zeros_like(ps.gt_classes))
-        w = fa + m_g.float() * float(self.classes_weight[-1])
-        total = L.mil_cross_entropy(scores, labels=labels, weights=w, avg_positives=True, reduction="sum")
+        if self.loss_type == "MILFocalLoss":  # fast_rcnn.py:468-472
+            alpha = torch.tensor(self.classes_weight, dtype=torch.float32, device=scores.device)
+            total = L.mil_focal_loss(scores, alpha, labels=labels, weights=ag.float(), reduction="sum")
+        else:
+            w = fa + m_g.float() * float(self.classes_weight[-1])
+            total = L.mil_cross_entropy(scores, labels=labels, weights=w, avg_positives=True, reduction="sum")
         losses["loss_cls"] = total / (n_a + n_g).clamp(min=1).float()
         oh_a = F.one_hot(labels, kc).float() * fa.unsqueeze(1)
         if update_prototype:

@@ -107,6 +107,17 @@ class FusedSGD:
         else:  # groups were edited independently: fall back to uploading the absolute rates
             self._table.step(grads, self.momentum, inv_loss_scale, lrs=[g["lr"] for g in self.param_groups], shadows=shadows)
 
+    def load_momentum(self, bufs):
+        """Momentum buffers from a checkpoint (None entries = that tensor has not been stepped yet)."""
+        if all(b is None for b in bufs):
+            self._table = None
+            return
+        self._table = K.SgdTable(self.params, [g["base_lr"] for g in self.param_groups], [g["weight_decay"] for g in self.param_groups])
+        for dst, src in zip(self._table.bufs, bufs):
+            if src is not None:
+                dst.copy_(src.reshape(dst.shape))
+        self._table.first = False
+
     def state_dict(self):
         bufs = self._table.bufs if self._table is not None else None
         return {"momentum_buffers": bufs, "first": self._table.first if self._table else True,

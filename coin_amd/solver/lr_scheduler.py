@@ -47,5 +47,7 @@ class WarmupTwoStageMultiStepLR:
         return {"last_epoch": self.last_epoch}
 
     def load_state_dict(self, sd):
+        if sd.get("base_lrs") is not None and len(sd["base_lrs"]) == len(self.base_lrs):
+            self.base_lrs = list(sd["base_lrs"])
         self.last_epoch = sd["last_epoch"] - 1
         self.step()

@@ -171,6 +171,15 @@ int coin_mil_ce_fwd_bwd(const float* x, int ldx, const float* target, const int6
                         const float* weights, int R, int C, int avg_positives, int reduction_mean,
                         float* loss, float* grad_x, void* stream);
 
+/* MIL focal loss (coin/utils/losses.py:36-73; selected by CLOUD.LOSS_TYPE "MILFocalLoss", fast_rcnn.py:468-469,581-582,595-596):
+ *   alpha_r = sum_c t*alpha_c / (sum_c t + 1e-6);  P = sum_c t*p / (avg_positives ? sum_c t + 1e-6 : 1),  p = softmax(x) without
+ *   max-subtraction;  l_r = -alpha_r (1 - P)^gamma log P * w_r;  loss = mean_r l_r (reduction_mean; R == 0 -> NaN: torch's mean of
+ *   an empty tensor) or sum_r l_r.  The reference passes no row weights (weights NULL); the fixed-shape sampler uses them as the
+ *   row-validity mask.  alpha [C] float32 (the class weights); other arguments as coin_mil_ce_fwd_bwd. */
+int coin_mil_focal_fwd_bwd(const float* x, int ldx, const float* target, const int64_t* labels,
+                           const float* weights, const float* alpha, float gamma, int R, int C,
+                           int avg_positives, int reduction_mean, float* loss, float* grad_x, void* stream);
+
 /* nn.KLDivLoss(reduction='mean')(log(p + eps), q)  -  ELEMENT mean over R*C, not batchmean
  * (fast_rcnn.py:273,526,538,544; rpn.py:335):   loss = 1/(R*C) * sum q * (log q - log(p+eps)),
  * terms with q == 0 contribute 0.

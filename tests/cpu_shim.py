@@ -38,6 +38,18 @@ def _mil(x, target=None, labels=None, weights=None, avg_positives=False, reducti
     return OL.mil_cross_entropy(x, target, weights, avg_positives, reduction)
 
 
+def _mil_focal(x, alpha, target=None, labels=None, gamma=1.5, avg_positives=True, weights=None, reduction="mean"):
+    if target is None:
+        target = F.one_hot(labels, x.shape[1]).to(x.dtype)
+    if weights is None and reduction == "mean":
+        return OL.mil_focal_loss(x, target, alpha.to(x.dtype), gamma, avg_positives)
+    rows = torch.stack([OL.mil_focal_loss(x[i:i + 1], target[i:i + 1], alpha.to(x.dtype), gamma, avg_positives) for i in range(x.shape[0])]) \
+        if x.shape[0] else x.new_zeros(0)
+    if weights is not None:
+        rows = rows * weights
+    return rows.mean() if reduction == "mean" else rows.sum()
+
+
 def _kl_logits(scores, q, row_mask=None):
     if row_mask is not None:
         scores, q = scores[row_mask], q[row_mask]
@@ -146,7 +158,7 @@ def cpu_kernels():
     import coin_amd.layers as L
 
     patches = {
-        L: dict(linear_act=_linear_act, cosine_logits=_cosine_logits, mil_cross_entropy=_mil, kl_div_from_logits=_kl_logits,
+        L: dict(linear_act=_linear_act, cosine_logits=_cosine_logits, mil_cross_entropy=_mil, mil_focal_loss=_mil_focal, kl_div_from_logits=_kl_logits,
                 kl_div_from_probs=_kl_probs, kl_div_binary=_kl_binary, box_reg_l1=_box_reg, l1_mean=lambda a, b: F.l1_loss(a, b),
                 rpn_losses=_rpn_losses, roi_align=_roi_align, bn_act=_bn_act, avg_pool2=lambda x: F.avg_pool2d(x, 2)),
         K: dict(normalize_pad=_normalize_pad, nms_batched=_nms_batched, SgdTable=_CpuSgdTable, EmaTable=_CpuEmaTable),

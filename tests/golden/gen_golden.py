@@ -371,6 +371,7 @@ def _pack_pretrain_props(props):
 
 def case_box_predictor_pretrain():
     for tag, nfg, nbg, dataset, upd in [
+        ("focal", (5, 0, 3), (9, 6, 4), ("foggytrain_0.02",), True),        # CLOUD.LOSS_TYPE MILFocalLoss (fast_rcnn.py:581-582)
         ("a", (5, 0, 3), (9, 6, 4), ("foggytrain_0.02",), True),
         # NB an image with fg but 0 bg trips the reference's own assert (fast_rcnn.py:383-385: `[-0:]` selects
         # every row), so that shape is not a valid input; an image with neither fg nor bg is.
@@ -380,7 +381,7 @@ def case_box_predictor_pretrain():
     ]:
         torch.manual_seed(31)
         te = build_text_encoder()
-        bp = build_box_predictor(te, in_ch=64, dataset=dataset)
+        bp = build_box_predictor(te, in_ch=64, dataset=dataset, loss_type="MILFocalLoss" if tag == "focal" else "MILCrossEntropy")
         with torch.no_grad():
             bp.cls_score.weight.normal_(std=0.05)
             bp.bbox_pred.weight.normal_(std=0.02)

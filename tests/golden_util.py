@@ -50,8 +50,9 @@ LOSS_W = {"loss_box_reg": 1.0, "loss_box_reg_offline": 1.0, "loss_box_reg_online
           "loss_text_align": 10.0, "loss_distillation": 0.1, "loss_cls_b": 0.1}
 
 
-def tiny_box_predictor(in_ch, dataset=("foggytrain_0.02",)):
-    return OC.BoxPredictor(in_ch, tiny_text_encoder(), TEXT_DIM, [1.0] * K + [0.9], LOSS_W, 32, cls_b_thresh=0.3, dataset=dataset)
+def tiny_box_predictor(in_ch, dataset=("foggytrain_0.02",), loss_type="MILCrossEntropy"):
+    return OC.BoxPredictor(in_ch, tiny_text_encoder(), TEXT_DIM, [1.0] * K + [0.9], LOSS_W, 32, cls_b_thresh=0.3, dataset=dataset,
+                           loss_type=loss_type)
 
 
 def tiny_detector():

@@ -154,6 +154,46 @@ def roi_label_and_sample(device):
             _cmp_inst_exact(bg, z, f"s.o{i}.bg")
 
 
+# ------------------------------------------------------------------------------------------ A7 / A9 / A11: predictor + pre_train losses (fast_rcnn.py:318-438)
+def box_predictor_pretrain(device, tag, tol=1e-4):
+    """FastRCNNOutputLayers.forward + losses('pre_train') of the PRODUCT in the reference's (fg, bg) layout vs box_predictor_pretrain_*.npz
+    (incl. an image without RoIs, no foreground at all, the clipart soft-target branch and CLOUD.LOSS_TYPE MILFocalLoss)."""
+    from coin_amd.box_ops import Box2BoxTransform
+    from coin_amd.modeling.fast_rcnn import FastRCNNOutputLayers
+    from coin_amd.structures import ShapeSpec
+    from golden_util import LOSS_W
+
+    z = load(f"box_predictor_pretrain_{tag}")
+    with kernels_for(device):
+        te = tiny_product_detector().roi_heads.box_predictor.text_encoder
+        bp = FastRCNNOutputLayers(ShapeSpec(channels=64, height=1, width=1), text_encoder=te, pooling_type="meanpool",
+                                  box2box_transform=Box2BoxTransform((10.0, 10.0, 5.0, 5.0)), text_dim=32, classes_weight=[1.0] * K + [0.9],
+                                  loss_type="MILFocalLoss" if tag == "focal" else "MILCrossEntropy", cls_agnostic_bbox_reg=True, loss_weight=LOSS_W,
+                                  batch_size_per_image=32, cls_b_thresh=0.3, dataset=(str(z["dataset"]),), prototype_update_rate=0.9996)
+        load_weights(bp, z)
+        bp.to(device).train()
+        props = [(_inst(z, f"p{i}.fg", (96, 128)).to(device), _inst(z, f"p{i}.bg", (96, 128)).to(device)) for i in range(int(z["n_img"]))]
+        x = T(z["x"]).to(device).requires_grad_(True)
+        preds = bp(x, "pre_train")
+        (scores, lta), deltas, feats = preds
+        close(scores.cpu(), z["scores"], tol, "scores")
+        close(deltas.cpu(), z["deltas"], tol, "deltas")
+        close(feats.cpu(), z["feats"], tol, "feats")
+        losses = bp.losses(preds, props, None, "pre_train", update_prototype=bool(z["update_prototype"]))
+        ref = {k[6:]: float(z[k]) for k in z.files if k.startswith("loss::")}
+        assert set(losses) == set(ref)
+        for k, v in ref.items():
+            assert abs(float(losses[k]) - v) < tol * max(1.0, abs(v)), (tag, k, float(losses[k]), v)
+        sum(losses.values()).backward()
+        close(x.grad.cpu(), z["gx"], tol, "gx")
+        params = dict(bp.named_parameters())
+        for k in z.files:
+            if k.startswith("g::"):
+                g = params[k[3:]].grad
+                close((g if g is not None else torch.zeros_like(params[k[3:]])).cpu(), z[k], tol, k)
+        close(bp.text_encoder.per_class_feat.cpu(), z["prototype_after"], 1e-6, "prototype")
+
+
 # ------------------------------------------------------------------------------------------ whole forward + backward WITH the samplers in the loop
 def e2e_pretrain_with_samplers(device, tol_loss=1e-4, tol_grad=1e-4):
     """OpenVocabularyRCNN.forward('pre_train') with NOTHING fed in: RPN, NMS, anchor labelling, RoI matching + sampling all run and

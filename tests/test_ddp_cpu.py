@@ -101,7 +101,7 @@ def _coin_worker(rank, world, port, out_dir):
 
         def teacher(batched_inputs, branch=None, **kw):
             real_forward(batched_inputs, branch=branch, **kw)
-            return [synthetic_offline_detections(tr.model_CLOUD.get_results()[d["file_name"]], g_det) for d in batched_inputs]
+            return [synthetic_offline_detections(tr.model_CLOUD.entry(d["file_name"]), g_det) for d in batched_inputs]
 
         tr.offline_teacher.forward = teacher
         with torch.no_grad():

@@ -136,7 +136,7 @@ def test_cointrainer_full_size_steps(burned_up, sync_free_step):
     def teacher(batched_inputs, branch=None, **kw):  # the real inference runs; the matcher gets CLIPDET-like detections
         out = real_forward(batched_inputs, branch=branch, **kw)
         assert len(out) == len(batched_inputs)
-        return [synthetic_offline_detections(tr.model_CLOUD.get_results()[d["file_name"]], g_det, device="cuda:0") for d in batched_inputs]
+        return [synthetic_offline_detections(tr.model_CLOUD.entry(d["file_name"]), g_det, device="cuda:0") for d in batched_inputs]
 
     tr.offline_teacher.forward = teacher
     merge_before = [p.detach().clone() for p in tr.merge.parameters()]

@@ -265,7 +265,7 @@ def test_cointrainer_run_step_on_cpu_with_shimmed_kernels(burned_up, sync_free_s
         def teacher(batched_inputs, branch=None, **kw):
             out = real_forward(batched_inputs, branch=branch, **kw)
             assert len(out) == len(batched_inputs) and all("instances" in o for o in out)
-            return [synthetic_offline_detections(tr.model_CLOUD.get_results()[d["file_name"]], g_det) for d in batched_inputs]
+            return [synthetic_offline_detections(tr.model_CLOUD.entry(d["file_name"]), g_det) for d in batched_inputs]
 
         tr.offline_teacher.forward = teacher
         teacher_before = {k: v.clone() for k, v in tr.offline_teacher.state_dict().items()}
@@ -361,7 +361,8 @@ def test_cloud_result_files_cross_the_boundary_in_both_directions(tmp_path):
     assert torch.equal(inst.probs, probs) and res["height"] == 1024 and res["image_id"] == "b"
     inst.pred_boxes.tensor.mul_(0)                        # a deep copy is handed out (gdino_collector.py:83-88)
     assert float(cache("a/b.png")["RCNN"]["instances"].pred_boxes.tensor.abs().sum()) > 0
-    assert cache("missing.png") is None
+    with pytest.raises(KeyError, match="missing.png"):
+        cache("missing.png")
     out = str(tmp_path / "resaved.pth")
     cache.save(out)                                       # written under detectron2's class paths again
     raw = open(out, "rb").read()
@@ -490,6 +491,13 @@ def test_product_rpn_labelling_losses_and_proposals_vs_reference():
     rpn_labelling_losses_and_proposals("cpu")
 
 
+@pytest.mark.parametrize("tag", ["a", "empty_image", "no_fg", "clipart", "focal"])
+def test_product_box_predictor_pretrain_vs_reference(tag):
+    from parity_cases import box_predictor_pretrain
+
+    box_predictor_pretrain("cpu", tag)
+
+
 def test_product_roi_label_and_sample_vs_reference():
     """OpenVocabularyRes5ROIHeads.label_and_sample_proposals (clip_roi_heads.py:283-399) of the PRODUCT vs roi_sampling.npz, both
     branches, bit for bit (GPU twin in tests/test_parity_gpu.py)."""
@@ -522,11 +530,12 @@ def test_pretrain_checkpoint_feeds_cointrainer(tmp_path):
         pre.save(ck)
         blob = load_file(ck)
         assert blob["iteration"] == 0 and set(blob["model"]) == set(pre.model.state_dict())
-        # the synthetic cache is flat (file name -> result); the reference nests it per dataset
+        # the cache already has the reference's {dataset: {file name: result}} layout
         results = str(tmp_path / "GDINO_collect.pth")
         from coin_amd.checkpoint import CloudResults
 
-        CloudResults({"synthetic_voc_train": pre.collect_model.get_results()}).save(results)
+        assert list(pre.collect_model.get_results()) == ["synthetic_voc_train"] and blob["results"].keys() == pre.collect_model.get_results().keys()
+        CloudResults(pre.collect_model.get_results()).save(results)
         cfg2 = get_cfg()
         cfg2.merge_from_file(os.path.join(root, "GDINO", "foggy_synthetic.yaml"))
         cfg2.merge_from_list(tiny + ["MODEL.WEIGHTS", ck + "+" + results])
@@ -535,7 +544,7 @@ def test_pretrain_checkpoint_feeds_cointrainer(tmp_path):
         coin.resume_or_load()
     for k, v in pre.model.state_dict().items():
         assert torch.equal(v, coin.offline_teacher.state_dict()[k]), k
-    name = next(iter(pre.collect_model.get_results()))
+    name = next(iter(pre.collect_model.get_results()["synthetic_voc_train"]))
     assert coin.model_CLOUD(name)["RCNN"]["instances"].pred_boxes.tensor.shape[1] == 4
 
 
@@ -778,7 +787,8 @@ def test_trainers_write_the_reference_named_checkpoints(tmp_path):
         cfg.merge_from_list(tiny + ["OUTPUT_DIR", str(tmp_path / "pre")])
         torch.manual_seed(0)
         PRETrainer(cfg).train()
-        assert sorted(os.listdir(tmp_path / "pre")) == ["model_0000001.pth", "pre_train_CLIP_0000002.pth"]
+        # MyPeriodicCheckpointer(file_prefix=CLOUD.PRE_TRAIN_NAME): CLIP_<iter>.pth every period, CLIP_final.pth at the end (hooks.py:60-84)
+        assert sorted(os.listdir(tmp_path / "pre")) == ["CLIP_0000001.pth", "CLIP_final.pth", "pre_train_CLIP_0000002.pth"]
         assert load_file(str(tmp_path / "pre" / "pre_train_CLIP_0000002.pth"))["iteration"] == 2
         cfg = get_cfg()
         cfg.merge_from_file(os.path.join(root, "GDINO", "foggy_synthetic.yaml"))
@@ -788,8 +798,121 @@ def test_trainers_write_the_reference_named_checkpoints(tmp_path):
         g = torch.Generator().manual_seed(7)
         fwd = tr.offline_teacher.forward
         tr.offline_teacher.forward = lambda bi, branch=None, **kw: (fwd(bi, branch=branch, **kw),
-                                                                    [synthetic_offline_detections(tr.model_CLOUD.get_results()[d["file_name"]], g) for d in bi])[1]
+                                                                    [synthetic_offline_detections(tr.model_CLOUD.entry(d["file_name"]), g) for d in bi])[1]
         tr.train()
-        assert sorted(os.listdir(tmp_path / "coin")) == ["burn_up_0000000.pth", "model_0000001.pth", "model_0000002.pth"]
-        blob = load_file(str(tmp_path / "coin" / "model_0000002.pth"))
+        assert sorted(os.listdir(tmp_path / "coin")) == ["burn_up_0000000.pth", "model_0000001.pth", "model_final.pth"]
+        blob = load_file(str(tmp_path / "coin" / "model_final.pth"))
         assert blob["iteration"] == 2 and any(k.startswith("model_student.") for k in blob["model"])
+
+
+def _tiny_trainer_cfg(kind, extra=()):
+    from coin_amd.config import get_cfg
+
+    tiny = ["MODEL.DEVICE", "cpu", "AMD.COMPUTE_DTYPE", "fp32", "AMD.SYNTHETIC.HEIGHT", 96, "AMD.SYNTHETIC.WIDTH", 128, "AMD.SYNTHETIC.BOXES_PER_IMAGE", 6,
+            "AMD.SYNTHETIC.NUM_IMAGES", 1, "SOLVER.IMG_PER_BATCH_UNLABEL", 1, "AMD.TEXT_TEMPLATES", 1, "MODEL.MERGE_DIM", 32,
+            "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 16, "MODEL.RPN.PRE_NMS_TOPK_TRAIN", 100, "MODEL.RPN.POST_NMS_TOPK_TRAIN", 30,
+            "MODEL.RPN.PRE_NMS_TOPK_TEST", 60, "MODEL.RPN.POST_NMS_TOPK_TEST", 20, "AMD.ARCH.LAYERS", [1, 1, 1, 1], "AMD.ARCH.WIDTH", 8,
+            "AMD.ARCH.TEXT_WIDTH", 32, "AMD.ARCH.TEXT_LAYERS", 2, "AMD.ARCH.TEXT_HEADS", 2, "AMD.ARCH.TEXT_DIM", 32, "AMD.ARCH.CONTEXT_LENGTH", 16,
+            "AMD.ARCH.VOCAB_SIZE", 64, "SOLVER.WARMUP_ITERS", 4, "SOLVER.STEPS", [5], "SOLVER.FACTOR_LIST", [1.0, 0.1]]
+    root = os.path.join(os.path.dirname(GOLDEN), "..", "configs", "coin")
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(root, *kind))
+    cfg.merge_from_list(tiny + list(extra))
+    return cfg
+
+
+def test_cointrainer_resume_restores_schedule_momentum_teacher_and_cache(tmp_path):
+    """trainer.py:220-262 + hooks: a run interrupted after `burn_up_<iter>.pth` and resumed from it (--resume) continues exactly like
+    the uninterrupted run: weights, both optimizers' momentum, both schedules, the teacher BEFORE the next iteration's EMA, the
+    cloud cache.  Without --resume only the weights and `scheduler.last_epoch` are taken (trainer.py:243-247)."""
+    import random
+
+    from coin_amd.checkpoint import load_file
+    from coin_amd.data.synthetic import synthetic_offline_detections
+    from coin_amd.engine import CoinTrainer
+
+    def make(extra):
+        cfg = _tiny_trainer_cfg(("GDINO", "foggy_synthetic.yaml"), ["CLOUD.BURN_UP_STEP", 2, "CLOUD.PROTOTYPE_UPDATE_START", 0, "SOLVER.MAX_ITER", 4,
+                                                                    "SOLVER.CHECKPOINT_PERIOD", 100] + extra)
+        torch.manual_seed(0)
+        tr = CoinTrainer(cfg)
+        fwd = tr.offline_teacher.forward
+
+        def teacher(bi, branch=None, **kw):  # detections, matcher tie-breaks and sampler draws are a function of the iteration only
+            fwd(bi, branch=branch, **kw)
+            random.seed(tr.iter)
+            torch.manual_seed(1000 + tr.iter)
+            g = torch.Generator().manual_seed(100 + tr.iter)
+            return [synthetic_offline_detections(tr.model_CLOUD.entry(d["file_name"]), g) for d in bi]
+
+        tr.offline_teacher.forward = teacher
+        return tr
+
+    with cpu_kernels():
+        a = make(["OUTPUT_DIR", str(tmp_path / "a")])
+        teacher0 = {k: v.clone() for k, v in a.offline_teacher.state_dict().items()}
+        a.train()                                               # uninterrupted: 4 iterations, teacher EMA from iteration 2 on
+        assert any(not torch.equal(v, teacher0[k]) for k, v in a.offline_teacher.state_dict().items() if v.is_floating_point())
+        ck = str(tmp_path / "a" / "burn_up_0000001.pth")
+        blob = load_file(ck)
+        assert {"optimizer", "optimizer_merge", "scheduler", "scheduler_merge", "online_results"} <= set(blob) and blob["iteration"] == 1
+        assert blob["scheduler"]["last_epoch"] == 2 and len(blob["optimizer"]["state"]) > 0
+        # the checkpoint holds the teacher as iteration 1 left it: the EMA of iteration 2 has not been applied (trainer.py:149-172)
+        for k, v in teacher0.items():
+            assert torch.equal(blob["model"]["offline_teacher." + k], v), k
+        b = make(["OUTPUT_DIR", str(tmp_path / "b"), "MODEL.WEIGHTS", ck])
+        b.resume_or_load(resume=True)
+        assert b.iter == b.start_iter == 2 and b.scheduler.last_epoch == 2 and b.scheduler_merge.last_epoch == 2
+        for g, st in zip(b.optimizer.param_groups, blob["optimizer"]["param_groups"]):
+            assert g["lr"] == st["lr"] and g["base_lr"] == st["initial_lr"]
+        assert b.optimizer._table is not None and not b.optimizer._table.first
+        for i, st in blob["optimizer"]["state"].items():
+            assert torch.equal(b.optimizer._table.bufs[i], st["momentum_buffer"])
+        assert list(b.model_CLOUD.get_results()) == ["synthetic_voc_train"]
+        b.train()                                               # iterations 2 and 3
+        for name in ("model", "merge", "offline_teacher"):
+            for k, v in getattr(a, name).state_dict().items():
+                assert torch.equal(v, getattr(b, name).state_dict()[k]), (name, k)
+        c = make(["MODEL.WEIGHTS", ck])
+        c.resume_or_load(resume=False)
+        assert c.iter == 2 and c.scheduler.last_epoch == 1 and c.optimizer._table is None  # trainer.py:246-247: last_epoch = iteration
+        c.scheduler.step()
+        assert c.scheduler.last_epoch == 2 and abs(c.optimizer.param_groups[0]["lr"] - blob["optimizer"]["param_groups"][0]["lr"]) < 1e-12
+
+
+def test_pretrainer_resume_and_load_models_flag(tmp_path):
+    """pre_train.py:238-279: weights are loaded with and without --resume, start_iter = iteration + 1, --resume restores optimizer and
+    schedule, a file with ``load_models: False`` (the collection run's CLIP_-0000001.pth) keeps the fresh initialisation."""
+    from coin_amd.checkpoint import load_file
+    from coin_amd.engine import PRETrainer
+
+    with cpu_kernels():
+        cfg = _tiny_trainer_cfg(("PRETRAINS", "CLIPDET_synthetic.yaml"), ["SOLVER.MAX_ITER", 3, "SOLVER.CHECKPOINT_PERIOD", 2, "OUTPUT_DIR", str(tmp_path / "a")])
+        torch.manual_seed(0)
+        a = PRETrainer(cfg)
+        a.train()
+        ck = str(tmp_path / "a" / "CLIP_0000001.pth")
+        blob = load_file(ck)
+        assert blob["iteration"] == 1 and "load_models" not in blob and blob["scheduler"]["last_epoch"] == 2
+        for resume in (False, True):
+            cfg_b = _tiny_trainer_cfg(("PRETRAINS", "CLIPDET_synthetic.yaml"), ["SOLVER.MAX_ITER", 3, "MODEL.WEIGHTS", ck])
+            torch.manual_seed(1)
+            b = PRETrainer(cfg_b)
+            b.resume_or_load(resume=resume)
+            assert b.iter == b.start_iter == 2
+            for k, v in blob["model"].items():
+                assert torch.equal(b.model.state_dict()[k], v), k
+            assert (b.scheduler.last_epoch == 2 and b.optimizer._table is not None) == resume
+            assert list(b.collect_model.get_results()) == ["synthetic_voc_train"]
+        # the collection run's file: results only, the freshly initialised weights stay
+        coll = str(tmp_path / "CLIP_-0000001.pth")
+        a.save(coll, iteration=-1, load_models=False)
+        assert load_file(coll)["load_models"] is False
+        cfg_c = _tiny_trainer_cfg(("PRETRAINS", "CLIPDET_synthetic.yaml"), ["MODEL.WEIGHTS", coll])
+        torch.manual_seed(2)
+        c = PRETrainer(cfg_c)
+        fresh = {k: v.clone() for k, v in c.model.state_dict().items()}
+        c.resume_or_load(resume=True)
+        assert c.iter == 0
+        for k, v in fresh.items():
+            assert torch.equal(c.model.state_dict()[k], v), k

@@ -241,6 +241,33 @@ def test_mil_ce_golden_and_grad(K):
     assert float(l) == 0.0 == float(z["ce_empty"])
 
 
+def test_mil_focal_golden_and_grad(K):
+    """coin_mil_focal_fwd_bwd vs the values captured from the reference's MILFocalLoss (losses.py:36-73) and the oracle's autograd."""
+    from oracle import losses as OL
+
+    z = load_golden("mil_losses")
+    x, hard, soft, alpha = (torch.from_numpy(z[k]) for k in ("x", "hard", "soft", "focal_alpha"))
+    l, _ = K.mil_focal(dev(x), dev(alpha), target=dev(hard), avg_positives=True)
+    assert abs(float(l) - float(z["focal_hard_avg"])) < 1e-5 * max(1.0, abs(float(z["focal_hard_avg"])))
+    l, _ = K.mil_focal(dev(x), dev(alpha), labels=dev(hard.argmax(1)), avg_positives=True)
+    assert abs(float(l) - float(z["focal_hard_avg"])) < 1e-5 * max(1.0, abs(float(z["focal_hard_avg"])))
+    l, gr = K.mil_focal(dev(x), dev(alpha), target=dev(soft + 1e-3), avg_positives=False)
+    assert abs(float(l) - float(z["focal_soft_noavg"])) < 1e-5 * max(1.0, abs(float(z["focal_soft_noavg"])))
+    xr = x.clone().double().requires_grad_(True)
+    OL.mil_focal_loss(xr, (soft + 1e-3).double(), alpha.double(), avg_positives=False).backward()
+    torch.testing.assert_close(gr.cpu().double(), xr.grad, rtol=1e-4, atol=1e-7)
+    # row weights / sum reduction (the fixed-shape sampler's validity mask) and the empty input
+    w = (torch.arange(40) % 3 != 0).float()
+    l, gr = K.mil_focal(dev(x), dev(alpha), target=dev(hard), weights=dev(w), reduction="sum")
+    xr = x.clone().double().requires_grad_(True)
+    ref = sum(OL.mil_focal_loss(xr[i:i + 1], hard[i:i + 1].double(), alpha.double()) * w[i] for i in range(40))
+    ref.backward()
+    assert abs(float(l) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    torch.testing.assert_close(gr.cpu().double(), xr.grad, rtol=1e-4, atol=1e-7)
+    l, _ = K.mil_focal(dev(x[:0]), dev(alpha), target=dev(hard[:0]))
+    assert np.isnan(float(l))  # torch's mean over zero rows, as the reference
+
+
 def test_mil_ce_vs_oracle_large(K):
     from oracle import losses as OL
 

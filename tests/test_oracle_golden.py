@@ -118,10 +118,10 @@ def _pretrain_props(z, n_img):
     return [(instances(z, f"p{i}.fg", (96, 128)), instances(z, f"p{i}.bg", (96, 128))) for i in range(n_img)]
 
 
-@pytest.mark.parametrize("tag", ["a", "empty_image", "no_fg", "clipart"])
+@pytest.mark.parametrize("tag", ["a", "empty_image", "no_fg", "clipart", "focal"])
 def test_box_predictor_pretrain(tag):
     z = load(f"box_predictor_pretrain_{tag}")
-    bp = tiny_box_predictor(64, dataset=(str(z["dataset"]),))
+    bp = tiny_box_predictor(64, dataset=(str(z["dataset"]),), loss_type="MILFocalLoss" if tag == "focal" else "MILCrossEntropy")
     load_weights(bp, z)
     bp.train()
     x = T(z["x"]).requires_grad_(True)

@@ -30,6 +30,11 @@ def test_roi_label_and_sample_on_device_vs_reference():
     PC.roi_label_and_sample(DEV)
 
 
+@pytest.mark.parametrize("tag", ["a", "empty_image", "no_fg", "clipart", "focal"])
+def test_box_predictor_pretrain_on_device_vs_reference(tag):
+    PC.box_predictor_pretrain(DEV, tag)
+
+
 def test_cointrainer_run_step_on_device_vs_reference_scripted_iteration():
     PC.cointrainer_scripted_iteration(DEV, tol=2e-5)
 

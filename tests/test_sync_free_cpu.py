@@ -40,7 +40,7 @@ def test_sample_masks_counts_and_membership():
 def test_losses_packed_equal_reference_losses_on_the_same_samples():
     from coin_amd.modeling.roi_heads import PackedSamples
 
-    for tag in ("a", "empty_image", "no_fg", "clipart"):
+    for tag in ("a", "empty_image", "no_fg", "clipart", "focal"):
         z = load(f"box_predictor_pretrain_{tag}")
         with cpu_kernels():
             det = tiny_product_detector()
@@ -51,8 +51,8 @@ def test_losses_packed_equal_reference_losses_on_the_same_samples():
 
             bp = FastRCNNOutputLayers(ShapeSpec(channels=64, height=1, width=1), text_encoder=det.roi_heads.box_predictor.text_encoder,
                                       pooling_type="meanpool", box2box_transform=Box2BoxTransform((10.0, 10.0, 5.0, 5.0)), text_dim=32,
-                                      classes_weight=[1.0] * K + [0.9], loss_type="MILCrossEntropy", cls_agnostic_bbox_reg=True,
-                                      loss_weight=LOSS_W, batch_size_per_image=32, cls_b_thresh=0.3, dataset=(str(z["dataset"]),),
+                                      classes_weight=[1.0] * K + [0.9], loss_type="MILFocalLoss" if tag == "focal" else "MILCrossEntropy",
+                                      cls_agnostic_bbox_reg=True, loss_weight=LOSS_W, batch_size_per_image=32, cls_b_thresh=0.3, dataset=(str(z["dataset"]),),
                                       prototype_update_rate=0.9996)
             load_weights(bp, z)
             bp.train()

@@ -41,15 +41,18 @@ def main():
 
     def teacher(batched_inputs, branch=None, **kw):  # real teacher inference is executed and timed; its (random-init) detections
         real_forward(batched_inputs, branch=branch, **kw)  # are replaced by CLIPDET-like ones so that A/B/C sets are populated
-        return [synthetic_offline_detections(tr.model_CLOUD.get_results()[d["file_name"]], g, device="cuda:0") for d in batched_inputs]
+        return [synthetic_offline_detections(tr.model_CLOUD.entry(d["file_name"]), g, device="cuda:0") for d in batched_inputs]
 
     tr.offline_teacher.forward = teacher
+    tr.max_iter = 10 ** 9
     for _ in range(args.warmup):
         tr.run_step()
+        tr.prepare_next()   # as CoinTrainer.train(): the next iteration's teacher pass / matching overlaps this backward
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         rec = tr.run_step()
+        tr.prepare_next()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     print(json.dumps({"workload": "targetDET " + ("step_two" if args.step_two else "step_one") + (" sync-free" if args.sync_free_step else ""), "images_per_step": args.images, "ms_per_step": dt * 1e3,

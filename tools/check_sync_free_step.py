@@ -23,7 +23,7 @@ real_forward, g = tr.offline_teacher.forward, torch.Generator().manual_seed(7)
 
 def teacher(batched_inputs, branch=None, **kw):
     real_forward(batched_inputs, branch=branch, **kw)
-    return [synthetic_offline_detections(tr.model_CLOUD.get_results()[d["file_name"]], g, device="cuda:0") for d in batched_inputs]
+    return [synthetic_offline_detections(tr.model_CLOUD.entry(d["file_name"]), g, device="cuda:0") for d in batched_inputs]
 
 
 tr.offline_teacher.forward = teacher
