@@ -185,9 +185,9 @@ class CLIP_TEXT(nn.Module):
         for ci in range(len(self.classes)):
             toks = torch.zeros(self.n_templates, enc.context_length, dtype=torch.int)
             for t in range(self.n_templates):
-                length = int(torch.randint(6, min(14, enc.context_length - 2), (1,), generator=g))
+                length = int(torch.randint(6, min(14, enc.context_length - 2), (1,), generator=g, device="cpu"))
                 hi = min(enc.vocab_size - 2, 40000)
-                body = torch.randint(min(300, hi // 4), hi, (length,), generator=g)
+                body = torch.randint(min(300, hi // 4), hi, (length,), generator=g, device="cpu")
                 body[-2] = (1000 + ci) % (enc.vocab_size - 2)
                 sos, eot = (SOS, EOT) if enc.vocab_size >= 49408 else (enc.vocab_size - 2, enc.vocab_size - 1)
                 seq = torch.cat([torch.tensor([sos]), body, torch.tensor([eot])])

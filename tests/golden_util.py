@@ -77,8 +77,8 @@ def load_weights(module, z, prefix="w::", strict=True):
 
 
 def close(a, b, tol=1e-4, what=""):
-    a = torch.as_tensor(np.asarray(a)).double() if not isinstance(a, torch.Tensor) else a.detach().double()
-    b = torch.as_tensor(np.asarray(b)).double() if not isinstance(b, torch.Tensor) else b.detach().double()
+    a = torch.as_tensor(np.asarray(a)).double() if not isinstance(a, torch.Tensor) else a.detach().cpu().double()
+    b = torch.as_tensor(np.asarray(b)).double() if not isinstance(b, torch.Tensor) else b.detach().cpu().double()
     assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
     scale = max(1.0, float(b.abs().max())) if b.numel() else 1.0
     err = float((a - b).abs().max()) if b.numel() else 0.0

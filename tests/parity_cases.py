@@ -310,3 +310,189 @@ def cointrainer_scripted_iteration(device, tol=1e-5):
         if k.startswith("s_after::"):
             close(sd[k[9:]].cpu(), z[k], tol, "student " + k[9:])
     assert tr.iter == 1 and tr.WEIGHT_FOR_BOX_A == 0.5
+
+
+# ------------------------------------------------------------------------------------------ sync-free (packed) losses
+def losses_packed_pretrain(device):
+    """`losses_packed` (fixed-shape rows with per-row labels / validity) == FastRCNNOutputLayers.losses('pre_train') of the reference
+    on the same rows, with invalid filler rows appended (they must not change anything)."""
+    from coin_amd.box_ops import Box2BoxTransform
+    from coin_amd.modeling.fast_rcnn import FastRCNNOutputLayers
+    from coin_amd.modeling.roi_heads import PackedSamples
+    from coin_amd.structures import ShapeSpec
+    from golden_util import LOSS_W
+
+    dev = torch.device(device)
+    for tag in ("a", "empty_image", "no_fg", "clipart", "focal"):
+        z = load(f"box_predictor_pretrain_{tag}")
+        with kernels_for(device):
+            det = tiny_product_detector()
+            bp = FastRCNNOutputLayers(ShapeSpec(channels=64, height=1, width=1), text_encoder=det.roi_heads.box_predictor.text_encoder,
+                                      pooling_type="meanpool", box2box_transform=Box2BoxTransform((10.0, 10.0, 5.0, 5.0)), text_dim=32,
+                                      classes_weight=[1.0] * K + [0.9], loss_type="MILFocalLoss" if tag == "focal" else "MILCrossEntropy",
+                                      cls_agnostic_bbox_reg=True, loss_weight=LOSS_W, batch_size_per_image=32, cls_b_thresh=0.3, dataset=(str(z["dataset"]),),
+                                      prototype_update_rate=0.9996)
+            load_weights(bp, z)
+            bp.to(dev).train()
+            n_img = int(z["n_img"])
+            boxes, cls, gtb, prs = [], [], [], []
+            for i in range(n_img):
+                fg, bg = _inst(z, f"p{i}.fg", (96, 128)).to(dev), _inst(z, f"p{i}.bg", (96, 128)).to(dev)
+                boxes += [fg.proposal_boxes.tensor, bg.proposal_boxes.tensor]
+                cls += [fg.gt_classes_offline, bg.gt_classes]
+                gtb += [fg.gt_boxes.tensor, bg.proposal_boxes.tensor]
+                prs += [fg.gt_probs_offline, torch.zeros(len(bg), K + 1, device=dev)]
+            x = T(z["x"]).to(dev)
+            # 3 invalid filler rows (fewer candidates than the batch size): they must not change anything
+            filler = torch.tensor([[1.0, 1, 20, 20]] * 3, device=dev)
+            x_ext = torch.cat([x, torch.randn(3, x.shape[1]).to(dev)]).requires_grad_(True)
+            ps = PackedSamples(torch.cat(boxes + [filler]), torch.cat(cls + [torch.full((3,), -1, device=dev)]),
+                               torch.cat(gtb + [filler]), torch.cat(prs + [torch.zeros(3, K + 1, device=dev)]), 0)
+            preds = bp(x_ext, "pre_train")
+            losses = bp.losses_packed(preds, ps, update_prototype=bool(z["update_prototype"]))
+            ref = {k[6:]: float(z[k]) for k in z.files if k.startswith("loss::")}
+            assert set(losses) == set(ref)
+            for k, v in ref.items():
+                assert abs(float(losses[k]) - v) < 1e-4 * max(1.0, abs(v)), (tag, k, float(losses[k]), v)
+            sum(losses.values()).backward()
+            close(x_ext.grad[: x.shape[0]], z["gx"], 1e-5 if str(device) == "cpu" else 1e-4, "gx")
+            assert float(x_ext.grad[x.shape[0]:].abs().max()) == 0.0
+            close(bp.text_encoder.per_class_feat, z["prototype_after"], 1e-6, "prototype")
+
+
+def losses_packed_step(device, tag):
+    """`losses_packed_step` (row roles + masks, no host-side row counts) == FastRCNNOutputLayers.losses(step_one / step_two) of
+    the reference on the same A / B / background rows, with filler rows interleaved; the masked `merge_grad_loss` reproduces
+    gradient_discrepancy_loss and the CKG gradients."""
+    from coin_amd.modeling.roi_heads import PackedStepSamples
+    from coin_amd.modeling.text_encoder import CKGNet
+    from e2e_util import _product_box_predictor
+
+    dev = torch.device(device)
+    z = load(f"box_predictor_{tag}")
+    branch = str(z["branch"])
+    with kernels_for(device):
+        bp = _product_box_predictor()
+        load_weights(bp, z)
+        merge = CKGNet(32, 32, K + 1, head_num=4)
+        load_weights(merge, z, "m::")
+        bp.to(dev).train()
+        merge.to(dev)
+        n_img = int(z["n_img"])
+        size = (96, 128)
+        x_ref = T(z["x"]).to(dev)
+        rows, role, cls, con, coff, gtb, pon, poff, boxes = [], [], [], [], [], [], [], [], []
+        cursor = 0
+        zero_p = lambda n: torch.zeros(n, K + 1, device=dev)
+        zl = lambda n: torch.zeros(n, dtype=torch.long, device=dev)
+        for i in range(n_img):
+            a, b, g = (_inst(z, f"p{i}.{t}", size).to(dev) for t in ("a", "b", "bg"))
+            for inst, r in ((a, 0), (b, 1), (g, 2)):
+                n = len(inst)
+                rows.append(x_ref[cursor:cursor + n])
+                cursor += n
+                role.append(torch.full((n,), r, device=dev))
+                boxes.append(inst.proposal_boxes.tensor)
+                if r == 0:
+                    cls.append(inst.gt_classes), con.append(zl(n)), coff.append(zl(n))
+                    gtb.append(inst.gt_boxes.tensor), pon.append(inst.gt_probs_online), poff.append(inst.gt_probs_offline)
+                elif r == 1:
+                    cls.append(zl(n)), con.append(inst.gt_classes_online), coff.append(inst.gt_classes_offline)
+                    gtb.append(inst.gt_boxes.tensor), pon.append(inst.gt_probs_online), poff.append(inst.gt_probs_offline)
+                else:
+                    cls.append(inst.gt_classes), con.append(zl(n)), coff.append(zl(n))
+                    gtb.append(inst.proposal_boxes.tensor), pon.append(zero_p(n)), poff.append(zero_p(n))
+            # two filler rows after every image
+            fb = torch.tensor([[1.0, 1, 20, 20]] * 2, device=dev)
+            rows.append(torch.randn(2, x_ref.shape[1]).to(dev)), role.append(torch.full((2,), -1, device=dev)), boxes.append(fb)
+            cls.append(zl(2)), con.append(zl(2)), coff.append(zl(2))
+            gtb.append(fb), pon.append(zero_p(2)), poff.append(zero_p(2))
+        assert cursor == x_ref.shape[0]
+        x = torch.cat(rows).requires_grad_(True)
+        role_t = torch.cat(role)
+        has_b = bool((role_t == 1).any())
+        ps = PackedStepSamples(torch.cat(boxes), role_t, torch.cat(cls), torch.cat(con), torch.cat(coff), torch.cat(gtb), torch.cat(pon),
+                               torch.cat(poff), 0, n_img, has_b)
+        cs = [_inst(z, f"p{i}.c", size).to(dev) for i in range(n_img)]
+        xc = T(z["xc"]).to(dev)
+        preds = bp(x, branch)
+        cpred = bp(xc, branch, return_feats=False) if xc.shape[0] else None
+        losses = bp.losses_packed_step(preds, ps, cpred, cs if xc.shape[0] else None, merge, branch, update_prototype=bool(z["update_prototype"]))
+        ref = {k[6:]: float(z[k]) for k in z.files if k.startswith("loss::")}
+        got = {k: float(v) for k, v in losses.items()}
+        if "loss_merge_a" in losses:
+            lg = bp.merge_grad_loss()
+            got["loss_merge_grad"] = float(lg)
+            (lg + losses["loss_merge_base"]).backward(inputs=list(merge.parameters()), retain_graph=True)
+            for n, p in merge.named_parameters():
+                close(p.grad, z["mg::" + n], 2e-4, n)
+        if "loss_cls_b" in got and "loss_cls_b" not in ref:  # no B row passed the threshold: the reference omits the (zero) term
+            assert got.pop("loss_cls_b") == 0.0
+        assert set(got) == set(ref), (sorted(got), sorted(ref))
+        for k, v in ref.items():
+            assert abs(got[k] - v) < 1e-4 * max(1.0, abs(v)), (tag, k, got[k], v)
+        skip = ["loss_merge_grad", "loss_merge_a", "loss_merge_b", "loss_merge_base"] + ([] if branch == "step_two" else ["loss_cls_b"])
+        sum(v for k, v in losses.items() if k not in skip).backward()
+        real = role_t >= 0
+        close(x.grad[real], z["gx"], 1e-5 if str(device) == "cpu" else 1e-4, "gx")
+        assert float(x.grad[~real].abs().max()) == 0.0
+        te = bp.text_encoder
+        for name, buf in (("prototype_after", te.per_class_feat), ("prototype_b_online_after", te.prototype_b_online), ("prototype_b_offline_after", te.prototype_b_offline)):
+            close(buf, z[name], 1e-6, name)
+        params = dict(bp.named_parameters())
+        for k in z.files:
+            if k.startswith("g::"):
+                close(params[k[3:]].grad, z[k], 1e-4, k)
+
+
+# ------------------------------------------------------------------------------------------ (f)-4: CLIP-teacher relabelling (clip_rcnn.py:87-132)
+def clip_relabel(device):
+    """coin_amd CLIP meta-arch + CLIPRes5ROIHeads + AttentionPool2d against the reference's CLIP teacher (tests/golden/clip_relabel.npz):
+    attention pooling, relabelled boxes with their full probabilities, background filter."""
+    from coin_amd.modeling.backbone import CLIP_IMAGE
+    from coin_amd.modeling.meta_arch import CLIP
+    from coin_amd.modeling.roi_heads import CLIPRes5ROIHeads, ROIPooler
+    from coin_amd.modeling.text_encoder import CLIP_TEXT
+    from coin_amd.structures import Boxes, Instances
+
+    dev = torch.device(device)
+    z = load("clip_relabel")
+    with kernels_for(device):
+        bb = CLIP_IMAGE("RN50", freeze_at=2, layers=(1, 1, 2, 2), width=8, attnpool_dim=32, attnpool_heads=4)
+        load_weights(bb, z, "bb::")
+        toks = torch.zeros(K + 1, 16, dtype=torch.int)
+        for i in range(K + 1):
+            seq = [62, 1, 2, 3, 1, 6, 6, 6, 6, 10 + i, 5, 63]
+            toks[i, : len(seq)] = torch.tensor(seq)
+        te = CLIP_TEXT("RN50", ["car", "person", "bus", "backgroud"], embed_dim=32, context_length=16, vocab_size=64, width=32, heads=2, layers=2,
+                       tokenized_prompts=toks, n_templates=2)
+        load_weights(te, z, "te::")
+        heads = CLIPRes5ROIHeads(in_features=["res4"], pooler=ROIPooler(14, (1.0 / 16,), 0, "ROIAlignV2"), text_encoder=te)
+        model = CLIP(backbone=bb, roi_heads=heads, pixel_mean=[0.48145466, 0.4578275, 0.40821073], pixel_std=[0.26862954, 0.26130258, 0.27577711],
+                     device=str(device))
+        model.to(dev).eval()
+        with torch.no_grad():
+            close(bb.attnpool(T(z["attn_x"]).to(dev)), z["attn_y"], 1e-5 if str(device) == "cpu" else 1e-4, "attnpool")
+        h, w = (int(v) for v in z["hw"])
+        probs = T(z["probs"]).to(dev)
+
+        def inst(n=None):
+            r = Instances((h, w))
+            r.pred_boxes = Boxes(T(z["boxes"]).to(dev))
+            r.scores, r.pred_classes, r.probs = probs[:, :-1].max(1).values, probs[:, :-1].argmax(1), probs
+            return r if n is None else r[:n]
+
+        pre = {"file_name": "x.png", "image_id": "x", "height": h, "width": w, "RCNN": {"instances": inst()}, "RPN": {"instances": inst(4)}}
+        binp = [{"image": T(z["img"]).to(dev), "height": h, "width": w, "file_name": "x.png", "image_id": "x"}]
+        out = model(binp, pre)
+        for tag in ("RCNN", "RPN"):
+            got = out[tag]["instances"]
+            assert len(got) == int(z["n_" + tag])
+            assert torch.equal(got.pred_classes.cpu(), T(z[f"out_{tag}.pred_classes"]).long())
+            close(got.probs, z[f"out_{tag}.probs"], 1e-4, tag + " probs")
+            close(got.scores, z[f"out_{tag}.scores"], 1e-4, tag + " scores")
+            close(got.pred_boxes.tensor, z[f"out_{tag}.pred_boxes"], 0, tag + " boxes")
+        assert out["height"] == h and out["file_name"] == "x.png"
+        with torch.no_grad():
+            te.per_class_feat[K] = T(z["bg_embedding_2"]).to(dev)
+        assert len(model(binp, pre)["RCNN"]["instances"]) == int(z["n2_RCNN"])

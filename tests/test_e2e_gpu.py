@@ -12,25 +12,27 @@ from golden_util import close
 pytestmark = pytest.mark.gpu
 
 
-def _check(losses, grads, case, tol_loss, exact, what):
-    """Losses: 1e-4 against the reference's values.  Gradients (row P, relative to the tensor's scale): the reference's fp32 values
-    are themselves 1e-3..2e-3 away from the exact gradient on the backbone / res5 tensors of this tiny net (train-mode BatchNorm
-    over a few hundred samples; profiles/r2_grad_precision_study.md), so each tensor is held to
-    max(1e-4, 2 x the reference's own fp32 error) against an fp64 run of the oracle -- the heads get 1e-4."""
+def check_grads(grads, ref_grads, g64, what):
+    """Row P, gradients relative to the tensor's scale.  The heads (RPN head, box predictor, prompt vectors) are held to 1e-4 of the
+    exact (fp64) gradient.  Everything behind train-mode BatchNorm over the few hundred samples of this tiny net (backbone / res5) is
+    not representable to 1e-4 in fp32 at all: the REFERENCE's own fp32 values are 1e-3..2e-3 away from the exact gradient
+    (profiles/r2_grad_precision_study.md).  Those tensors are held to 2 x the largest error the reference itself shows on any of
+    them -- a measured floor of the net, not a per-tensor excuse."""
     from real_width import rel_err
 
+    rows = [(k, rel_err(grads[k], g64[k]), rel_err(ref, g64[k]), rel_err(grads[k], ref)) for k, ref in ref_grads.items()]
+    print("\n".join(f"{what} {k:62s} product vs fp64 {a:.2e}   reference vs fp64 {b:.2e}   product vs reference {c:.2e}" for k, a, b, c in rows))
+    floor = max([b for k, a, b, c in rows if k.startswith("backbone.")] + [0.0])
+    for k, a, b, c in rows:
+        bound = max(1e-4, 2.0 * floor) if k.startswith("backbone.") else 1e-4
+        assert a <= bound, f"{what} {k}: {a:.2e} from the exact gradient (bound {bound:.2e}; the reference's fp32 floor on this net {floor:.2e})"
+
+
+def _check(losses, grads, case, tol_loss, exact, what):
     assert set(losses) == set(case["ref_losses"])
     for k, ref in case["ref_losses"].items():
         assert abs(float(losses[k]) - ref) < tol_loss * max(1.0, abs(ref)), (k, float(losses[k]), ref)
-    _, g64 = exact
-    rows = []
-    for k, ref in case["ref_grads"].items():
-        e_ref, e_got = rel_err(ref, g64[k]), rel_err(grads[k], g64[k])
-        rows.append(f"{what} {k:62s} product vs fp64 {e_got:.2e}   reference vs fp64 {e_ref:.2e}   product vs reference {rel_err(grads[k], ref):.2e}")
-    print("\n".join(rows))
-    for k, ref in case["ref_grads"].items():
-        bound = max(1e-4, 2.0 * rel_err(ref, g64[k]))
-        assert rel_err(grads[k], g64[k]) <= bound, (k, rel_err(grads[k], g64[k]), bound)
+    check_grads(grads, case["ref_grads"], exact[1], what)
 
 
 def test_pretrain_step_fp32_vs_reference_golden_and_oracle():

@@ -620,54 +620,9 @@ def test_load_voc_instances_vs_reference(tmp_path):
 
 # ------------------------------------------------------------------------------------------ CLIP-teacher relabelling
 def test_product_clip_relabel_vs_reference():
-    """coin_amd CLIP meta-arch + CLIPRes5ROIHeads + AttentionPool2d (kernels shimmed) against the reference's CLIP teacher
-    (tests/golden/clip_relabel.npz): attention pooling, relabelled boxes with their full probabilities, background filter."""
-    from coin_amd.modeling.backbone import CLIP_IMAGE
-    from coin_amd.modeling.meta_arch import CLIP
-    from coin_amd.modeling.roi_heads import CLIPRes5ROIHeads, ROIPooler
-    from coin_amd.modeling.text_encoder import CLIP_TEXT
-    from coin_amd.structures import Boxes, Instances
+    from parity_cases import clip_relabel
 
-    z = load("clip_relabel")
-    with cpu_kernels():
-        bb = CLIP_IMAGE("RN50", freeze_at=2, layers=(1, 1, 2, 2), width=8, attnpool_dim=32, attnpool_heads=4)
-        load_weights(bb, z, "bb::")
-        toks = torch.zeros(K + 1, 16, dtype=torch.int)
-        for i in range(K + 1):
-            seq = [62, 1, 2, 3, 1, 6, 6, 6, 6, 10 + i, 5, 63]
-            toks[i, : len(seq)] = torch.tensor(seq)
-        te = CLIP_TEXT("RN50", ["car", "person", "bus", "backgroud"], embed_dim=32, context_length=16, vocab_size=64, width=32, heads=2, layers=2,
-                       tokenized_prompts=toks, n_templates=2)
-        load_weights(te, z, "te::")
-        heads = CLIPRes5ROIHeads(in_features=["res4"], pooler=ROIPooler(14, (1.0 / 16,), 0, "ROIAlignV2"), text_encoder=te)
-        model = CLIP(backbone=bb, roi_heads=heads, pixel_mean=[0.48145466, 0.4578275, 0.40821073], pixel_std=[0.26862954, 0.26130258, 0.27577711],
-                     device="cpu")
-        model.eval()
-        with torch.no_grad():
-            close(bb.attnpool(T(z["attn_x"])), z["attn_y"], 1e-5, "attnpool")
-        h, w = (int(v) for v in z["hw"])
-        probs = T(z["probs"])
-
-        def inst(n=None):
-            r = Instances((h, w))
-            r.pred_boxes = Boxes(T(z["boxes"]))
-            r.scores, r.pred_classes, r.probs = probs[:, :-1].max(1).values, probs[:, :-1].argmax(1), probs
-            return r if n is None else r[:n]
-
-        pre = {"file_name": "x.png", "image_id": "x", "height": h, "width": w, "RCNN": {"instances": inst()}, "RPN": {"instances": inst(4)}}
-        binp = [{"image": T(z["img"]), "height": h, "width": w, "file_name": "x.png", "image_id": "x"}]
-        out = model(binp, pre)
-        for tag in ("RCNN", "RPN"):
-            got = out[tag]["instances"]
-            assert len(got) == int(z["n_" + tag])
-            assert torch.equal(got.pred_classes, T(z[f"out_{tag}.pred_classes"]).long())
-            close(got.probs, z[f"out_{tag}.probs"], 1e-4, tag + " probs")
-            close(got.scores, z[f"out_{tag}.scores"], 1e-4, tag + " scores")
-            close(got.pred_boxes.tensor, z[f"out_{tag}.pred_boxes"], 0, tag + " boxes")
-        assert out["height"] == h and out["file_name"] == "x.png"
-        with torch.no_grad():
-            te.per_class_feat[K] = T(z["bg_embedding_2"])
-        assert len(model(binp, pre)["RCNN"]["instances"]) == int(z["n2_RCNN"])
+    clip_relabel("cpu")   # GPU twin: tests/test_parity_gpu.py
 
 
 def test_clip_teacher_builds_from_config():

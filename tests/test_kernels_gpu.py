@@ -455,17 +455,20 @@ def test_bn_act_vs_torch(dtype, relu, res, pool, shape):
     rd = r.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True) if res else None
     out = L.bn_act(xd, bn, relu, rd, pool)
     out.backward(dy.cuda())
-    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    # fp32: measured 6e-7 (outputs) / 1e-6 (gradients) of the tensor's scale at the largest launch shape
+    # (tests/test_parity_gpu.py::test_bn_train_at_the_timed_shape_vs_fp64); bf16: output rounding (2^-9 relative per element)
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
     torch.testing.assert_close(out.detach().cpu().double(), y.detach(), rtol=tol, atol=tol)
-    gtol = 1e-3 if dtype == torch.float32 else 5e-2
+    gtol = 1e-4 if dtype == torch.float32 else 5e-2
     scale = float(xr.grad.abs().max())
     torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=gtol, atol=gtol * scale)
     torch.testing.assert_close(bn.weight.grad.cpu().double(), ref_bn.weight.grad, rtol=gtol, atol=gtol * float(ref_bn.weight.grad.abs().max()))
     torch.testing.assert_close(bn.bias.grad.cpu().double(), ref_bn.bias.grad, rtol=gtol, atol=gtol * float(ref_bn.bias.grad.abs().max()))
     if res:
         torch.testing.assert_close(rd.grad.cpu().double(), rr.grad, rtol=gtol, atol=gtol)
-    torch.testing.assert_close(bn.running_mean.cpu().double(), ref_bn.running_mean, rtol=1e-3, atol=1e-3)
-    torch.testing.assert_close(bn.running_var.cpu().double(), ref_bn.running_var, rtol=2e-3, atol=2e-3)
+    rtol = 1e-5 if dtype == torch.float32 else 1e-3
+    torch.testing.assert_close(bn.running_mean.cpu().double(), ref_bn.running_mean, rtol=rtol, atol=rtol)
+    torch.testing.assert_close(bn.running_var.cpu().double(), ref_bn.running_var, rtol=rtol, atol=rtol)
     assert int(bn.num_batches_tracked) == 1
 
 

@@ -38,47 +38,9 @@ def test_sample_masks_counts_and_membership():
 
 
 def test_losses_packed_equal_reference_losses_on_the_same_samples():
-    from coin_amd.modeling.roi_heads import PackedSamples
+    from parity_cases import losses_packed_pretrain
 
-    for tag in ("a", "empty_image", "no_fg", "clipart", "focal"):
-        z = load(f"box_predictor_pretrain_{tag}")
-        with cpu_kernels():
-            det = tiny_product_detector()
-            from coin_amd.modeling.fast_rcnn import FastRCNNOutputLayers
-            from coin_amd.box_ops import Box2BoxTransform
-            from coin_amd.structures import ShapeSpec
-            from golden_util import LOSS_W
-
-            bp = FastRCNNOutputLayers(ShapeSpec(channels=64, height=1, width=1), text_encoder=det.roi_heads.box_predictor.text_encoder,
-                                      pooling_type="meanpool", box2box_transform=Box2BoxTransform((10.0, 10.0, 5.0, 5.0)), text_dim=32,
-                                      classes_weight=[1.0] * K + [0.9], loss_type="MILFocalLoss" if tag == "focal" else "MILCrossEntropy",
-                                      cls_agnostic_bbox_reg=True, loss_weight=LOSS_W, batch_size_per_image=32, cls_b_thresh=0.3, dataset=(str(z["dataset"]),),
-                                      prototype_update_rate=0.9996)
-            load_weights(bp, z)
-            bp.train()
-            n_img = int(z["n_img"])
-            boxes, cls, gtb, prs = [], [], [], []
-            for i in range(n_img):
-                fg, bg = _inst(z, f"p{i}.fg", (96, 128)), _inst(z, f"p{i}.bg", (96, 128))
-                boxes += [fg.proposal_boxes.tensor, bg.proposal_boxes.tensor]
-                cls += [fg.gt_classes_offline, bg.gt_classes]
-                gtb += [fg.gt_boxes.tensor, bg.proposal_boxes.tensor]
-                prs += [fg.gt_probs_offline, torch.zeros(len(bg), K + 1)]
-            x = T(z["x"])
-            # 3 invalid filler rows (fewer candidates than the batch size): they must not change anything
-            x_ext = torch.cat([x, torch.randn(3, x.shape[1])]).requires_grad_(True)
-            ps = PackedSamples(torch.cat(boxes + [torch.tensor([[1.0, 1, 20, 20]] * 3)]), torch.cat(cls + [torch.full((3,), -1)]),
-                               torch.cat(gtb + [torch.tensor([[1.0, 1, 20, 20]] * 3)]), torch.cat(prs + [torch.zeros(3, K + 1)]), 0)
-            preds = bp(x_ext, "pre_train")
-            losses = bp.losses_packed(preds, ps, update_prototype=bool(z["update_prototype"]))
-            ref = {k[6:]: float(z[k]) for k in z.files if k.startswith("loss::")}
-            assert set(losses) == set(ref)
-            for k, v in ref.items():
-                assert abs(float(losses[k]) - v) < 1e-4 * max(1.0, abs(v)), (tag, k, float(losses[k]), v)
-            sum(losses.values()).backward()
-            close(x_ext.grad[: x.shape[0]], z["gx"], 1e-5, "gx")
-            assert float(x_ext.grad[x.shape[0]:].abs().max()) == 0.0
-            close(bp.text_encoder.per_class_feat, z["prototype_after"], 1e-6, "prototype")
+    losses_packed_pretrain("cpu")   # GPU twin: tests/test_parity_gpu.py
 
 
 def test_sync_free_detector_step_matches_counting_rules():
@@ -121,85 +83,9 @@ def test_sync_free_detector_step_matches_counting_rules():
 
 @pytest.mark.parametrize("tag", ["one", "two", "two_nobg_noC", "two_noB", "one_noproto"])
 def test_losses_packed_step_equal_reference_losses_on_the_same_samples(tag):
-    """`losses_packed_step` (row roles + masks, no host-side row counts) == FastRCNNOutputLayers.losses(step_one / step_two) of
-    the reference on the same A / B / background rows, with filler rows interleaved; the masked `merge_grad_loss` reproduces
-    gradient_discrepancy_loss and the CKG gradients."""
-    from coin_amd.modeling.roi_heads import PackedStepSamples
-    from coin_amd.modeling.text_encoder import CKGNet
-    from e2e_util import _product_box_predictor
+    from parity_cases import losses_packed_step
 
-    z = load(f"box_predictor_{tag}")
-    branch = str(z["branch"])
-    with cpu_kernels():
-        bp = _product_box_predictor()
-        load_weights(bp, z)
-        merge = CKGNet(32, 32, K + 1, head_num=4)
-        load_weights(merge, z, "m::")
-        bp.train()
-        n_img = int(z["n_img"])
-        size = (96, 128)
-        x_ref = T(z["x"])
-        rows, role, cls, con, coff, gtb, pon, poff, boxes = [], [], [], [], [], [], [], [], []
-        cursor = 0
-        zero_p = lambda n: torch.zeros(n, K + 1)
-        for i in range(n_img):
-            a, b, g = (_inst(z, f"p{i}.{t}", size) for t in ("a", "b", "bg"))
-            for inst, r in ((a, 0), (b, 1), (g, 2)):
-                n = len(inst)
-                rows.append(x_ref[cursor:cursor + n])
-                cursor += n
-                role.append(torch.full((n,), r))
-                boxes.append(inst.proposal_boxes.tensor)
-                if r == 0:
-                    cls.append(inst.gt_classes); con.append(torch.zeros(n, dtype=torch.long)); coff.append(torch.zeros(n, dtype=torch.long))
-                    gtb.append(inst.gt_boxes.tensor); pon.append(inst.gt_probs_online); poff.append(inst.gt_probs_offline)
-                elif r == 1:
-                    cls.append(torch.zeros(n, dtype=torch.long)); con.append(inst.gt_classes_online); coff.append(inst.gt_classes_offline)
-                    gtb.append(inst.gt_boxes.tensor); pon.append(inst.gt_probs_online); poff.append(inst.gt_probs_offline)
-                else:
-                    cls.append(inst.gt_classes); con.append(torch.zeros(n, dtype=torch.long)); coff.append(torch.zeros(n, dtype=torch.long))
-                    gtb.append(inst.proposal_boxes.tensor); pon.append(zero_p(n)); poff.append(zero_p(n))
-            # two filler rows after every image
-            rows.append(torch.randn(2, x_ref.shape[1])); role.append(torch.full((2,), -1)); boxes.append(torch.tensor([[1.0, 1, 20, 20]] * 2))
-            cls.append(torch.zeros(2, dtype=torch.long)); con.append(torch.zeros(2, dtype=torch.long)); coff.append(torch.zeros(2, dtype=torch.long))
-            gtb.append(torch.tensor([[1.0, 1, 20, 20]] * 2)); pon.append(zero_p(2)); poff.append(zero_p(2))
-        assert cursor == x_ref.shape[0]
-        x = torch.cat(rows).requires_grad_(True)
-        role_t = torch.cat(role)
-        has_b = bool((role_t == 1).any())
-        ps = PackedStepSamples(torch.cat(boxes), role_t, torch.cat(cls), torch.cat(con), torch.cat(coff), torch.cat(gtb), torch.cat(pon),
-                               torch.cat(poff), 0, n_img, has_b)
-        cs = [_inst(z, f"p{i}.c", size) for i in range(n_img)]
-        xc = T(z["xc"])
-        preds = bp(x, branch)
-        cpred = bp(xc, branch, return_feats=False) if xc.shape[0] else None
-        losses = bp.losses_packed_step(preds, ps, cpred, cs if xc.shape[0] else None, merge, branch, update_prototype=bool(z["update_prototype"]))
-        ref = {k[6:]: float(z[k]) for k in z.files if k.startswith("loss::")}
-        got = {k: float(v) for k, v in losses.items()}
-        if "loss_merge_a" in losses:
-            lg = bp.merge_grad_loss()
-            got["loss_merge_grad"] = float(lg)
-            (lg + losses["loss_merge_base"]).backward(inputs=list(merge.parameters()), retain_graph=True)
-            for n, p in merge.named_parameters():
-                close(p.grad, z["mg::" + n], 2e-4, n)
-        if "loss_cls_b" in got and "loss_cls_b" not in ref:  # no B row passed the threshold: the reference omits the (zero) term
-            assert got.pop("loss_cls_b") == 0.0
-        assert set(got) == set(ref), (sorted(got), sorted(ref))
-        for k, v in ref.items():
-            assert abs(got[k] - v) < 1e-4 * max(1.0, abs(v)), (tag, k, got[k], v)
-        skip = ["loss_merge_grad", "loss_merge_a", "loss_merge_b", "loss_merge_base"] + ([] if branch == "step_two" else ["loss_cls_b"])
-        sum(v for k, v in losses.items() if k not in skip).backward()
-        real = role_t >= 0
-        close(x.grad[real], z["gx"], 1e-5, "gx")
-        assert float(x.grad[~real].abs().max()) == 0.0
-        for name in ("prototype_after", "prototype_b_online_after", "prototype_b_offline_after"):
-            buf = {"prototype_after": bp.text_encoder.per_class_feat, "prototype_b_online_after": bp.text_encoder.prototype_b_online,
-                   "prototype_b_offline_after": bp.text_encoder.prototype_b_offline}[name]
-            close(buf, z[name], 1e-6, name)
-        params = dict(bp.named_parameters())
-        for k in z.files:
-            if k.startswith("g::"):
-                close(params[k[3:]].grad, z[k], 1e-4, k)
+    losses_packed_step("cpu", tag)   # GPU twin: tests/test_parity_gpu.py
 
 
 def _step_two_batch():
