@@ -1,0 +1,339 @@
+// bf16 GEMM / implicit-GEMM convolution for the res5 bottlenecks on the RoI tiles (gfx950).
+//
+// Replaces the library convolutions of `backbone.layer4` on the RoI tiles (coin/modeling/utils.py:77-90,184-186 run through
+// coin/modeling/roi_heads/clip_roi_heads.py:172-176): the 1x1 convolutions are plain NHWC GEMMs [R*hw, Cin] x [Cout, Cin]^T,
+// the 3x3 / pad 1 convolutions implicit GEMMs with K = 9*Cin (tap-major, the channels-last weight layout).  Forward and
+// data-gradient use this kernel (dgrad = the same contraction with the weight re-laid [Cin][flipped tap][Cout]).
+//
+// Why hand-written: at these shapes (M = 100 352 or 401 408 rows, N = 512..2048, K = 512..4608) the 1x1 GEMMs sit ON the HBM
+// roofline (342 FLOP/B for layer4.0.conv1 against a machine balance of ~400): what bounds them is how the output tile leaves
+// the chip and what else can be done while it is on chip.  So:
+//   * 256 x 128 x 64 block tile, 8 waves (4 x 2), each wave 64 x 64 = 4 x 4 MFMA 16x16x32 accumulators;
+//   * operands staged by 16-byte LDS-DMA (global_load_lds) into a 3-deep ring (3 x 48 KiB), XOR-swizzled on the SOURCE address
+//     (rule 21) so that the ds_read_b128 fragment reads are conflict-free; ONE raw s_barrier per K-step, counted
+//     `s_waitcnt vmcnt(6)`: the loads of step t+1 stay in flight across the barrier while step t is multiplied and step t+2
+//     is issued;
+//   * the 3x3 gather is done by the DMA's per-lane source address (a shifted pixel, or a zero page outside the image);
+//   * MFMA operands swapped (D = W-frag x A-frag) so that a lane ends up with 4 CONSECUTIVE output channels of one pixel:
+//     the tile is packed to bf16 in registers, transposed through LDS once and stored as whole 256-byte rows;
+//   * the BatchNorm statistics of the output (per-channel pivoted sum and sum of squares of the STORED bf16 values, per row
+//     tile) are taken during that store pass -- the separate statistics pass over the activation (coin_bn_stats) disappears.
+#include "common.h"
+
+namespace {
+
+constexpr int GM = 256, GN = 128, GK = 64;
+constexpr int A_BYTES = GM * GK * 2;              // 32 KiB
+constexpr int B_BYTES = GN * GK * 2;              // 16 KiB
+constexpr int STAGE_BYTES = A_BYTES + B_BYTES;    // 48 KiB
+constexpr int NSTAGE = 3;
+constexpr int C_ROW_BYTES = GN * 2 + 16;          // padded row of the output tile image
+
+__device__ __attribute__((aligned(256))) unsigned char coin_zero_page[256];  // source of the 3x3 taps that fall outside the image
+
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8 frag(const char* tile, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+
+struct ARows {             // the 4 A-tile rows this thread stages (fixed for the whole K loop)
+  const bf16_t* base[4];   // row start (1x1: the matrix row; 3x3: the centre pixel's channel 0)
+  unsigned taps[4];        // 3x3: bit t set = tap t lies inside the image
+};
+
+template <bool GATHER3, bool STATS>
+__global__ __launch_bounds__(512) void conv_gemm_bf16_kernel(
+    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, bf16_t* __restrict__ Cmat, int ldc, int M, int N,
+    int K, int H, int W, int Cin, float* __restrict__ stats, int64_t stats_rows, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // XCD-aware tile order: consecutive tiles along N (sharing the A panel) stay on one XCD
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * GM, n0 = tn * GN;
+  const int wr = wave >> 1, wc = wave & 1;  // 4 x 2 waves
+
+  // ---- per-thread staging addresses
+  const int rl = lane >> 3;            // row within the 8-row group one DMA instruction writes
+  const int sc = (lane & 7) ^ rl;      // logical 16-byte chunk that must land at physical chunk lane & 7
+  ARows ar;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int row = m0 + (wave * 4 + j) * 8 + rl;
+    row = row < M ? row : M - 1;
+    if (GATHER3) {
+      const int hw = H * W;
+      const int nb = row / hw, rem = row - nb * hw;
+      const int oy = rem / W, ox = rem - oy * W;
+      ar.base[j] = A + (size_t)row * Cin;
+      unsigned m = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = oy + t / 3 - 1, xx = ox + t % 3 - 1;
+        m |= (yy >= 0 && yy < H && xx >= 0 && xx < W ? 1u : 0u) << t;
+      }
+      ar.taps[j] = m;
+    } else {
+      ar.base[j] = A + (size_t)row * lda;
+      ar.taps[j] = 0;
+    }
+  }
+  const bf16_t* brow[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int row = n0 + (wave * 2 + j) * 8 + rl;
+    row = row < N ? row : N - 1;
+    brow[j] = B + (size_t)row * ldb;
+  }
+  const int kc = GATHER3 ? Cin / GK : 1;  // K-steps per tap
+
+  auto stage = [&](int t, int slot) {
+    char* sa = lds + slot * STAGE_BYTES;
+    char* sb = sa + A_BYTES;
+    int koff = t * GK, tap = 0;
+    long long shift = 0;
+    if (GATHER3) {
+      tap = t / kc;
+      koff = (t - tap * kc) * GK;
+      shift = ((long long)(tap / 3 - 1) * W + (tap % 3 - 1)) * Cin;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16_t* src = ar.base[j] + koff + sc * 8;
+      if (GATHER3) src = ((ar.taps[j] >> tap) & 1u) ? src + shift : reinterpret_cast<const bf16_t*>(coin_zero_page) + sc * 8;
+      glds16(src, sa + (wave * 4 + j) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds16(brow[j] + (size_t)t * GK + sc * 8, sb + (wave * 2 + j) * 1024);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = K / GK;
+  stage(0, 0);
+  if (nt > 1) stage(1, 1);
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int t = 0; t < nt; ++t) {
+    // stage t has landed once at most the 6 loads of stage t+1 are outstanding; the barrier publishes every wave's DMA writes
+    // and guarantees that slot (t+2) % 3 == (t-1) % 3 is no longer being read
+    if (t + 1 < nt)
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nt) stage(t + 2, (t + 2) % NSTAGE);
+    const char* la = lds + (t % NSTAGE) * STAGE_BYTES;
+    const char* lb = la + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = frag(la, wr * 64 + i * 16 + fr, kk * 4 + fq);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = frag(lb, wc * 64 + j * 16 + fr, kk * 4 + fq);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          // operands swapped: D[n][m] -> lane fr = output row m, registers = 4 consecutive output columns n
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+
+  // ---- epilogue: registers -> bf16 tile image in LDS -> whole rows to HBM (+ statistics of the stored values)
+  __syncthreads();  // every wave is done with the staging ring
+  char* ct = lds;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wr * 64 + i * 16 + fr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = wc * 64 + j * 16 + fq * 4;
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[i][j][r];
+      *reinterpret_cast<bf16x4*>(ct + row * C_ROW_BYTES + col * 2) = o;
+    }
+  }
+  __syncthreads();
+  const int chunk = threadIdx.x & 15, rsub = threadIdx.x >> 4;  // 16 chunks of 8 columns per row, 32 rows per pass
+  const int gcol = n0 + chunk * 8;
+  float s1[8], s2[8], piv[8];
+  if (STATS) {
+    const bf16x8 p = *reinterpret_cast<const bf16x8*>(ct + chunk * 16);  // the tile's first row is every thread's pivot
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      piv[i] = (float)p[i];
+      s1[i] = s2[i] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < GM / 32; ++p) {
+    const int row = p * 32 + rsub;
+    const int grow = m0 + row;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(ct + row * C_ROW_BYTES + chunk * 16);
+    if (grow < M && gcol < N) *reinterpret_cast<bf16x8*>(Cmat + (size_t)grow * ldc + gcol) = v;
+    if (STATS && (int64_t)grow < stats_rows) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float d = (float)v[i] - piv[i];
+        s1[i] += d;
+        s2[i] += d * d;
+      }
+    }
+  }
+  if (STATS) {
+    // threads with equal `chunk`: lanes l, l^16, l^32 inside a wave, then the 8 waves through LDS (fixed order)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      s1[i] += __shfl_xor(s1[i], 16, 64);
+      s2[i] += __shfl_xor(s2[i], 16, 64);
+      s1[i] += __shfl_xor(s1[i], 32, 64);
+      s2[i] += __shfl_xor(s2[i], 32, 64);
+    }
+    __syncthreads();  // the tile image has been consumed
+    float* red = reinterpret_cast<float*>(lds + GM * C_ROW_BYTES);  // [8 waves][16 chunks][16]
+    if (lane < 16) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        red[(wave * 16 + lane) * 16 + i] = s1[i];
+        red[(wave * 16 + lane) * 16 + 8 + i] = s2[i];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < GN) {  // one thread per column of the tile
+      const int c = threadIdx.x, ch = c >> 3, ci = c & 7;
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        a1 += red[(w * 16 + ch) * 16 + ci];
+        a2 += red[(w * 16 + ch) * 16 + 8 + ci];
+      }
+      if (n0 + c < N) {
+        float* __restrict__ part = stats + (size_t)tm * 3 * N + n0 + c;
+        part[0] = (float)*reinterpret_cast<const bf16_t*>(ct + c * 2);  // pivot
+        part[N] = a1;
+        part[2 * (size_t)N] = a2;
+      }
+    }
+  }
+}
+
+// mean / rstd (+ running statistics) from the per-row-tile pivoted partials: tile t holds n_t = clamp(rows - 256 t, 0, 256) values
+// per channel as (pivot p, S1 = sum(x - p), S2 = sum((x - p)^2)) -> (mean_t, M2_t) -> Chan's pairwise update, in a fixed order.
+__global__ __launch_bounds__(1024) void conv_stats_finalize_kernel(const float* __restrict__ part, int tiles_m, int N, int64_t rows,
+                                                                    float eps, float momentum, float* __restrict__ mean,
+                                                                    float* __restrict__ rstd, float* __restrict__ running_mean,
+                                                                    float* __restrict__ running_var) {
+  __shared__ float red[16][3][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float n_a = 0.f, mu_a = 0.f, m2_a = 0.f;
+  if (c < N) {
+    for (int t = wave; t < tiles_m; t += 16) {
+      const int64_t left = rows - (int64_t)t * GM;
+      const float n_b = (float)(left <= 0 ? 0 : (left < GM ? left : GM));
+      if (n_b == 0.f) continue;
+      const float* __restrict__ p = part + (size_t)t * 3 * N + c;
+      const float s1 = p[N], s2 = p[2 * (size_t)N];
+      const float mu_b = p[0] + s1 / n_b;
+      const float m2_b = fmaxf(s2 - s1 * s1 / n_b, 0.f);
+      const float n = n_a + n_b, d = mu_b - mu_a;
+      mu_a += d * (n_b / n);
+      m2_a += m2_b + d * d * (n_a * n_b / n);
+      n_a = n;
+    }
+  }
+  red[wave][0][lane] = n_a;
+  red[wave][1][lane] = mu_a;
+  red[wave][2][lane] = m2_a;
+  __syncthreads();
+  if (wave != 0 || c >= N) return;
+  n_a = mu_a = m2_a = 0.f;
+  for (int w = 0; w < 16; ++w) {
+    const float n_b = red[w][0][lane];
+    if (n_b == 0.f) continue;
+    const float n = n_a + n_b, d = red[w][1][lane] - mu_a;
+    mu_a += d * (n_b / n);
+    m2_a += red[w][2][lane] + d * d * (n_a * n_b / n);
+    n_a = n;
+  }
+  const float var = n_a > 0.f ? m2_a / n_a : 0.f;
+  mean[c] = mu_a;
+  rstd[c] = 1.0f / sqrtf(var + eps);
+  if (running_mean) {
+    const float unbiased = n_a > 1.f ? m2_a / (n_a - 1.f) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu_a;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t coin_conv_gemm_stats_bytes(int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  return (size_t)((M + GM - 1) / GM) * 3 * (size_t)N * sizeof(float);
+}
+
+extern "C" int coin_conv_gemm_bf16(const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb, void* C, int ldc,
+                                   int M, int N, int K, float* stats, int64_t stats_rows, void* stream) {
+  if (!A || !B || !C) return COIN_EINVAL;
+  if (M < 0 || N < 0 || K <= 0 || ldb < K || ldc < N || (mode != 0 && mode != 1)) return COIN_EINVAL;
+  if (M == 0 || N == 0) return COIN_OK;
+  if (K % GK || ldb % 8 || ldc % 8 || N % 8) return COIN_ESHAPE;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15)) return COIN_EALIGN;
+  if (mode == 0) {
+    if (lda < K) return COIN_EINVAL;
+    if (lda % 8) return COIN_ESHAPE;
+  } else {
+    if (H <= 0 || W <= 0 || Cin <= 0 || M % (H * W)) return COIN_EINVAL;
+    if (Cin % GK || K != 9 * Cin) return COIN_ESHAPE;
+  }
+  const int tm = (M + GM - 1) / GM, tn = (N + GN - 1) / GN;
+  const size_t lds = (size_t)NSTAGE * STAGE_BYTES;
+  hipStream_t st = (hipStream_t)stream;
+  const bf16_t* a = (const bf16_t*)A;
+  const bf16_t* b = (const bf16_t*)B;
+  bf16_t* c = (bf16_t*)C;
+#define COIN_LAUNCH(G3, ST)                                                                                                   \
+  do {                                                                                                                        \
+    static bool attr_set = false;                                                                                             \
+    if (!attr_set) {                                                                                                          \
+      (void)hipFuncSetAttribute((const void*)conv_gemm_bf16_kernel<G3, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      attr_set = true;                                                                                                        \
+    }                                                                                                                         \
+    conv_gemm_bf16_kernel<G3, ST><<<tm * tn, 512, lds, st>>>(a, lda, b, ldb, c, ldc, M, N, K, H, W, Cin, stats, stats_rows, tm, tn); \
+  } while (0)
+  if (mode == 1) {
+    if (stats) COIN_LAUNCH(true, true); else COIN_LAUNCH(true, false);
+  } else {
+    if (stats) COIN_LAUNCH(false, true); else COIN_LAUNCH(false, false);
+  }
+#undef COIN_LAUNCH
+  return coin_launch_status();
+}
+
+extern "C" int coin_conv_gemm_stats_finalize(const float* partials, int M, int N, int64_t rows, float eps, float momentum, float* mean,
+                                             float* rstd, float* running_mean, float* running_var, void* stream) {
+  if (!partials || !mean || !rstd || M <= 0 || N <= 0 || rows <= 0 || rows > M) return COIN_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return COIN_EINVAL;
+  conv_stats_finalize_kernel<<<(N + 63) / 64, 1024, 0, (hipStream_t)stream>>>(partials, (M + GM - 1) / GM, N, rows, eps, momentum, mean, rstd,
+                                                                             running_mean, running_var);
+  return coin_launch_status();
+}

@@ -137,6 +137,152 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_kernel(
   }
 }
 
+// summed bilinear weight that the samples of bin `b` put on map coordinate `k` (one axis); same ops as axis_taps
+__device__ __forceinline__ float bin_weight(float start, float binsz, int grid, int b, int k, int size) {
+  float wsum = 0.f;
+  for (int i = 0; i < grid; ++i) {
+    const float v = start + (float)b * binsz + ((float)i + 0.5f) * binsz / (float)grid;
+    int lo, hi;
+    float wl, wh;
+    if (!axis_taps(v, size, lo, hi, wl, wh)) continue;
+    if (lo == k) wsum += wl;
+    if (hi == k) wsum += wh;
+  }
+  return wsum;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// forward, NHWC, separable gather (the shipped NHWC path for pw <= 16):
+//   out[py][px][c] = 1/count * sum_y Wy[py][y] * sum_x Wx[px][x] * feat[y][x][c]
+// Wy[py][y] / Wx[px][x] = summed bilinear weight that the samples of bin row py / bin column px put on map row y / column x
+// (exactly the per-sample arithmetic of torchvision's bilinear_interpolate, `axis_taps`).  A block owns one RoI x one channel
+// part (lane = one 16-byte channel vector, a wave spans 64 of them); it builds the RoI's column table Wx once in LDS.  A work
+// item = (bin row py, 8 consecutive bin columns): its wave keeps the 8 output vectors in registers, walks the (few) map rows
+// with non-zero Wy[py][.] and, on each, the footprint columns of its 8 bins ONCE -- every loaded 16-byte vector is converted
+// once and fanned out to the bins that touch it.  Against the per-sample loop (4 taps x gh x gw samples per output vector)
+// this moves 2.5-5x fewer bytes through the vector L1, which is what bounded that kernel (0.26 of the HBM peak).
+// ------------------------------------------------------------------------------------------
+constexpr int FWD_NB = 8;   // bins per work item = accumulator vectors per lane
+constexpr int FWD_NX = 12;  // map columns requested together
+
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_fwd_sep_kernel(
+    const T* __restrict__ feat, const float* __restrict__ rois, T* __restrict__ out, int C, int H, int W, int R, int ph, int pw,
+    float scale, int sampling_ratio, int aligned, int nparts) {
+  constexpr int VEC = Vec16<T>::N;
+  typedef typename Vec16<T>::type vec_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* wx = reinterpret_cast<float*>(smem);                  // [W][16]
+  unsigned* xmask = reinterpret_cast<unsigned*>(wx + (size_t)W * 16);  // [W] bit px: bin column px has weight on column x
+  int* xr = reinterpret_cast<int*>(xmask + W);                  // [2 halves][lo, hi]
+  const int roi = blockIdx.x / nparts, part = blockIdx.x - roi * nparts;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = (part * 64 + lane) * VEC;
+  const bool c_ok = c0 < C;
+  const RoiGeom g = roi_geom(rois + (size_t)roi * 5, ph, pw, scale, sampling_ratio, aligned);
+
+  for (int i = threadIdx.x; i < W * 16; i += 256) wx[i] = 0.f;
+  if (threadIdx.x < 4) xr[threadIdx.x] = (threadIdx.x & 1) ? -1 : W;
+  __syncthreads();
+  if ((int)threadIdx.x < pw) {  // one thread per bin column: only it writes wx[.][px]
+    const int px = threadIdx.x;
+    for (int ix = 0; ix < g.gw; ++ix) {
+      const float x = g.x0 + (float)px * g.bw + ((float)ix + 0.5f) * g.bw / (float)g.gw;
+      int lo, hi;
+      float wl, wh;
+      if (!axis_taps(x, W, lo, hi, wl, wh)) continue;
+      wx[lo * 16 + px] += wl;
+      wx[hi * 16 + px] += wh;
+    }
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x < W; x += 256) {
+    unsigned m = 0;
+    for (int px = 0; px < pw; ++px) m |= (wx[x * 16 + px] != 0.f ? 1u : 0u) << px;
+    xmask[x] = m;
+    if (m & 0xffu) { atomicMin(&xr[0], x); atomicMax(&xr[1], x); }
+    if (m >> 8) { atomicMin(&xr[2], x); atomicMax(&xr[3], x); }
+  }
+  __syncthreads();
+
+  const int nh = (pw + FWD_NB - 1) / FWD_NB;
+  const T* __restrict__ fmap = feat + (size_t)g.n * H * W * C + (c_ok ? c0 : 0);
+  for (int item = wave; item < ph * nh; item += 4) {
+    const int py = item / nh, hx = item - py * nh;
+    const int pb = hx * FWD_NB;
+    const int xlo = xr[2 * hx], xhi = xr[2 * hx + 1];
+    float acc[FWD_NB][VEC];
+#pragma unroll
+    for (int t = 0; t < FWD_NB; ++t)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[t][i] = 0.f;
+    if (g.gh > 0 && xhi >= xlo) {
+      // map rows that the samples of bin row py can touch
+      const float ysa = g.y0 + (float)py * g.bh + 0.5f * g.bh / (float)g.gh;
+      const float ysb = g.y0 + (float)py * g.bh + ((float)g.gh - 0.5f) * g.bh / (float)g.gh;
+      const float ymin = fminf(ysa, ysb), ymax = fmaxf(ysa, ysb);
+      int ylo = (int)floorf(fmaxf(ymin, 0.f)), yhi = (int)floorf(fminf(fmaxf(ymax, 0.f), (float)(H - 1))) + 1;
+      ylo = ylo > H - 1 ? H - 1 : ylo;
+      yhi = yhi > H - 1 ? H - 1 : yhi;
+      if (!(ymax < -1.0f || ymin > (float)H)) {
+        for (int ybase = ylo; ybase <= yhi; ybase += 64) {
+          const int yl = ybase + lane;
+          const float wr = yl <= yhi ? bin_weight(g.y0, g.bh, g.gh, py, yl, H) * g.inv_count : 0.f;
+          unsigned long long rows = __ballot(wr != 0.f);
+          while (rows) {
+            const int r = __builtin_ctzll(rows);
+            rows &= rows - 1;
+            const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wr), r));
+            const T* __restrict__ rowp = fmap + (size_t)(ybase + r) * W * C;
+            for (int x = xlo; x <= xhi; x += FWD_NX) {
+              // every column of the segment is requested before the first is used: the loop is bound by load latency, not by
+              // bytes (FWD_NX x 1 KiB in flight per wave)
+              vec_t v[FWD_NX];
+#pragma unroll
+              for (int j = 0; j < FWD_NX; ++j) {
+                const int xx = x + j <= xhi ? x + j : xhi;  // clamped: the tail re-reads a valid column, its mask is skipped
+                if (c_ok) v[j] = *reinterpret_cast<const vec_t*>(rowp + (size_t)xx * C);
+              }
+#pragma unroll
+              for (int j = 0; j < FWD_NX; ++j) {
+                if (x + j > xhi) break;
+                const unsigned mk = ((unsigned)__builtin_amdgcn_readfirstlane((int)xmask[x + j]) >> pb) & 0xffu;
+                if (mk == 0) continue;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(&wx[(x + j) * 16 + pb]);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(&wx[(x + j) * 16 + pb + 4]);
+                float vf[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) vf[i] = c_ok ? (float)v[j][i] : 0.f;
+#pragma unroll
+                for (int t = 0; t < FWD_NB; ++t) {
+                  if (mk & (1u << t)) {
+                    const float wt = a * (t < 4 ? w0[t & 3] : w1[t & 3]);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc[t][i] += wt * vf[i];
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    if (c_ok) {
+      T* __restrict__ orow = out + (((size_t)roi * ph + py) * pw + pb) * C + c0;
+#pragma unroll
+      for (int t = 0; t < FWD_NB; ++t) {
+        if (pb + t < pw) {
+          vec_t o;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) o[i] = (T)acc[t][i];
+          __builtin_nontemporal_store(o, reinterpret_cast<vec_t*>(orow + (size_t)t * C));
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // backward, NHWC: separable gather.
 //   d feat[y][x][c] = sum_py sum_px Wy[py][y] * Wx[px][x] * gout[py][px][c] / count
@@ -259,20 +405,6 @@ constexpr int TILE = 8;      // tile edge in map pixels
 constexpr int BINS = 16;     // padded bins per axis
 constexpr int LIST_CAP = 4096;
 constexpr int BWD_TCH = 128;  // channels per block of the tiled backward: lane = 2 adjacent channels
-
-// summed bilinear weight that the samples of bin `b` put on map coordinate `k` (one axis); same ops as axis_taps
-__device__ __forceinline__ float bin_weight(float start, float binsz, int grid, int b, int k, int size) {
-  float wsum = 0.f;
-  for (int i = 0; i < grid; ++i) {
-    const float v = start + (float)b * binsz + ((float)i + 0.5f) * binsz / (float)grid;
-    int lo, hi;
-    float wl, wh;
-    if (!axis_taps(v, size, lo, hi, wl, wh)) continue;
-    if (lo == k) wsum += wl;
-    if (hi == k) wsum += wh;
-  }
-  return wsum;
-}
 
 template <typename T> struct Pair;
 template <> struct Pair<float> {
@@ -433,6 +565,217 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tiled_kernel(
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// backward, NHWC, atomic-free gather per map tile (the shipped NHWC path for ph, pw <= 16):
+//   d feat[n][y][x][c] = sum over RoIs r of image n:  sum_py sum_px Wy_r[py][y] * Wx_r[px][x] * gout[r][py][px][c] / count_r
+// A block owns a 4-row x 8-column tile of one image's gradient map x one channel part; wave w owns tile row w, a lane one 16-byte
+// channel vector of it: 8 pixel accumulators x VEC channels in registers, every map element stored exactly once with plain
+// stores, RoIs summed in index order (bit-reproducible; no float atomics: their ~1.3 TB/s ceiling bound the scatter form).
+//   phase 0: ordered compaction of the RoIs whose footprint may touch the tile;
+//   phase 1 (per 32 list entries, whole block): the bilinear weight tables of those RoIs restricted to the tile -- one thread
+//            per (RoI, axis, bin) walks the bin's samples once (the forward's arithmetic) -- plus bit masks of the non-zero
+//            entries.  The previous kernel recomputed these per wave and per 128-channel block (32x redundant) inside its
+//            load -> use chain; now they are off the critical path and the inner loop is loads + FMAs only;
+//   phase 2: each wave streams the gradient bins with non-zero weight on its row: 16 bytes per lane per bin (1 KiB per
+//            wave-instruction), four bins in flight, converted once and fanned out to the <= 3 tile columns they touch.
+// ------------------------------------------------------------------------------------------
+constexpr int BT_ROWS = 4, BT_COLS = 8, BT_LC = 32;
+
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
+    const T* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gfeat, int C, int H, int W, int R, int ph, int pw,
+    float scale, int sampling_ratio, int aligned, int tiles_x, int tiles_y, int ntiles, int nparts) {
+  constexpr int VEC = Vec16<T>::N;
+  typedef typename Vec16<T>::type vec_t;
+  __shared__ unsigned short list[LIST_CAP];
+  __shared__ int wave_cnt[4];
+  __shared__ int list_n;
+  __shared__ __attribute__((aligned(16))) float wyt[BT_LC][16][BT_ROWS];
+  __shared__ __attribute__((aligned(16))) float wxt[BT_LC][16][BT_COLS];
+  __shared__ unsigned xmk[BT_LC][16];      // bit t: bin column px has weight on tile column t
+  __shared__ unsigned ymk[BT_LC][BT_ROWS]; // bit py: bin row py has weight on tile row r
+  __shared__ int pxr[BT_LC][2];            // bin columns [lo, hi) with any weight on the tile
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // XCD-aware order: blocks b and b + 8 share an XCD (L2); give each XCD a contiguous run of tiles so that the bins which
+  // straddle tile borders are re-read from the same L2 (speed only, placement is not assumed for correctness)
+  const int nblk = ntiles * nparts;
+  const int q = nblk / 8, rem = nblk % 8, xcd = blockIdx.x & 7;
+  const int logical = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (blockIdx.x >> 3);
+  const int part = logical / ntiles, tile = logical - part * ntiles;
+  const int tx0 = (tile % tiles_x) * BT_COLS;
+  const int ty0 = ((tile / tiles_x) % tiles_y) * BT_ROWS;
+  const int n = tile / (tiles_x * tiles_y);
+  const int c0 = (part * 64 + lane) * VEC;
+  const bool c_ok = c0 < C;
+
+  float acc[BT_COLS][VEC];
+#pragma unroll
+  for (int t = 0; t < BT_COLS; ++t)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[t][i] = 0.f;
+
+  for (int base = 0; base < R; base += LIST_CAP) {
+    const int lim = (R - base) < LIST_CAP ? (R - base) : LIST_CAP;
+    // ---- phase 0: ordered compaction of the RoIs of image n whose footprint may touch this tile
+    if (threadIdx.x == 0) list_n = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < lim; i0 += 256) {
+      const int i = i0 + threadIdx.x;
+      bool hit = false;
+      if (i < lim) {
+        const RoiGeom g = roi_geom(rois + (size_t)(base + i) * 5, ph, pw, scale, sampling_ratio, aligned);
+        if (g.n == n && g.gh > 0 && g.gw > 0) {
+          // conservative footprint: first / last sample of each axis, +-1 pixel for the bilinear taps (the border rows /
+          // columns also collect the clamped samples from [-1, 0] and [size-1, size])
+          const float ys0 = g.y0 + 0.5f * g.bh / (float)g.gh, ys1 = g.y0 + ((float)(ph - 1) + ((float)g.gh - 0.5f) / (float)g.gh) * g.bh;
+          const float xs0 = g.x0 + 0.5f * g.bw / (float)g.gw, xs1 = g.x0 + ((float)(pw - 1) + ((float)g.gw - 0.5f) / (float)g.gw) * g.bw;
+          const float ylo = fminf(ys0, ys1), yhi = fmaxf(ys0, ys1), xlo = fminf(xs0, xs1), xhi = fmaxf(xs0, xs1);
+          hit = (yhi >= (float)(ty0 - 1)) && (ylo <= (float)(ty0 + BT_ROWS)) && (xhi >= (float)(tx0 - 1)) && (xlo <= (float)(tx0 + BT_COLS));
+        }
+      }
+      const unsigned long long m = __ballot(hit);
+      if (lane == 0) wave_cnt[wave] = __popcll(m);
+      __syncthreads();
+      int off = list_n;
+      for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+      if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
+      __syncthreads();
+      if (threadIdx.x == 0) list_n += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+      __syncthreads();
+    }
+    const int nlist = list_n;
+    for (int lb = 0; lb < nlist; lb += BT_LC) {
+      const int lcn = (nlist - lb) < BT_LC ? (nlist - lb) : BT_LC;
+      // ---- phase 1: weight tables of the chunk's RoIs on this tile; task = (list entry, axis, bin)
+      for (int task = threadIdx.x; task < lcn * 32; task += 256) {
+        const int li = task >> 5, b = task & 15, isx = (task >> 4) & 1;
+        const RoiGeom g = roi_geom(rois + (size_t)(base + (int)list[lb + li]) * 5, ph, pw, scale, sampling_ratio, aligned);
+        if (isx) {
+          float w[BT_COLS];
+#pragma unroll
+          for (int t = 0; t < BT_COLS; ++t) w[t] = 0.f;
+          if (b < pw) {
+            for (int ix = 0; ix < g.gw; ++ix) {
+              const float v = g.x0 + (float)b * g.bw + ((float)ix + 0.5f) * g.bw / (float)g.gw;
+              int lo, hi;
+              float wl, wh;
+              if (!axis_taps(v, W, lo, hi, wl, wh)) continue;
+#pragma unroll
+              for (int t = 0; t < BT_COLS; ++t) {
+                if (lo == tx0 + t) w[t] += wl;
+                if (hi == tx0 + t) w[t] += wh;
+              }
+            }
+          }
+          unsigned m = 0;
+#pragma unroll
+          for (int t = 0; t < BT_COLS; ++t) {
+            wxt[li][b][t] = w[t];
+            m |= (w[t] != 0.f ? 1u : 0u) << t;
+          }
+          xmk[li][b] = m;
+        } else {
+          float w[BT_ROWS];
+#pragma unroll
+          for (int t = 0; t < BT_ROWS; ++t) w[t] = 0.f;
+          if (b < ph) {
+            for (int iy = 0; iy < g.gh; ++iy) {
+              const float v = g.y0 + (float)b * g.bh + ((float)iy + 0.5f) * g.bh / (float)g.gh;
+              int lo, hi;
+              float wl, wh;
+              if (!axis_taps(v, H, lo, hi, wl, wh)) continue;
+#pragma unroll
+              for (int t = 0; t < BT_ROWS; ++t) {
+                if (lo == ty0 + t) w[t] += wl;
+                if (hi == ty0 + t) w[t] += wh;
+              }
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < BT_ROWS; ++t) wyt[li][b][t] = w[t] * g.inv_count;
+        }
+      }
+      __syncthreads();
+      if ((int)threadIdx.x < lcn * BT_ROWS) {
+        const int li = threadIdx.x / BT_ROWS, r = threadIdx.x % BT_ROWS;
+        unsigned m = 0;
+        for (int py = 0; py < ph; ++py) m |= (wyt[li][py][r] != 0.f ? 1u : 0u) << py;
+        ymk[li][r] = m;
+      } else if ((int)threadIdx.x >= 128 && (int)threadIdx.x < 128 + lcn) {
+        const int li = threadIdx.x - 128;
+        int lo = pw, hi = 0;
+        for (int px = 0; px < pw; ++px)
+          if (xmk[li][px]) {
+            lo = px < lo ? px : lo;
+            hi = px + 1;
+          }
+        pxr[li][0] = lo;
+        pxr[li][1] = hi;
+      }
+      __syncthreads();
+      // ---- phase 2: wave w gathers for tile row w
+      for (int li = 0; li < lcn; ++li) {
+        unsigned ym = (unsigned)__builtin_amdgcn_readfirstlane((int)ymk[li][wave]);
+        const int pa = __builtin_amdgcn_readfirstlane(pxr[li][0]), pe = __builtin_amdgcn_readfirstlane(pxr[li][1]);
+        if (ym == 0 || pa >= pe) continue;
+        const int roi = base + (int)list[lb + li];
+        const T* __restrict__ go = gout + (size_t)roi * ph * pw * C + (c_ok ? c0 : 0);
+        while (ym) {
+          const int py = __builtin_ctz(ym);
+          ym &= ym - 1;
+          const float a = wyt[li][py][wave];
+          const T* __restrict__ grow = go + (size_t)py * pw * C;
+          {
+            // the whole bin-row segment (<= 16 bins) is requested before the first bin is used (latency-bound loop)
+            vec_t v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+              const int pp = pa + j < pe ? pa + j : pe - 1;
+              if (c_ok) v[j] = *reinterpret_cast<const vec_t*>(grow + (size_t)pp * C);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+              if (pa + j >= pe) break;
+              const unsigned mk = (unsigned)__builtin_amdgcn_readfirstlane((int)xmk[li][pa + j]);
+              if (mk == 0) continue;
+              const f32x4 w0 = *reinterpret_cast<const f32x4*>(&wxt[li][pa + j][0]);
+              const f32x4 w1 = *reinterpret_cast<const f32x4*>(&wxt[li][pa + j][4]);
+              float vf[VEC];
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) vf[i] = c_ok ? (float)v[j][i] : 0.f;
+#pragma unroll
+              for (int t = 0; t < BT_COLS; ++t) {
+                if (mk & (1u << t)) {
+                  const float wt = a * (t < 4 ? w0[t & 3] : w1[t & 3]);
+#pragma unroll
+                  for (int i = 0; i < VEC; ++i) acc[t][i] += wt * vf[i];
+                }
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();  // the tables are rewritten for the next chunk
+    }
+    __syncthreads();  // list is rebuilt for the next chunk of RoIs
+  }
+  const int y = ty0 + wave;
+  if (!c_ok || y >= H) return;
+  float* __restrict__ gmap = gfeat + (((size_t)n * H + y) * W) * C + c0;
+#pragma unroll
+  for (int t = 0; t < BT_COLS; ++t) {
+    const int x = tx0 + t;
+    if (x < W) {
+#pragma unroll
+      for (int i0 = 0; i0 < VEC; i0 += 4) {
+        const f32x4 o = {acc[t][i0], acc[t][i0 + 1], acc[t][i0 + 2], acc[t][i0 + 3]};
+        *reinterpret_cast<f32x4*>(gmap + (size_t)x * C + i0) = o;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // NCHW (reference layout) kernels: one thread per output element / per grad element
 // ------------------------------------------------------------------------------------------
@@ -522,7 +865,19 @@ extern "C" int coin_roi_align_fwd(const void* feat, int N, int C, int H, int W, 
   if (rc) return rc;
   if (R == 0) return COIN_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (layout == COIN_NHWC) {
+  const size_t sep_lds = sizeof(float) * (size_t)W * 16 + sizeof(unsigned) * (size_t)W + 4 * sizeof(int);
+  if (layout == COIN_NHWC && pw <= 2 * FWD_NB && sep_lds <= 64 * 1024) {
+    // separable gather with register-resident output rows (see the kernel)
+    if (dtype == COIN_F32) {
+      const int nparts = (C + 64 * 4 - 1) / (64 * 4);
+      roi_align_fwd_sep_kernel<float><<<R * nparts, 256, sep_lds, st>>>((const float*)feat, rois, (float*)out, C, H, W, R, ph, pw,
+                                                                        spatial_scale, sampling_ratio, aligned, nparts);
+    } else {
+      const int nparts = (C + 64 * 8 - 1) / (64 * 8);
+      roi_align_fwd_sep_kernel<bf16_t><<<R * nparts, 256, sep_lds, st>>>((const bf16_t*)feat, rois, (bf16_t*)out, C, H, W, R, ph, pw,
+                                                                         spatial_scale, sampling_ratio, aligned, nparts);
+    }
+  } else if (layout == COIN_NHWC) {
     const int grid = ((R + 7) / 8) * 8 * ph;
     if (dtype == COIN_F32)
       roi_align_fwd_nhwc_kernel<float><<<grid, 256, 0, st>>>((const float*)feat, rois, (float*)out, C, H, W, R, ph,
@@ -554,16 +909,19 @@ extern "C" int coin_roi_align_bwd(const void* grad_out, int N, int C, int H, int
     if (hipMemsetAsync(grad_feat, 0, sizeof(float) * (size_t)N * C * H * W, st) != hipSuccess) return coin_launch_status();
     if (R == 0) return COIN_OK;
   }
-  if (layout == COIN_NHWC && ph <= BINS && pw <= BINS) {
-    // atomic-free tiled gather: writes every element of grad_feat exactly once
-    const int tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE;
-    dim3 grid(tiles_x * tiles_y * N, (C + BWD_TCH - 1) / BWD_TCH);
-    if (dtype == COIN_F32)
-      roi_align_bwd_tiled_kernel<float><<<grid, 256, 0, st>>>((const float*)grad_out, rois, grad_feat, C, H, W, R, ph, pw,
-                                                               spatial_scale, sampling_ratio, aligned, tiles_x, tiles_y);
-    else
-      roi_align_bwd_tiled_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)grad_out, rois, grad_feat, C, H, W, R, ph, pw,
-                                                                spatial_scale, sampling_ratio, aligned, tiles_x, tiles_y);
+  if (layout == COIN_NHWC && ph <= 16 && pw <= 16) {
+    // atomic-free gather per map tile: writes every element of grad_feat exactly once
+    const int tiles_x = (W + BT_COLS - 1) / BT_COLS, tiles_y = (H + BT_ROWS - 1) / BT_ROWS;
+    const int ntiles = tiles_x * tiles_y * N;
+    if (dtype == COIN_F32) {
+      const int nparts = (C + 64 * 4 - 1) / (64 * 4);
+      roi_align_bwd_gather_kernel<float><<<ntiles * nparts, 256, 0, st>>>((const float*)grad_out, rois, grad_feat, C, H, W, R, ph, pw, spatial_scale,
+                                                                          sampling_ratio, aligned, tiles_x, tiles_y, ntiles, nparts);
+    } else {
+      const int nparts = (C + 64 * 8 - 1) / (64 * 8);
+      roi_align_bwd_gather_kernel<bf16_t><<<ntiles * nparts, 256, 0, st>>>((const bf16_t*)grad_out, rois, grad_feat, C, H, W, R, ph, pw, spatial_scale,
+                                                                           sampling_ratio, aligned, tiles_x, tiles_y, ntiles, nparts);
+    }
   } else if (layout == COIN_NHWC) {
     if (hipMemsetAsync(grad_feat, 0, sizeof(float) * (size_t)N * C * H * W, st) != hipSuccess) return coin_launch_status();
     if (R == 0) return COIN_OK;

@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, COIN_BF16, COIN_F32, COIN_NCHW, COIN_NHWC, CoinHipError, check
 
 __all__ = [
-    "roi_align_fwd", "roi_align_bwd", "gemm_nt", "transpose2d", "bias_act_bwd", "cosine_logits_fwd",
+    "roi_align_fwd", "roi_align_bwd", "gemm_nt", "conv_gemm", "conv_stats_finalize", "transpose2d", "bias_act_bwd", "cosine_logits_fwd",
     "cosine_logits_bwd", "bn_stats", "bn_apply_fwd", "bn_bwd", "avgpool2_fwd", "avgpool2_bwd", "nms_batched", "mil_ce", "mil_focal", "kl_div", "box_reg_l1", "l1_mean", "rpn_losses", "normalize_pad",
     "SgdTable", "EmaTable",
 ]
@@ -171,6 +171,50 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
         check(_lib.lib().coin_gemm_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), m, n, k, _p(bias),
                                       act, float(act_alpha), _dt(a), _dt(out), _stream()), "coin_gemm_nt")
     return out
+
+
+def conv_gemm(a: torch.Tensor, w: torch.Tensor, spatial: Optional[Tuple[int, int, int]] = None, stats_rows: Optional[int] = None,
+              out: Optional[torch.Tensor] = None):
+    """bf16 GEMM / implicit-GEMM convolution (coin_conv_gemm_bf16).
+    a: [M, K] row-major (1x1 convolution on NHWC rows, nn.Linear) or, with ``spatial=(H, W, Cin)``, the NHWC activation flattened
+    to [M, Cin] for the implicit 3x3 / pad 1 convolution (M = NB*H*W);  w: [N, K] with K = Cin or 9*Cin (ky, kx, ci).
+    -> C [M, N] bf16, and -- when ``stats_rows`` is given -- the per-row-tile statistics partials of the stored outputs over the
+    first ``stats_rows`` rows (input of `conv_stats_finalize`)."""
+    _dev(a, w, out)
+    if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or a.dim() != 2 or w.dim() != 2 or a.stride(1) != 1 or w.stride(1) != 1:
+        raise CoinHipError("conv_gemm needs 2-D K-contiguous bf16 operands")
+    m, n, k = a.shape[0], w.shape[0], w.shape[1]
+    if spatial is None:
+        if a.shape[1] != k:
+            raise CoinHipError(f"conv_gemm shape mismatch {tuple(a.shape)} x {tuple(w.shape)}^T")
+        mode, h, wd, cin = 0, 0, 0, 0
+    else:
+        h, wd, cin = spatial
+        if a.shape[1] != cin or k != 9 * cin or not a.is_contiguous() or m % (h * wd):
+            raise CoinHipError("conv_gemm (3x3): a must be the contiguous [NB*H*W, Cin] activation and w [Cout, 9*Cin]")
+        mode = 1
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
+    elif out.shape != (m, n) or out.stride(1) != 1 or out.dtype != torch.bfloat16:
+        raise CoinHipError("conv_gemm: bad `out`")
+    part = None
+    if stats_rows is not None:
+        part = torch.empty(_lib.lib().coin_conv_gemm_stats_bytes(m, n) // 4, dtype=torch.float32, device=a.device)
+    with _timed("coin_conv_gemm_bf16", 2 * m * n * k):  # "bytes" slot carries FLOPs for the MFMA entry point
+        check(_lib.lib().coin_conv_gemm_bf16(_p(a), a.stride(0), mode, h, wd, cin, _p(w), w.stride(0), _p(out), out.stride(0), m, n, k,
+                                             _p(part), int(stats_rows or 0), _stream()), "coin_conv_gemm_bf16")
+    return out, part
+
+
+def conv_stats_finalize(part: torch.Tensor, m: int, n: int, rows: int, eps: float, momentum: float,
+                        running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None):
+    """Per-channel batch mean / rstd (+ in-place running statistics) from `conv_gemm`'s partials."""
+    _dev(part, running_mean, running_var)
+    mean = torch.empty(n, dtype=torch.float32, device=part.device)
+    rstd = torch.empty(n, dtype=torch.float32, device=part.device)
+    check(_lib.lib().coin_conv_gemm_stats_finalize(_p(part), m, n, int(rows), float(eps), float(momentum), _p(mean), _p(rstd), _p(running_mean),
+                                                   _p(running_var), _stream()), "coin_conv_gemm_stats_finalize")
+    return mean, rstd
 
 
 def transpose2d(x: torch.Tensor) -> torch.Tensor:

@@ -156,6 +156,26 @@ int coin_cosine_logits_bwd(const float* d_scores, const void* feats, int ldf, co
                            float inv_scale, void* d_feats, float* d_text, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * bf16 GEMM / implicit-GEMM convolution of the res5 bottlenecks on the RoI tiles (coin/modeling/utils.py:77-90,184-186 as run by
+ * coin/modeling/roi_heads/clip_roi_heads.py:172-176): replaces the cuDNN convolutions of `backbone.layer4` forward and
+ * data-gradient (the weight gradient stays a library contraction).
+ *   C[M,N] (bf16, row stride ldc) = Aop[M,K] . B[N,K]^T      fp32 accumulation, bf16 operands, K % 64 == 0
+ *   mode 0: Aop = A, a row-major [M,K] matrix (row stride lda): 1x1 convolution on NHWC activations, nn.Linear;
+ *   mode 1: implicit 3x3 / pad 1 / stride 1 convolution: A = NHWC activation [M/(H*W), H, W, Cin], K = 9*Cin ordered
+ *           (ky, kx, ci) = the channels-last weight layout [Cout][3][3][Cin]; taps outside the image read zeros.
+ * The data-gradient is the same contraction with the weight re-laid as [Cin][flipped tap][Cout].
+ * stats (optional): per (256-row tile, column) statistics of the STORED bf16 outputs over rows < stats_rows, as
+ *   stats[tile][0][n] = pivot (the tile's first row), [1][n] = sum(x - pivot), [2][n] = sum((x - pivot)^2);
+ *   coin_conv_gemm_stats_bytes(M, N) bytes.  coin_conv_gemm_stats_finalize turns them into the train-mode BatchNorm
+ *   statistics (mean, 1/sqrt(var + eps), running statistics as nn.BatchNorm2d) in a fixed summation order: the separate
+ *   statistics pass over the activation (coin_bn_stats) is not needed after a convolution run through this entry point. */
+size_t coin_conv_gemm_stats_bytes(int M, int N);
+int coin_conv_gemm_bf16(const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb,
+                        void* C, int ldc, int M, int N, int K, float* stats, int64_t stats_rows, void* stream);
+int coin_conv_gemm_stats_finalize(const float* partials, int M, int N, int64_t rows, float eps, float momentum,
+                                  float* mean, float* rstd, float* running_mean, float* running_var, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused losses: each computes the scalar loss AND the gradient w.r.t. its differentiable
  * input for a unit upstream gradient, in one launch.  `loss` is a single float32 that is
  * OVERWRITTEN.  Rows are independent; per-row reductions use wavefront shuffles.

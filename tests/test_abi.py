@@ -47,7 +47,7 @@ def test_binding_table_matches_header(lib):
             if not is_ptr:
                 want = {"int": ctypes.c_int, "float": ctypes.c_float, "int64_t": ctypes.c_int64}[d.split()[-2] if len(d.split()) > 1 else d]
                 assert ct is want, (name, d, ct)
-    unbound = set(decl) - set(_lib.SIGNATURES) - {"coin_abi_version", "coin_build_arch", "coin_nms_workspace_bytes"}
+    unbound = set(decl) - set(_lib.SIGNATURES) - {"coin_abi_version", "coin_build_arch", "coin_nms_workspace_bytes", "coin_conv_gemm_stats_bytes"}
     assert not unbound, unbound
 
 
@@ -67,6 +67,8 @@ def test_argument_validation_without_gpu(lib):
     assert lib.coin_gemm_nt(None, 8, None, 8, None, 8, 1, 1, 8, None, 0, 0.0, 0, 0, None) == -1
     assert lib.coin_mil_ce_fwd_bwd(None, 9, None, None, None, 4, 9, 1, 1, None, None, None) == -1
     assert lib.coin_nms_batched(None, None, 1, 20000, 0.5, 10, None, None, None, None) == -1
+    assert lib.coin_conv_gemm_bf16(None, 64, 0, 0, 0, 0, None, 64, None, 8, 256, 8, 64, None, 0, None) == -1
+    assert lib.coin_conv_gemm_stats_bytes(401408, 512) == 1568 * 3 * 512 * 4
 
 
 def test_product_has_no_cpu_fallback():

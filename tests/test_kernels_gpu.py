@@ -181,6 +181,49 @@ def test_gemm_nt_f32_exact_path(K, m, n, k):
     assert torch.equal(out, basym.t())
 
 
+@pytest.mark.parametrize("m,n,k", [(256, 128, 64), (1000, 200, 192), (4096, 512, 1024), (300, 2048, 512), (37, 8, 64)])
+def test_conv_gemm_1x1_and_stats_vs_fp64(K, m, n, k):
+    """coin_conv_gemm_bf16 mode 0 (1x1 convolution / linear) + the fused BatchNorm statistics of the stored outputs."""
+    g = torch.Generator().manual_seed(m + n + k)
+    a = (torch.randn(m, k, generator=g) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(n, k, generator=g) * 0.1 + 0.02).to(torch.bfloat16)
+    rows = m - m // 7
+    out, part = K.conv_gemm(dev(a), dev(w), stats_rows=rows)
+    ref = a.double() @ w.double().t()
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-2, atol=1e-2 * float(ref.abs().max()))  # one bf16 rounding of the output
+    bn_rm, bn_rv = torch.zeros(n, device="cuda"), torch.ones(n, device="cuda")
+    mean, rstd = K.conv_stats_finalize(part, m, n, rows, 1e-5, 0.1, bn_rm, bn_rv)
+    y = out[:rows].double()                                  # statistics of the STORED values over the first `rows` rows
+    mu, var = y.mean(0), y.var(0, unbiased=False)
+    torch.testing.assert_close(mean.double(), mu, rtol=1e-5, atol=1e-5 * float(y.abs().max()))
+    torch.testing.assert_close(rstd.double(), (var + 1e-5).rsqrt(), rtol=1e-4, atol=0)
+    torch.testing.assert_close(bn_rm.double(), 0.1 * mu, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bn_rv.double(), 0.9 + 0.1 * y.var(0, unbiased=True), rtol=1e-4, atol=1e-6)
+    out2, none = K.conv_gemm(dev(a), dev(w))
+    assert none is None and torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("nb,h,w,cin,cout", [(3, 7, 7, 64, 128), (2, 14, 14, 128, 64), (1, 5, 9, 192, 40), (5, 7, 7, 512, 512)])
+def test_conv_gemm_3x3_vs_torch(K, nb, h, w, cin, cout):
+    """coin_conv_gemm_bf16 mode 1 = F.conv2d(x, W, padding=1) on NHWC bf16 (fp64 reference on the same bf16 inputs), and the
+    data-gradient as the same contraction with the weight re-laid [Cin][flipped tap][Cout]."""
+    g = torch.Generator().manual_seed(nb * h + cin)
+    x = torch.randn(nb, cin, h, w, generator=g).to(torch.bfloat16)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(torch.bfloat16)
+    ref = F.conv2d(x.double(), wt.double(), padding=1)
+    xa = dev(x.permute(0, 2, 3, 1).contiguous().reshape(-1, cin))
+    wk = dev(wt.permute(0, 2, 3, 1).contiguous().reshape(cout, 9 * cin))
+    out, _ = K.conv_gemm(xa, wk, spatial=(h, w, cin))
+    got = out.reshape(nb, h, w, cout).permute(0, 3, 1, 2).cpu().double()
+    torch.testing.assert_close(got, ref, rtol=1e-2, atol=1e-2 * float(ref.abs().max()))
+    if cout % 64 == 0:  # dgrad: contraction over Cout must be a multiple of the K-step
+        gy = torch.randn(nb, cout, h, w, generator=g).to(torch.bfloat16)
+        gref = torch.nn.grad.conv2d_input(x.shape, wt.double(), gy.double(), padding=1)
+        wd = dev(wt.flip(2, 3).permute(1, 2, 3, 0).contiguous().reshape(cin, 9 * cout))
+        gx, _ = K.conv_gemm(dev(gy.permute(0, 2, 3, 1).contiguous().reshape(-1, cout)), wd, spatial=(h, w, cout))
+        torch.testing.assert_close(gx.reshape(nb, h, w, cin).permute(0, 3, 1, 2).cpu().double(), gref, rtol=1e-2, atol=1e-2 * float(gref.abs().max()))
+
+
 def test_gemm_rejects_bad_shapes(K):
     from coin_amd._lib import CoinHipError
 
