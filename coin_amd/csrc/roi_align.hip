@@ -164,7 +164,7 @@ __device__ __forceinline__ float bin_weight(float start, float binsz, int grid, 
 // this moves 2.5-5x fewer bytes through the vector L1, which is what bounded that kernel (0.26 of the HBM peak).
 // ------------------------------------------------------------------------------------------
 constexpr int FWD_NB = 8;   // bins per work item = accumulator vectors per lane
-constexpr int FWD_NX = 12;  // map columns requested together
+constexpr int FWD_NX = 8;   // map columns requested together
 
 template <typename T>
 __global__ __launch_bounds__(256) void roi_align_fwd_sep_kernel(
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_sep_kernel(
   __syncthreads();
 
   const int nh = (pw + FWD_NB - 1) / FWD_NB;
-  const T* __restrict__ fmap = feat + (size_t)g.n * H * W * C + (c_ok ? c0 : 0);
+  const T* __restrict__ fmap = feat + (size_t)g.n * H * W * C + (c_ok ? c0 : 0);  // lanes beyond C read channel 0 (never stored)
   for (int item = wave; item < ph * nh; item += 4) {
     const int py = item / nh, hx = item - py * nh;
     const int pb = hx * FWD_NB;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_sep_kernel(
 #pragma unroll
               for (int j = 0; j < FWD_NX; ++j) {
                 const int xx = x + j <= xhi ? x + j : xhi;  // clamped: the tail re-reads a valid column, its mask is skipped
-                if (c_ok) v[j] = *reinterpret_cast<const vec_t*>(rowp + (size_t)xx * C);
+                v[j] = *reinterpret_cast<const vec_t*>(rowp + (size_t)xx * C);
               }
 #pragma unroll
               for (int j = 0; j < FWD_NX; ++j) {
@@ -253,10 +253,11 @@ __global__ __launch_bounds__(256) void roi_align_fwd_sep_kernel(
                 const f32x4 w1 = *reinterpret_cast<const f32x4*>(&wx[(x + j) * 16 + pb + 4]);
                 float vf[VEC];
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) vf[i] = c_ok ? (float)v[j][i] : 0.f;
+                for (int i = 0; i < VEC; ++i) vf[i] = (float)v[j][i];
 #pragma unroll
                 for (int t = 0; t < FWD_NB; ++t) {
                   if (mk & (1u << t)) {
+                    asm volatile("; bin taken");  // keeps this a (wave-uniform) branch: hipcc otherwise if-converts it into 8 FMAs + 8 selects per bin
                     const float wt = a * (t < 4 ? w0[t & 3] : w1[t & 3]);
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) acc[t][i] += wt * vf[i];
@@ -726,27 +727,27 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
           ym &= ym - 1;
           const float a = wyt[li][py][wave];
           const T* __restrict__ grow = go + (size_t)py * pw * C;
-          {
-            // the whole bin-row segment (<= 16 bins) is requested before the first bin is used (latency-bound loop)
-            vec_t v[16];
+          for (int px = pa; px < pe; px += 4) {
+            vec_t v[4];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-              const int pp = pa + j < pe ? pa + j : pe - 1;
-              if (c_ok) v[j] = *reinterpret_cast<const vec_t*>(grow + (size_t)pp * C);
+            for (int j = 0; j < 4; ++j) {
+              const int pp = px + j < pe ? px + j : pe - 1;
+              v[j] = *reinterpret_cast<const vec_t*>(grow + (size_t)pp * C);
             }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-              if (pa + j >= pe) break;
-              const unsigned mk = (unsigned)__builtin_amdgcn_readfirstlane((int)xmk[li][pa + j]);
+            for (int j = 0; j < 4; ++j) {
+              if (px + j >= pe) break;
+              const unsigned mk = (unsigned)__builtin_amdgcn_readfirstlane((int)xmk[li][px + j]);
               if (mk == 0) continue;
-              const f32x4 w0 = *reinterpret_cast<const f32x4*>(&wxt[li][pa + j][0]);
-              const f32x4 w1 = *reinterpret_cast<const f32x4*>(&wxt[li][pa + j][4]);
+              const f32x4 w0 = *reinterpret_cast<const f32x4*>(&wxt[li][px + j][0]);
+              const f32x4 w1 = *reinterpret_cast<const f32x4*>(&wxt[li][px + j][4]);
               float vf[VEC];
 #pragma unroll
-              for (int i = 0; i < VEC; ++i) vf[i] = c_ok ? (float)v[j][i] : 0.f;
+              for (int i = 0; i < VEC; ++i) vf[i] = (float)v[j][i];
 #pragma unroll
               for (int t = 0; t < BT_COLS; ++t) {
                 if (mk & (1u << t)) {
+                  asm volatile("; col taken");  // a real wave-uniform branch (see the forward kernel)
                   const float wt = a * (t < 4 ? w0[t & 3] : w1[t & 3]);
 #pragma unroll
                   for (int i = 0; i < VEC; ++i) acc[t][i] += wt * vf[i];

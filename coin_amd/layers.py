@@ -105,6 +105,89 @@ def conv2d(x: torch.Tensor, conv: torch.nn.Conv2d) -> torch.Tensor:
                                       conv.dilation, conv.groups)
 
 
+# --------------------------------------------------------------------------- convolutions on the hand-written GEMM
+# res5 runs on the RoI tiles ([R*196, 1024] ... [R*49, 2048] rows): its 1x1 convolutions are NHWC GEMMs that sit on the HBM
+# roofline and its 3x3 convolutions implicit GEMMs; forward and data-gradient go through coin_conv_gemm_bf16 (with the BatchNorm
+# statistics of the output taken in the epilogue), the weight gradient stays a library contraction.  bf16 compute mode only: the
+# fp32 parity mode keeps the library's fp32 convolutions.
+CONV_GEMM = {"enabled": False, "min_rows": 32768}
+
+
+def _conv_gemm_ok(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
+    if not (CONV_GEMM["enabled"] and x.is_cuda and x.dim() == 4 and compute_dtype_of(x) == torch.bfloat16):
+        return False
+    ks = conv.kernel_size
+    if ks not in ((1, 1), (3, 3)) or conv.stride != (1, 1) or conv.padding != (ks[0] // 2, ks[1] // 2) or conv.dilation != (1, 1):
+        return False
+    if conv.groups != 1 or conv.bias is not None or conv.in_channels % 64 or conv.out_channels % 64:
+        return False
+    return x.shape[0] * x.shape[2] * x.shape[3] >= CONV_GEMM["min_rows"]
+
+
+class _ConvGemm(Function):
+    """nn.Conv2d (1x1, or 3x3 / pad 1; stride 1, no bias) of the CLIP Bottleneck (coin/modeling/utils.py:40-58,77-90) on
+    channels-last bf16 activations."""
+
+    @staticmethod
+    def forward(ctx, x, weight, wq, stats_rows):
+        xn = _as_nhwc(x)
+        n, h, w, c = xn.shape
+        co, ks = wq.shape[0], wq.shape[2]
+        wk = wq.permute(0, 2, 3, 1)
+        wk = (wk if wk.is_contiguous() else wk.contiguous()).reshape(co, ks * ks * c)
+        out, part = K.conv_gemm(xn.reshape(n * h * w, c), wk, spatial=(h, w, c) if ks == 3 else None, stats_rows=stats_rows)
+        ctx.save_for_backward(x, wq)
+        ctx.ks = ks
+        if part is None:
+            part = out.new_zeros(0, dtype=torch.float32)
+        ctx.mark_non_differentiable(part)
+        return out.view(n, h, w, co).permute(0, 3, 1, 2), part
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy, _gpart):
+        x, wq = ctx.saved_tensors
+        ks, pad = ctx.ks, ctx.ks // 2
+        gyn = _as_nhwc(gy)
+        if gyn.dtype != torch.bfloat16:
+            gyn = gyn.to(torch.bfloat16)
+        n, h, w, co = gyn.shape
+        ci = wq.shape[1]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            # dgrad = the same contraction over (flipped tap, Cout): weight re-laid [Cin][ky'][kx'][Cout] (a few MB, once per call)
+            wd = wq.flip(2, 3).permute(1, 2, 3, 0).contiguous().reshape(ci, ks * ks * co)
+            gx, _ = K.conv_gemm(gyn.reshape(n * h * w, co), wd, spatial=(h, w, co) if ks == 3 else None)
+            dx = gx.view(n, h, w, ci).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            dw = torch.ops.aten.convolution_backward(gyn.permute(0, 3, 1, 2), x, wq, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1].float()
+        return dx, dw, None, None
+
+
+def conv2d_gemm(x: torch.Tensor, conv: torch.nn.Conv2d, stats_rows: Optional[int] = None):
+    """-> (conv(x), statistics partials or None); caller checked `_conv_gemm_ok`."""
+    if x.dtype != torch.bfloat16:
+        x = x.to(torch.bfloat16)
+    wq = _shadow_entry(conv.weight, torch.bfloat16).tensor
+    y, part = _ConvGemm.apply(x, conv.weight, wq, stats_rows)
+    return y, (part if stats_rows is not None else None)
+
+
+def conv_bn_act(x: torch.Tensor, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, relu: bool, residual: Optional[torch.Tensor] = None,
+                pool: int = 1) -> torch.Tensor:
+    """conv -> train-mode BatchNorm (+ identity) (+ ReLU) (+ pool): with the hand-written GEMM the BatchNorm statistics come out of
+    the convolution's epilogue (no statistics pass over the activation)."""
+    if _conv_gemm_ok(x, conv):
+        if bn.training and bn.momentum is not None:
+            nv = _VALID_ROWS[0]
+            rows = (x.shape[0] if nv is None or nv >= x.shape[0] else int(nv)) * x.shape[2] * x.shape[3]
+            y, part = conv2d_gemm(x, conv, stats_rows=rows)
+            return bn_act(y, bn, relu, residual, pool, stats_part=(part, rows))
+        return bn_act(conv2d_gemm(x, conv)[0], bn, relu, residual, pool)
+    return bn_act(conv2d(x, conv), bn, relu, residual, pool)
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     dt = compute_dtype_of(x)
     if x.dtype != dt:
@@ -174,13 +257,18 @@ class _BNAct(Function):
     as two HIP streams forward and two backward (coin_bn_stats / coin_bn_apply_fwd / coin_bn_bwd)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, pool):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, pool, stats_part=None):
         xn = _as_nhwc(x)
         rn = _as_nhwc(residual) if residual is not None else None
         g, b = gamma.float().contiguous(), beta.float().contiguous()
         nv = _VALID_ROWS[0]
         nv = None if (nv is None or nv >= xn.shape[0]) else int(nv)
-        mean, rstd = K.bn_stats(xn if nv is None else xn[:nv], eps, momentum, running_mean, running_var)
+        if stats_part is not None:  # taken in the producing convolution's epilogue (coin_conv_gemm_bf16) over the same valid rows
+            part, rows = stats_part
+            assert rows == (xn.shape[0] if nv is None else nv) * xn.shape[1] * xn.shape[2]
+            mean, rstd = K.conv_stats_finalize(part, xn.shape[0] * xn.shape[1] * xn.shape[2], xn.shape[3], rows, eps, momentum, running_mean, running_var)
+        else:
+            mean, rstd = K.bn_stats(xn if nv is None else xn[:nv], eps, momentum, running_mean, running_var)
         y = K.bn_apply_fwd(xn, mean, rstd, g, b, rn, relu, pool)
         ctx.relu, ctx.pool, ctx.has_res, ctx.nv = relu, pool, residual is not None, nv
         # pool 1: the saved output is only needed for the ReLU mask when a residual was added (otherwise coin_bn_bwd recomputes
@@ -213,10 +301,11 @@ class _BNAct(Function):
                 dres = torch.zeros_like(xn)
                 dres[:nv] = dresv
         return (dx.permute(0, 3, 1, 2), dgamma, dbeta, dres.permute(0, 3, 1, 2) if dres is not None else None,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
-def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm2d, relu: bool, residual: Optional[torch.Tensor] = None, pool: int = 1) -> torch.Tensor:
+def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm2d, relu: bool, residual: Optional[torch.Tensor] = None, pool: int = 1,
+           stats_part=None) -> torch.Tensor:
     """Train-mode BatchNorm with batch statistics (per GPU, as the reference) fused with the elementwise tail.
     x / residual / result: logical [N,C,H,W] in channels-last memory format.
     pool: 1 = none, 2 = nn.AvgPool2d(2) fused in, 0 = global spatial mean fused in (result [N,C,1,1])."""
@@ -227,7 +316,7 @@ def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm2d, relu: bool, residual: Opti
             bn.num_batches_tracked.add_(1)
         rm = bn.running_mean if bn.track_running_stats else None
         rv = bn.running_var if bn.track_running_stats else None
-        return _BNAct.apply(x, bn.weight, bn.bias, residual, rm, rv, float(bn.momentum), float(bn.eps), bool(relu), int(pool))
+        return _BNAct.apply(x, bn.weight, bn.bias, residual, rm, rv, float(bn.momentum), float(bn.eps), bool(relu), int(pool), stats_part)
     # eval mode (teacher inference): a per-channel affine map with the running statistics
     if x.is_cuda and not (torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad)):
         # no gradient wanted: the fused apply kernel with (running_mean, 1/sqrt(running_var + eps)) as the statistics

@@ -128,14 +128,14 @@ class Bottleneck(nn.Module):
         # trainable stage: every BatchNorm + elementwise tail is a fused HIP stream (coin_amd.layers.bn_act)
         pool = 2 if self.stride > 1 else 1
         assert self.stride in (1, 2)
-        y = L.bn_act(L.conv2d(x, self.conv1), self.bn1, relu=True)
-        y = L.bn_act(L.conv2d(y, self.conv2), self.bn2, relu=True, pool=pool)          # ReLU and the anti-aliasing avg-pool fused in
+        y = L.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        y = L.conv_bn_act(y, self.conv2, self.bn2, relu=True, pool=pool)               # ReLU and the anti-aliasing avg-pool fused in
         if self.downsample is not None:
             sx = L.avg_pool2(x) if pool == 2 else x
-            sx = L.bn_act(L.conv2d(sx, self.downsample[1]), self.downsample[2], relu=False)
+            sx = L.conv_bn_act(sx, self.downsample[1], self.downsample[2], relu=False)
         else:
             sx = x
-        return L.bn_act(L.conv2d(y, self.conv3), self.bn3, relu=True, residual=sx, pool=0 if mean_pool else 1)  # bn3 + identity + ReLU
+        return L.conv_bn_act(y, self.conv3, self.bn3, relu=True, residual=sx, pool=0 if mean_pool else 1)  # bn3 + identity + ReLU
 
 
 class ModifiedResNet(nn.Module):

@@ -13,6 +13,7 @@ import torch
 from torch import nn
 
 from .. import kernels as K
+from .. import layers as L
 from .._lib import COIN_NHWC
 from ..box_ops import detector_postprocess
 from ..registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY
@@ -55,6 +56,9 @@ class OpenVocabularyRCNN(nn.Module):
 
     @classmethod
     def from_config(cls, cfg):
+        import os
+
+        L.CONV_GEMM["enabled"] = bool(cfg.AMD.CONV_GEMM) and os.environ.get("COIN_CONV_GEMM", "1") != "0"
         backbone = build_backbone(cfg)
         if cfg.MODEL.ROI_HEADS.POOLING_TYPE != "attnpool":
             backbone.del_attnpool()

@@ -90,6 +90,51 @@ def test_real_width_res5_on_device_vs_reference_and_fp64():
                     ("" if r[4] is None else f" | max-err vs fp64: product {r[4]:.2e}  reference {r[5]:.2e}") for r in rows))
 
 
+def test_real_width_res5_bf16_conv_gemm_vs_library_convs_and_fp64():
+    """The throughput mode of res5 at real widths: bf16 activations, convolutions forward / dgrad on coin_conv_gemm_bf16 with the
+    BatchNorm statistics taken in its epilogue, against (a) the same bf16 graph on the library's convolutions and (b) the fp64
+    oracle: the hand-written path must be as close to fp64 as the library path is (relative L2; bf16 storage sets the scale)."""
+    import real_width as RW
+    import seeded
+    from coin_amd import layers as L
+    from coin_amd.modeling.backbone import Bottleneck
+    from oracle import coin as OC
+
+    z, x, gy = RW.res5_inputs()
+    o64 = torch.nn.Sequential(OC.Bottleneck(1024, 512, 2), OC.Bottleneck(2048, 512, 1), OC.Bottleneck(2048, 512, 1))
+    seeded.fill_module(o64, 501)
+    y64, gx64, g64, _ = RW.run_res5(o64, x, gy, dtype=torch.float64)
+
+    def run(gemm):
+        net = torch.nn.Sequential(Bottleneck(1024, 512, 2), Bottleneck(2048, 512), Bottleneck(2048, 512))
+        seeded.fill_module(net, 501)
+        saved = dict(L.CONV_GEMM)
+        L.CONV_GEMM.update(enabled=gemm, min_rows=0)
+        try:
+            def fwd(n, xx):
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    h = n[1](n[0](xx.to(torch.bfloat16)))
+                    return n[2](h, mean_pool=True).flatten(1).float()
+            return RW.run_res5(net, x, gy, device=DEV, mean_pool=fwd)
+        finally:
+            L.CONV_GEMM.update(saved)
+
+    res = {g: run(g) for g in (False, True)}
+    names = ["0.conv1.weight", "0.conv2.weight", "0.downsample.0.weight", "1.conv3.weight", "2.conv2.weight", "0.bn2.weight", "2.bn3.bias"]
+    rows = []
+    for what, pick in [("y", lambda r: r[0]), ("gx", lambda r: r[1])] + [(n, (lambda r, n=n: r[2][n])) for n in names]:
+        ex = {"y": y64, "gx": gx64}.get(what, g64.get(what))
+        e_lib, e_own = RW.l2_err(pick(res[False]), ex), RW.l2_err(pick(res[True]), ex)
+        rows.append((what, e_lib, e_own, RW.l2_err(pick(res[True]), pick(res[False]))))
+    print("\n".join(f"res5 bf16 {n:24s} L2 vs fp64: library convs {a:.2e}  conv_gemm {b:.2e} | conv_gemm vs library {c:.2e}" for n, a, b, c in rows))
+    for n, a, b, c in rows:
+        assert b <= max(1.5 * a, 2e-2), (n, a, b)
+    sd_lib, sd_own = res[False][3], res[True][3]
+    for k in sd_lib:
+        if "running" in k:  # the epilogue statistics are those of the stored activations
+            torch.testing.assert_close(sd_own[k].float(), sd_lib[k].float(), rtol=2e-2, atol=2e-3)
+
+
 def test_real_width_box_predictor_on_device_vs_reference():
     """FastRCNNOutputLayers at 2048 -> 1024 -> 1024 -> 2048 -> (1024-d cosine logits vs 9 classes, 4 deltas), 512 RoIs, pre_train
     losses: scores / deltas / losses 1e-4, gradients 1e-4 of the tensor's scale (exact-f32 MFMA path)."""
