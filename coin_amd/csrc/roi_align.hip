@@ -16,6 +16,7 @@
 // naive backward on this chip (~1.3 TB/s of atomic bytes, MI355X_MICROARCH.md "Global float atomics").
 //
 // The NCHW kernels are the layout-compatible (reference layout) path: one thread per element.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -866,8 +867,13 @@ extern "C" int coin_roi_align_fwd(const void* feat, int N, int C, int H, int W, 
   if (rc) return rc;
   if (R == 0) return COIN_OK;
   hipStream_t st = (hipStream_t)stream;
+  // Forward variants (both exact to rounding): 0 = one thread per output vector, 4 taps per sample (wins on the detector's
+  // proposal mix, where half of the RoIs are smaller than 64 px: measured 0.39 ms against 0.50 ms at the benchmark shape);
+  // 1 = separable gather with register-resident output rows (wins on large RoIs: 0.46 ms against 0.51 ms on a uniform
+  // 32..400 px mix).  The shipped choice is 0; COIN_ROI_ALIGN_FWD=1 selects the other one for measurements.
+  static const int variant = [] { const char* e = getenv("COIN_ROI_ALIGN_FWD"); return e && e[0] == '1' ? 1 : 0; }();
   const size_t sep_lds = sizeof(float) * (size_t)W * 16 + sizeof(unsigned) * (size_t)W + 4 * sizeof(int);
-  if (layout == COIN_NHWC && pw <= 2 * FWD_NB && sep_lds <= 64 * 1024) {
+  if (layout == COIN_NHWC && pw <= 2 * FWD_NB && sep_lds <= 64 * 1024 && variant == 1) {
     // separable gather with register-resident output rows (see the kernel)
     if (dtype == COIN_F32) {
       const int nparts = (C + 64 * 4 - 1) / (64 * 4);

@@ -1341,10 +1341,52 @@ def case_real_width():
     npz("real_width_box_predictor", **out)
 
 
+def case_rn101():
+    """BASELINE configs[3] (targetDET, RN101 backbone, BDD100K: 7 classes, D = 512, MERGE_DIM 512 -- configs/coin/GDINO/clipart.yaml:4-8,
+    coin/modeling/utils.py:184-186 with layers (3, 4, 23, 3), coin/data/datasets/builtin.py:162): the reference's ModifiedResNet-101
+    trunk (frozen stem + layer1, train-mode BN in layer2 / layer3) on a small image and its CKGNet at 512 dims / 8 classes.
+    Weights and inputs are seeded (tests/seeded.py); res5 of RN101 is RN50's (real_width_res5)."""
+    sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..")))
+    import seeded
+
+    mu = shim.ref("coin.modeling.utils")
+    torch.manual_seed(0)
+    net = mu.ModifiedResNet(layers=(3, 4, 23, 3), output_dim=512, heads=32, width=64, out_features=["res4"], freeze_at=0, depth=101)
+    seeded.fill_module(net, 601)       # filled BEFORE freezing: the FrozenBatchNorm conversion copies these statistics
+    net.freeze(2)
+    net.train()
+    x = seeded.randn((2, 3, 96, 128), 602)
+    y = net(x)["res4"]
+    gy = seeded.randn(tuple(y.shape), 603)
+    (y * gy).sum().backward()
+    p = dict(net.named_parameters())
+    out = {"x_checksum": np.array(seeded.checksum(x)), "w_checksum": np.array(seeded.checksum(p["layer3.22.conv2.weight"])), "res4": y,
+           "frozen_names": np.array([n for n, q in p.items() if not q.requires_grad]),
+           "g::layer3.22.conv3.weight_sub": _sub(p["layer3.22.conv3.weight"].grad, 8, 4, 1, 1), "g::layer3.11.conv2.weight_sub": _sub(p["layer3.11.conv2.weight"].grad, 4, 4, 1, 1),
+           "g::layer3.0.conv1.weight_sub": _sub(p["layer3.0.conv1.weight"].grad, 2, 8, 1, 1), "g::layer2.0.conv1.weight": p["layer2.0.conv1.weight"].grad,
+           "g::layer3.22.bn3.weight": p["layer3.22.bn3.weight"].grad, "g::layer3.5.bn1.bias": p["layer3.5.bn1.bias"].grad, "g::layer2.3.bn2.weight": p["layer2.3.bn2.weight"].grad,
+           "after::layer3.22.bn1.running_mean": net.state_dict()["layer3.22.bn1.running_mean"], "after::layer2.0.bn3.running_var": net.state_dict()["layer2.0.bn3.running_var"]}
+    npz("rn101_res4", **out)
+    ckg = shim.ref("coin.modeling.merge.ckg")
+    torch.manual_seed(0)
+    merge = ckg.CKGNet(hidden_size=512, all_head_size=512, num_classes=8, logger=None)   # 8 heads (ckg.py default), 7 classes + background
+    seeded.fill_module(merge, 611)
+    g = torch.Generator().manual_seed(612)
+    xm = torch.randn(40, 512, generator=g)
+    poff, pon = F.normalize(torch.randn(8, 512, generator=g), dim=1), F.normalize(torch.randn(8, 512, generator=g), dim=1)
+    a, b = torch.softmax(3 * torch.randn(40, 8, generator=g), 1), torch.softmax(3 * torch.randn(40, 8, generator=g), 1)
+    ym = merge(xm, poff, pon, a, b)
+    gym = torch.randn(ym.shape, generator=g)
+    (ym * gym).sum().backward()
+    npz("rn101_ckg", x=xm, proto_off=poff, proto_on=pon, probs_off=a, probs_on=b, y=ym, gy=gym,
+        w_checksum=np.array(seeded.checksum(dict(merge.named_parameters())[sorted(dict(merge.named_parameters()))[0]])),
+        **{"mg::" + n + "_sub": _sub(q.grad, *([4, 4] if q.dim() == 2 else [1])) for n, q in merge.named_parameters()})
+
+
 
 CASES = [case_mil_losses, case_bottleneck, case_resnet, case_box_predictor_pretrain, case_box_predictor_step,
          case_text_encoder, case_ckg, case_lr_and_fusion, case_optimizer_groups, case_rpn, case_roi_sampling,
-         case_e2e_pretrain, case_e2e_step_and_inference, case_ema, case_match_dual_teacher, case_e2e_coin_step, case_voc_eval, case_voc_dataset, case_clip_relabel, case_real_width]
+         case_e2e_pretrain, case_e2e_step_and_inference, case_ema, case_match_dual_teacher, case_e2e_coin_step, case_voc_eval, case_voc_dataset, case_clip_relabel, case_real_width, case_rn101]
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])

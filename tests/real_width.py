@@ -184,3 +184,81 @@ def run_head(bp, z, x, make_inst, device="cpu"):
     grads = {n: (p.grad.detach().cpu() if p.grad is not None else torch.zeros_like(p).cpu()) for n, p in bp.named_parameters()}
     return (scores.detach().cpu(), deltas.detach().cpu(), {k: float(v) for k, v in losses.items()}, xx.grad.detach().cpu(), grads,
             bp.text_encoder.per_class_feat.detach().cpu())
+
+
+# ------------------------------------------------------------------------------------------ RN101 trunk + CKG at MERGE_DIM 512 (BASELINE configs[3])
+RN101_SUB = {"layer3.22.conv3.weight": (8, 4, 1, 1), "layer3.11.conv2.weight": (4, 4, 1, 1), "layer3.0.conv1.weight": (2, 8, 1, 1)}
+
+
+def rn101_inputs():
+    z = load("rn101_res4")
+    x = seeded.randn((2, 3, 96, 128), 602)
+    assert abs(seeded.checksum(x) - float(z["x_checksum"])) <= 1e-9 * abs(float(z["x_checksum"]))
+    return z, x, seeded.randn(tuple(z["res4"].shape), 603)
+
+
+def run_rn101(net, x, gy, device="cpu", dtype=torch.float32):
+    """net: a ModifiedResNet((3,4,23,3)) built with freeze_at=0 -> seeded fill -> freeze(2) here (the generator's order)."""
+    seeded.fill_module(net, 601)
+    net.freeze(2)
+    net.to(device)
+    if dtype == torch.float64:
+        net.double()
+    net.train()
+    xx = x.detach().clone().to(device=device, dtype=dtype)
+    if str(device) != "cpu":
+        xx = xx.contiguous(memory_format=torch.channels_last)
+    y = net(xx)["res4"]
+    (y * gy.to(device=device, dtype=y.dtype)).sum().backward()
+    p = dict(net.named_parameters())
+    return y.detach(), {n: q.grad.detach() for n, q in p.items() if q.grad is not None}, net.state_dict(), [n for n, q in p.items() if not q.requires_grad]
+
+
+def check_rn101(z, y, grads, sd, frozen, tol_y, tol_g, exact=None, what=""):
+    """As check_res5: forward against the reference; gradients against the reference (oracle on the CPU) or, with `exact`
+    (an fp64 run), within max(tol_g, 2 x the reference's own worst fp32 error) of fp64 (relative L2)."""
+    assert sorted(frozen) == sorted(str(n) for n in z["frozen_names"]), "frozen parameter set differs from the reference's"
+    e = rel_err(y, z["res4"])
+    assert e <= tol_y, f"{what}res4: rel err {e:.2e} > {tol_y:.0e}"
+    items = []
+    for k in z.files:
+        if k.startswith("g::"):
+            name = k[3:]
+            if name.endswith("_sub"):
+                items.append((name[:-4], lambda t, n=name[:-4]: sub(t, RN101_SUB[n]), z[k]))
+            else:
+                items.append((name, lambda t: t, z[k]))
+    rows = [("res4", e, None, None)]
+    if exact is None:
+        for name, pick, ref in items:
+            e = rel_err(pick(grads[name]), ref)
+            rows.append((name, e, None, None))
+            assert e <= tol_g, f"{what}{name}: rel err {e:.2e} > {tol_g:.0e} vs the reference"
+    else:
+        _, eg = exact
+        for name, pick, ref in items:
+            rows.append((name, rel_err(pick(grads[name]), ref), l2_err(pick(grads[name]), pick(eg[name])), l2_err(ref, pick(eg[name]))))
+        floor = max(r[3] for r in rows[1:])
+        bound = max(tol_g, 2.0 * floor)
+        bad = [(r[0], r[2]) for r in rows[1:] if r[2] > bound]
+        assert not bad, f"{what}gradients further from fp64 than {bound:.2e} (reference fp32 floor {floor:.2e}): {bad}"
+    for k in z.files:
+        if k.startswith("after::"):
+            close(sd[k[7:]].float().cpu(), z[k], 1e-5, what + k)
+    return rows
+
+
+def check_rn101_ckg(merge, device="cpu", tol=1e-5):
+    """CKGNet at hidden 512 / 8 classes / 8 heads against rn101_ckg.npz (forward + every parameter gradient, sub-sampled)."""
+    z = load("rn101_ckg")
+    seeded.fill_module(merge, 611)
+    names = sorted(dict(merge.named_parameters()))
+    assert abs(seeded.checksum(dict(merge.named_parameters())[names[0]]) - float(z["w_checksum"])) <= 1e-9 * abs(float(z["w_checksum"]))
+    merge.to(device)
+    t = lambda k: T(z[k]).to(device)
+    y = merge(t("x"), t("proto_off"), t("proto_on"), t("probs_off"), t("probs_on"))
+    close(y, z["y"], tol, "ckg y")
+    (y * t("gy")).sum().backward()
+    for n, q in merge.named_parameters():
+        e = rel_err(sub(q.grad, (4, 4) if q.dim() == 2 else (1,)), z[f"mg::{n}_sub"])
+        assert e <= max(tol, 1e-5) * 10, (n, e)

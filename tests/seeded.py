@@ -11,13 +11,15 @@ import torch
 def fill_module(module: torch.nn.Module, seed: int) -> torch.nn.Module:
     """Deterministic non-trivial values for every parameter and float buffer, keyed by the state-dict name (so modules with the
     same key set get the same values whatever their class)."""
+    import zlib
+
     sd = module.state_dict()
     with torch.no_grad():
-        for i, name in enumerate(sorted(sd)):
+        for name in sorted(sd):
             t = sd[name]
             if not t.is_floating_point():
                 continue
-            g = torch.Generator().manual_seed(seed * 1000003 + i)
+            g = torch.Generator().manual_seed(seed * 1000003 + zlib.crc32(name.encode()))  # keyed by NAME: extra / missing keys elsewhere do not shift it
             if name.endswith("running_var"):
                 v = torch.rand(t.shape, generator=g) + 0.5
             elif name.endswith("running_mean"):

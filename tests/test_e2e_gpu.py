@@ -161,6 +161,52 @@ def test_cointrainer_full_size_steps(burned_up, sync_free_step):
     assert (not torch.equal(tw_before, teacher_w)) == burned_up
 
 
+def test_cointrainer_rn101_bdd100k_full_size_steps():
+    """BASELINE configs[3] (configs/coin/GDINO/bdd100k_rn101_synthetic.yaml): CLIP-RN101 detector (layer3 = 23 blocks, text dim 512,
+    CKG at MERGE_DIM 512, 7 classes), BDD100K-shaped 750x1333 views, one GPU's share of the global batch of 64 (8 images): teacher
+    inference on 8 x 1000 RoIs, student step_one on 8 x 512 RoIs, CKG + student updates, bf16.  Its pieces are pinned to the
+    reference in tests/test_parity_gpu.py::test_rn101_trunk_and_ckg512_on_device_vs_reference_and_fp64; this is the full-size run."""
+    import os
+    import time
+
+    from coin_amd.config import get_cfg
+    from coin_amd.data.synthetic import synthetic_offline_detections
+    from coin_amd.engine import CoinTrainer
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(root, "configs", "coin", "GDINO", "bdd100k_rn101_synthetic.yaml"))
+    cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", 8, "AMD.SYNTHETIC.NUM_IMAGES", 8, "AMD.TEXT_TEMPLATES", 2, "MODEL.DEVICE", "cuda:0",
+                         "CLOUD.BURN_UP_STEP", 100, "CLOUD.PROTOTYPE_UPDATE_START", 0, "CLOUD.CLS_B_THRESH", 0.2])
+    torch.manual_seed(13)
+    tr = CoinTrainer(cfg)
+    assert len(tr.model.backbone.encoder.visual.layer3) == 23 and tr.model.roi_heads.box_predictor.cls_score.weight.shape[0] == 512
+    assert tr.model.roi_heads.num_classes == 7 and all(p.shape[-1] == 512 for p in tr.merge.parameters() if p.dim() == 2)
+    real_forward, g_det = tr.offline_teacher.forward, torch.Generator().manual_seed(7)
+
+    def teacher(batched_inputs, branch=None, **kw):  # the real inference runs; the matcher gets CLIPDET-like detections
+        out = real_forward(batched_inputs, branch=branch, **kw)
+        assert len(out) == len(batched_inputs)
+        return [synthetic_offline_detections(tr.model_CLOUD.entry(d["file_name"]), g_det, device="cuda:0") for d in batched_inputs]
+
+    tr.offline_teacher.forward = teacher
+    merge_before = [p.detach().clone() for p in tr.merge.parameters()]
+    recs = []
+    for i in range(3):
+        if i == 2:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        recs.append(tr.run_step())
+    torch.cuda.synchronize()
+    print(f"CoinTrainer RN101 / BDD100K-shape step_one: {(time.perf_counter() - t0) * 1e3:.1f} ms for 8 views")
+    for rec in recs:
+        vals = {k: float(v) for k, v in rec.items()}
+        assert all(np.isfinite(v) for v in vals.values()), vals
+        assert {"loss_text_align", "loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc", "loss_rpn_distillation", "loss_distillation",
+                "loss_merge_a", "loss_merge_b", "loss_merge_base", "loss_merge_grad"} <= set(vals), sorted(vals)
+    assert any(not torch.equal(a, b) for a, b in zip(merge_before, tr.merge.parameters()))
+
+
 def test_inference_fp32_vs_reference_golden():
     """Teacher / evaluation path (OpenVocabularyRCNN.inference, clip_rcnn.py:381-426; fast_rcnn_inference, fast_rcnn.py:116-175) on
     the device: eval-mode BatchNorm through the fused apply kernel, RPN top-k + device NMS, RoIAlign, class-wise NMS, top-100."""

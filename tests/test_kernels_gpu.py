@@ -597,3 +597,15 @@ def test_bn_act_valid_rows_padding_is_exact():
         assert torch.equal(ya, yb[:n]) and torch.equal(xa.grad, xb.grad[:n])
         assert float(xb.grad[n:].abs().max()) == 0.0
         assert torch.equal(bn_a.weight.grad, bn_b.weight.grad) and torch.equal(bn_a.running_var, bn_b.running_var)
+
+
+def test_roi_align_separable_forward_variant_in_a_subprocess():
+    """The second forward kernel (separable gather, COIN_ROI_ALIGN_FWD=1: chosen at library load) passes the same RoIAlign tests."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, COIN_ROI_ALIGN_FWD="1")
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "roi_align and not subprocess", "-p", "no:cacheprovider"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and " passed" in res.stdout and "failed" not in res.stdout, res.stdout[-2000:] + res.stderr[-1000:]

@@ -580,6 +580,17 @@ def test_real_width_res5_and_box_predictor_vs_reference():
     RW.check_head(zh, *RW.run_head(bp, zh, xh, instances), tol=1e-5, tol_g=1e-5)
 
 
+def test_rn101_trunk_and_ckg512_vs_reference():
+    """BASELINE configs[3] (RN101 / BDD100K: 7 classes, D = 512, MERGE_DIM 512): the oracle's ModifiedResNet-101 trunk (layers 3, 4, 23, 3;
+    frozen stem + layer1) and CKGNet(512, 512, 8) against outputs captured from the reference's modules (rn101_*.npz)."""
+    import real_width as RW
+
+    z, x, gy = RW.rn101_inputs()
+    y, grads, sd, frozen = RW.run_rn101(OC.ModifiedResNet((3, 4, 23, 3), 64, freeze_at=0), x, gy)
+    RW.check_rn101(z, y, grads, sd, frozen, 1e-5, 1e-5)
+    RW.check_rn101_ckg(OC.CKGNet(512, 512, 8))
+
+
 # ------------------------------------------------------------------------------------------ CLIP-teacher relabelling (collection)
 def _clip_relabel_oracle(z):
     from oracle import clip_collect as CC

@@ -135,6 +135,22 @@ def test_real_width_res5_bf16_conv_gemm_vs_library_convs_and_fp64():
             torch.testing.assert_close(sd_own[k].float(), sd_lib[k].float(), rtol=2e-2, atol=2e-3)
 
 
+def test_rn101_trunk_and_ckg512_on_device_vs_reference_and_fp64():
+    """BASELINE configs[3] pieces on the device: the RN101 trunk (23-block layer3, train-mode BN kernels, frozen stem) forward 1e-4 and
+    gradients against fp64 with the measured fp32 floor; CKGNet at MERGE_DIM 512 / 8 classes."""
+    import real_width as RW
+    from coin_amd.modeling.backbone import ModifiedResNet
+    from coin_amd.modeling.text_encoder import CKGNet
+    from oracle import coin as OC
+
+    z, x, gy = RW.rn101_inputs()
+    y64, g64, _, _ = RW.run_rn101(OC.ModifiedResNet((3, 4, 23, 3), 64, freeze_at=0), x, gy, dtype=torch.float64)
+    y, grads, sd, frozen = RW.run_rn101(ModifiedResNet((3, 4, 23, 3), 64, ("res4",), 0), x, gy, device=DEV)
+    rows = RW.check_rn101(z, y, grads, sd, frozen, 1e-4, 1e-4, exact=(y64, g64), what="rn101 ")
+    print("\n".join(f"rn101 {r[0]:28s} max-err vs reference {r[1]:.2e}" + ("" if r[2] is None else f" | L2 vs fp64: product {r[2]:.2e}  reference {r[3]:.2e}") for r in rows))
+    RW.check_rn101_ckg(CKGNet(512, 512, 8), device=DEV, tol=1e-4)
+
+
 def test_real_width_box_predictor_on_device_vs_reference():
     """FastRCNNOutputLayers at 2048 -> 1024 -> 1024 -> 2048 -> (1024-d cosine logits vs 9 classes, 4 deltas), 512 RoIs, pre_train
     losses: scores / deltas / losses 1e-4, gradients 1e-4 of the tensor's scale (exact-f32 MFMA path)."""

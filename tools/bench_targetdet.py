@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Timing of the targetDET distillation step (BASELINE.json configs[2] shape) on ONE GPU -- informational, not the bench.py metric.
 
-    python tools/bench_targetdet.py [--steps 8] [--warmup 4] [--images 2] [--step-two]
+    python tools/bench_targetdet.py [--steps 8] [--warmup 4] [--images 2] [--step-two] [--sync-free-step]
+    python tools/bench_targetdet.py --config bdd100k_rn101 --images 8          # BASELINE configs[3]: RN101, 750x1333, 8 images / GPU
 
 Reports ms/step and student views/s (a step = teacher inference on the weak views + matching + student step on the strong views).
 """
@@ -21,6 +22,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--images", type=int, default=2)
     ap.add_argument("--step-two", action="store_true")
+    ap.add_argument("--config", default="foggy", choices=["foggy", "bdd100k_rn101"])
     ap.add_argument("--sync-free-step", action="store_true", help="cfg.AMD.SYNC_FREE_STEP: fixed-shape samplers + packed losses in the step branches")
     args = ap.parse_args()
     import torch
@@ -31,7 +33,7 @@ def main():
 
     torch.backends.cudnn.benchmark = True
     cfg = get_cfg()
-    cfg.merge_from_file(os.path.join(ROOT, "configs", "coin", "GDINO", "foggy_synthetic.yaml"))
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "coin", "GDINO", "foggy_synthetic.yaml" if args.config == "foggy" else "bdd100k_rn101_synthetic.yaml"))
     cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", args.images, "AMD.SYNTHETIC.NUM_IMAGES", args.images, "AMD.TEXT_TEMPLATES", 4,
                          "MODEL.DEVICE", "cuda:0", "CLOUD.BURN_UP_STEP", 0 if args.step_two else 10 ** 9, "CLOUD.PROTOTYPE_UPDATE_START", 0,
                          "AMD.SYNC_FREE_STEP", args.sync_free_step])
@@ -55,7 +57,7 @@ def main():
         tr.prepare_next()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    print(json.dumps({"workload": "targetDET " + ("step_two" if args.step_two else "step_one") + (" sync-free" if args.sync_free_step else ""), "images_per_step": args.images, "ms_per_step": dt * 1e3,
+    print(json.dumps({"config": args.config, "workload": "targetDET " + ("step_two" if args.step_two else "step_one") + (" sync-free" if args.sync_free_step else ""), "images_per_step": args.images, "ms_per_step": dt * 1e3,
                       "student_views_per_s": args.images / dt, "losses": {k: round(float(v), 4) for k, v in rec.items()}}))
 
 
