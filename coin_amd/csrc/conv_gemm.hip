@@ -18,6 +18,7 @@
 //     the tile is packed to bf16 in registers, transposed through LDS once and stored as whole 256-byte rows;
 //   * the BatchNorm statistics of the output (per-channel pivoted sum and sum of squares of the STORED bf16 values, per row
 //     tile) are taken during that store pass -- the separate statistics pass over the activation (coin_bn_stats) disappears.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -235,6 +236,217 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// 256 x 256 x 32 variant (N % 256 == 0): the 256 x 128 kernel above is bound by the L2 -> LDS stream (measured: 48 KiB per K-step
+// arrive at ~42 GB/s per CU, 1.13 us per step against 0.43 us of MFMA time).  A square tile needs 1.5x fewer operand bytes per
+// FLOP: (256 + 256) x 32 x 2 B = 32 KiB per 4.2 MFLOP step.  8 waves as 2 (M) x 4 (N), each 128 x 64 = 8 x 4 accumulators
+// (128 VGPRs); 4-deep ring of 32 KiB stages (128 KiB), the loads of steps t+1 and t+2 stay in flight across the barrier of step t
+// (`s_waitcnt vmcnt(8)`).  Rows are 64 B (32 k): one DMA instruction covers 16 rows; chunk c of row r is stored at physical
+// chunk c ^ ((-(r >> 2)) & 3), which makes every 16-lane group of the ds_read_b128 fragment reads hit 16 distinct 16-byte slots
+// (lane groups of MI355X_MICROARCH.md section LDS).  The epilogue goes through LDS in two 128-column halves.
+// ------------------------------------------------------------------------------------------
+constexpr int QM = 256, QN = 256, QK = 32;
+constexpr int QA_BYTES = QM * QK * 2;             // 16 KiB
+constexpr int QSTAGE_BYTES = QA_BYTES * 2;        // 32 KiB
+constexpr int QNSTAGE = 4;
+
+__device__ __forceinline__ bf16x8 qfrag(const char* tile, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(tile + row * 64 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 4));
+}
+
+template <bool GATHER3, bool STATS>
+__global__ __launch_bounds__(512) void conv_gemm256_bf16_kernel(
+    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, bf16_t* __restrict__ Cmat, int ldc, int M, int N,
+    int K, int H, int W, int Cin, float* __restrict__ stats, int64_t stats_rows, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * QM, n0 = tn * QN;
+  const int wr = wave >> 2, wc = wave & 3;  // 2 x 4 waves
+
+  // ---- per-thread staging addresses: one DMA instruction = 16 rows x 64 B; this thread: row (lane >> 2) of the group, and the
+  // logical chunk that must land at physical chunk lane & 3
+  const int rl = lane >> 2;
+  const int sc = (lane & 3) ^ ((0 - (rl >> 2)) & 3);
+  const bf16_t* abase[2];
+  unsigned ataps[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int row = m0 + (wave * 2 + j) * 16 + rl;
+    row = row < M ? row : M - 1;
+    if (GATHER3) {
+      const int hw = H * W;
+      const int nb = row / hw, rem = row - nb * hw;
+      const int oy = rem / W, ox = rem - oy * W;
+      abase[j] = A + (size_t)row * Cin;
+      unsigned m = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = oy + t / 3 - 1, xx = ox + t % 3 - 1;
+        m |= (yy >= 0 && yy < H && xx >= 0 && xx < W ? 1u : 0u) << t;
+      }
+      ataps[j] = m;
+    } else {
+      abase[j] = A + (size_t)row * lda;
+      ataps[j] = 0;
+    }
+  }
+  const bf16_t* brow[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int row = n0 + (wave * 2 + j) * 16 + rl;
+    row = row < N ? row : N - 1;
+    brow[j] = B + (size_t)row * ldb;
+  }
+  const int kc = GATHER3 ? Cin / QK : 1;  // K-steps per tap
+
+  auto stage = [&](int t, int slot) {
+    char* sa = lds + slot * QSTAGE_BYTES;
+    char* sb = sa + QA_BYTES;
+    int koff = t * QK, tap = 0;
+    long long shift = 0;
+    if (GATHER3) {
+      tap = t / kc;
+      koff = (t - tap * kc) * QK;
+      shift = ((long long)(tap / 3 - 1) * W + (tap % 3 - 1)) * Cin;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bf16_t* src = abase[j] + koff + sc * 8;
+      if (GATHER3) src = ((ataps[j] >> tap) & 1u) ? src + shift : reinterpret_cast<const bf16_t*>(coin_zero_page) + sc * 8;
+      glds16(src, sa + (wave * 2 + j) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds16(brow[j] + (size_t)t * QK + sc * 8, sb + (wave * 2 + j) * 1024);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = K / QK;
+  stage(0, 0);
+  if (nt > 1) stage(1, 1);
+  if (nt > 2) stage(2, 2);
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int t = 0; t < nt; ++t) {
+    // stage t has landed once at most the 4 + 4 loads of stages t+1, t+2 are outstanding
+    if (t + 2 < nt)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (t + 1 < nt)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 3 < nt) stage(t + 3, (t + 3) % QNSTAGE);
+    const char* la = lds + (t % QNSTAGE) * QSTAGE_BYTES;
+    const char* lb = la + QA_BYTES;
+    bf16x8 af[8], bfr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = qfrag(lb, wc * 64 + j * 16 + fr, fq);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = qfrag(la, wr * 128 + i * 16 + fr, fq);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // swapped: lane = row m, regs = 4 columns n
+    __builtin_amdgcn_s_setprio(0);
+  }
+
+  // ---- epilogue in two 128-column halves: waves wc = {0,1} then {2,3} park their tiles in LDS, all threads store whole rows
+  const int chunk = threadIdx.x & 15, rsub = threadIdx.x >> 4;
+  char* ct = lds;
+  float* red = reinterpret_cast<float*>(lds + QM * C_ROW_BYTES);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();  // ring (half 0) / previous half's image and reduction scratch (half 1) are free
+    if ((wc >> 1) == half) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = wr * 128 + i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int col = (wc & 1) * 64 + j * 16 + fq * 4;
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[i][j][r];
+          *reinterpret_cast<bf16x4*>(ct + row * C_ROW_BYTES + col * 2) = o;
+        }
+      }
+    }
+    __syncthreads();
+    const int gcol = n0 + half * 128 + chunk * 8;
+    float s1[8], s2[8], piv[8];
+    if (STATS) {
+      const bf16x8 p = *reinterpret_cast<const bf16x8*>(ct + chunk * 16);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        piv[i] = (float)p[i];
+        s1[i] = s2[i] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < QM / 32; ++p) {
+      const int row = p * 32 + rsub;
+      const int grow = m0 + row;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(ct + row * C_ROW_BYTES + chunk * 16);
+      if (grow < M && gcol < N) *reinterpret_cast<bf16x8*>(Cmat + (size_t)grow * ldc + gcol) = v;
+      if (STATS && (int64_t)grow < stats_rows) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float d = (float)v[i] - piv[i];
+          s1[i] += d;
+          s2[i] += d * d;
+        }
+      }
+    }
+    if (STATS) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        s1[i] += __shfl_xor(s1[i], 16, 64);
+        s2[i] += __shfl_xor(s2[i], 16, 64);
+        s1[i] += __shfl_xor(s1[i], 32, 64);
+        s2[i] += __shfl_xor(s2[i], 32, 64);
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          red[(wave * 16 + lane) * 16 + i] = s1[i];
+          red[(wave * 16 + lane) * 16 + 8 + i] = s2[i];
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x < 128) {
+        const int c = threadIdx.x, ch = c >> 3, ci = c & 7;
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          a1 += red[(w * 16 + ch) * 16 + ci];
+          a2 += red[(w * 16 + ch) * 16 + 8 + ci];
+        }
+        const int gc = n0 + half * 128 + c;
+        if (gc < N) {
+          float* __restrict__ part = stats + (size_t)tm * 3 * N + gc;
+          part[0] = (float)*reinterpret_cast<const bf16_t*>(ct + c * 2);
+          part[N] = a1;
+          part[2 * (size_t)N] = a2;
+        }
+      }
+    }
+  }
+}
+
 // mean / rstd (+ running statistics) from the per-row-tile pivoted partials: tile t holds n_t = clamp(rows - 256 t, 0, 256) values
 // per channel as (pivot p, S1 = sum(x - p), S2 = sum((x - p)^2)) -> (mean_t, M2_t) -> Chan's pairwise update, in a fixed order.
 __global__ __launch_bounds__(1024) void conv_stats_finalize_kernel(const float* __restrict__ part, int tiles_m, int N, int64_t rows,
@@ -296,7 +508,7 @@ extern "C" int coin_conv_gemm_bf16(const void* A, int lda, int mode, int H, int 
   if (!A || !B || !C) return COIN_EINVAL;
   if (M < 0 || N < 0 || K <= 0 || ldb < K || ldc < N || (mode != 0 && mode != 1)) return COIN_EINVAL;
   if (M == 0 || N == 0) return COIN_OK;
-  if (K % GK || ldb % 8 || ldc % 8 || N % 8) return COIN_ESHAPE;
+  if (K % GK || ldb % 8 || ldc % 8 || N % 8) return COIN_ESHAPE;  // GK = 64 is also a multiple of the square tile's K-step
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15)) return COIN_EALIGN;
   if (mode == 0) {
     if (lda < K) return COIN_EINVAL;
@@ -305,12 +517,33 @@ extern "C" int coin_conv_gemm_bf16(const void* A, int lda, int mode, int H, int 
     if (H <= 0 || W <= 0 || Cin <= 0 || M % (H * W)) return COIN_EINVAL;
     if (Cin % GK || K != 9 * Cin) return COIN_ESHAPE;
   }
-  const int tm = (M + GM - 1) / GM, tn = (N + GN - 1) / GN;
-  const size_t lds = (size_t)NSTAGE * STAGE_BYTES;
   hipStream_t st = (hipStream_t)stream;
   const bf16_t* a = (const bf16_t*)A;
   const bf16_t* b = (const bf16_t*)B;
   bf16_t* c = (bf16_t*)C;
+  static const int force_rect = [] { const char* e = getenv("COIN_CONV_GEMM_TILE"); return e && e[0] == '1' ? 1 : 0; }();  // measurements only
+  if (N % QN == 0 && !force_rect) {
+    const int tm = (M + QM - 1) / QM, tn = N / QN;
+    const size_t lds = (size_t)QNSTAGE * QSTAGE_BYTES;
+#define COIN_LAUNCH_Q(G3, ST)                                                                                                  \
+  do {                                                                                                                         \
+    static bool attr_set = false;                                                                                              \
+    if (!attr_set) {                                                                                                           \
+      (void)hipFuncSetAttribute((const void*)conv_gemm256_bf16_kernel<G3, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      attr_set = true;                                                                                                         \
+    }                                                                                                                          \
+    conv_gemm256_bf16_kernel<G3, ST><<<tm * tn, 512, lds, st>>>(a, lda, b, ldb, c, ldc, M, N, K, H, W, Cin, stats, stats_rows, tm, tn); \
+  } while (0)
+    if (mode == 1) {
+      if (stats) COIN_LAUNCH_Q(true, true); else COIN_LAUNCH_Q(true, false);
+    } else {
+      if (stats) COIN_LAUNCH_Q(false, true); else COIN_LAUNCH_Q(false, false);
+    }
+#undef COIN_LAUNCH_Q
+    return coin_launch_status();
+  }
+  const int tm = (M + GM - 1) / GM, tn = (N + GN - 1) / GN;
+  const size_t lds = (size_t)NSTAGE * STAGE_BYTES;
 #define COIN_LAUNCH(G3, ST)                                                                                                   \
   do {                                                                                                                        \
     static bool attr_set = false;                                                                                             \

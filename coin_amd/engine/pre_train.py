@@ -5,9 +5,8 @@
 dict, backward, SGD step.  Differences that do not change values: bf16 autocast needs no GradScaler (the
 reference's fp16 autocast does, pre_train.py:84,199-202); no per-step ``empty_cache()/gc.collect()``
 (pre_train.py:210-211); metrics are read back every ``log_period`` steps instead of every step.
-Data parallelism = torch DistributedDataParallel over RCCL (one process per GPU), gradients all-reduced in
-buckets overlapped with backward; BatchNorm statistics stay per GPU (broadcast_buffers=False) as in
-pre_train.py:59-62.
+Data parallelism = one process per GPU over RCCL, gradients all-reduced in 32 MiB slices overlapped with backward
+(coin_amd.parallel.GradReducer); BatchNorm statistics stay per GPU (broadcast_buffers=False in pre_train.py:59-62).
 """
 from __future__ import annotations
 
@@ -25,6 +24,8 @@ from .base import BASE_Trainer
 
 
 class PRETrainer(BASE_Trainer):
+    reducer = None  # coin_amd.parallel.GradReducer when world_size > 1
+
     def __init__(self, cfg, data_loader=None, collect_model=None):
         self.cfg = cfg
         self.device = torch.device(cfg.MODEL.DEVICE)
@@ -34,12 +35,15 @@ class PRETrainer(BASE_Trainer):
         self.model = build_model(cfg)
         self.model.train()
         self.optimizer = build_optimizer(cfg, self.model, name="all")
-        self.ddp_model = self.model
-        force_ddp = os.environ.get("COIN_FORCE_DDP") == "1" and dist.is_available() and dist.is_initialized()  # 1-rank dry run of the DDP path
+        # data parallelism (pre_train.py:59-62): replicas synchronised once, gradients averaged per step (coin_amd.parallel)
+        force_ddp = os.environ.get("COIN_FORCE_DDP") == "1" and dist.is_available() and dist.is_initialized()  # 1-rank dry run of the collective path
+        self.reducer = None
         if self.world_size > 1 or force_ddp:
-            self.ddp_model = torch.nn.parallel.DistributedDataParallel(
-                self.model, device_ids=[self.device.index] if self.device.type == "cuda" else None, broadcast_buffers=False,
-                gradient_as_bucket_view=True, bucket_cap_mb=32)
+            from ..parallel import GradReducer, broadcast_parameters, force_collectives
+
+            force_collectives(force_ddp)
+            broadcast_parameters(self.model)
+            self.reducer = GradReducer(self.optimizer.params)
         self.scheduler = build_lr_scheduler(cfg, self.optimizer)
         if data_loader is None:
             assert cfg.AMD.SYNTHETIC.ENABLED, "only the synthetic loader is built in (the input pipeline is out of scope)"
@@ -88,11 +92,11 @@ class PRETrainer(BASE_Trainer):
             self.model.set_lookahead(self._next_batch)
         start = self.cfg.CLOUD.PROTOTYPE_UPDATE_START
         update_prototype = start != -1 and self.iter >= start
-        record = self.ddp_model(strong, branch="pre_train", update_prototype=update_prototype)
+        record = self.model(strong, branch="pre_train", update_prototype=update_prototype)
         losses = sum(record.values())
         self.optimizer.zero_grad()
-        losses.backward()
-        self.optimizer.step()
+        losses.backward()   # with a reducer: 32 MiB gradient slices are all-reduced over RCCL while backward is still running
+        self.optimizer.step(inv_loss_scale=self.reducer.finalize() if self.reducer is not None else 1.0)
         self.scheduler.step()
         self.last_losses = record
         self.iter += 1

@@ -48,12 +48,15 @@ class CoinTrainer(BASE_Trainer):
         self.offline_teacher.train()
         self.optimizer = build_optimizer(cfg, self.model, name="all")
         self.optimizer_merge = build_optimizer(cfg, self.merge, name="all")
-        self.ddp_model, self.ddp_merge = self.model, self.merge
-        if self.world_size > 1:  # trainer.py:66-72
-            ids = [self.device.index] if self.device.type == "cuda" else None
-            self.ddp_model = torch.nn.parallel.DistributedDataParallel(self.model, device_ids=ids, broadcast_buffers=False,
-                                                                       gradient_as_bucket_view=True, bucket_cap_mb=32)
-            self.ddp_merge = torch.nn.parallel.DistributedDataParallel(self.merge, device_ids=ids, broadcast_buffers=False)
+        self.ddp_model, self.ddp_merge = self.model, self.merge  # kept for callers of the reference's attribute names
+        self.reducer = self.reducer_merge = None
+        if self.world_size > 1:  # trainer.py:66-72: the student AND the CKG module are data parallel
+            from ..parallel import GradReducer, broadcast_parameters
+
+            broadcast_parameters(self.model)
+            broadcast_parameters(self.merge)
+            self.reducer = GradReducer(self.optimizer.params)
+            self.reducer_merge = GradReducer(self.optimizer_merge.params)
         self.scheduler = build_lr_scheduler(cfg, self.optimizer)
         self.scheduler_merge = build_lr_scheduler(cfg, self.optimizer_merge)
         if data_loader is None:
@@ -117,6 +120,7 @@ class CoinTrainer(BASE_Trainer):
             return self.match_boxes(weak, offline_results)
 
     _pending = None
+    reducer = reducer_merge = None  # coin_amd.parallel.GradReducer when world_size > 1
 
     def run_step(self):
         cfg = self.cfg
@@ -128,14 +132,10 @@ class CoinTrainer(BASE_Trainer):
         else:
             strong, dual_teacher_instances = self._pending
             self._pending = None
-        # Under DDP every rank runs the merge module once at this fixed point of the step, whatever its batch contains: DDP's own
-        # collectives (bucket rebuild after the first step) and the gradient all-reduce are then entered in the same order
-        # everywhere.  The term is identically zero.
-        merge_zero = self._zero_merge_loss() if self.world_size > 1 else None
         start = cfg.CLOUD.PROTOTYPE_UPDATE_START
         update_prototype = start != -1 and self.iter >= start
         branch = "step_one" if self.iter < burn else "step_two"
-        record = self.ddp_model(strong, self.ddp_merge, dual_teacher_instances, branch=branch, update_prototype=update_prototype)
+        record = self.model(strong, self.merge, dual_teacher_instances, branch=branch, update_prototype=update_prototype)
         self.optimizer.zero_grad()
         self.optimizer_merge.zero_grad()
         has_merge = "loss_merge_a" in record
@@ -149,18 +149,17 @@ class CoinTrainer(BASE_Trainer):
             run_merge = bool(flag.item() > 0)
         if run_merge:
             # CKG update (trainer.py:192-197); gradients are formed for the merge parameters only
-            ckg_loss = merge_zero if merge_zero is not None else 0.0
             if has_merge:
                 record["loss_merge_grad"] = self.model.roi_heads.box_predictor.merge_grad_loss()
-                ckg_loss = ckg_loss + record["loss_merge_grad"] + record["loss_merge_base"]
-            ckg_loss.backward(inputs=list(self.merge.parameters()), retain_graph=has_merge)
-            self.optimizer_merge.step()
+                (record["loss_merge_grad"] + record["loss_merge_base"]).backward(inputs=list(self.merge.parameters()), retain_graph=True)
+            # a rank without merge terms has no gradient: its slices are flushed with zeros, every rank enters the same collectives
+            self.optimizer_merge.step(inv_loss_scale=self.reducer_merge.finalize() if self.reducer_merge is not None else 1.0)
         self.optimizer.zero_grad()
         self.optimizer_merge.zero_grad()
         skip = _MERGE_TERMS if self.iter >= burn else _MERGE_TERMS + ("loss_cls_b",)
         losses = sum(v for k, v in record.items() if k not in skip)
         losses.backward()
-        self.optimizer.step()
+        self.optimizer.step(inv_loss_scale=self.reducer.finalize() if self.reducer is not None else 1.0)
         self.scheduler.step()
         self.scheduler_merge.step()
         self.last_losses = record
@@ -191,15 +190,6 @@ class CoinTrainer(BASE_Trainer):
         assert not (resume and "+" in self.cfg.MODEL.WEIGHTS), "resume need only one model."
         load_cointrainer_weights(self, self.cfg.MODEL.WEIGHTS, resume=resume)
         self._pending, self._ema = None, None
-
-    def _zero_merge_loss(self) -> torch.Tensor:
-        """A loss that is identically zero but whose graph runs through the (DDP-wrapped) merge module: lets a rank without B
-        boxes take part in the merge module's gradient all-reduce."""
-        te = self.model.roi_heads.box_predictor.text_encoder
-        proto = te.prototype_b_offline.data
-        x = proto.new_zeros((0, proto.shape[1]))
-        probs = proto.new_zeros((0, proto.shape[0]))
-        return self.ddp_merge(x, proto, te.prototype_b_online.data, probs, probs).sum() * 0.0
 
     def after_step(self):
         """trainer.py:149-157 + MyPeriodicCheckpointer (hooks.py:60-84): ``burn_up_<iter>.pth`` at the end of the burn-up phase,

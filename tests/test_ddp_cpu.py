@@ -134,3 +134,58 @@ def test_two_rank_gloo_cointrainer_keeps_student_and_ckg_in_sync(tmp_path):
     assert a["loss"] != b["loss"]
     # the CKG update ran (at least one rank had B boxes; a rank without them joins the all-reduce with a zero gradient)
     assert "loss_merge_grad" in a["loss"] or "loss_merge_grad" in b["loss"]
+
+
+def _reducer_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from coin_amd.parallel import GradReducer, broadcast_parameters
+
+    def make():
+        torch.manual_seed(3)
+        m = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 4, 1), torch.nn.Flatten(),
+                                torch.nn.Linear(4 * 6 * 6, 5), torch.nn.Linear(5, 2))
+        m[0].weight.data = m[0].weight.data.contiguous(memory_format=torch.channels_last)  # a non-default dense layout
+        return m
+
+    a, b = make(), make()                       # a: reducer, b: plain autograd (reference of the local gradients)
+    with torch.no_grad():
+        for p in a.parameters():
+            p.add_(rank)                        # replicas start different ...
+    broadcast_parameters(a)                     # ... and are synchronised from rank 0 once
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.equal(pa, pb)
+    red = GradReducer(list(a.parameters()), slice_mb=0.0005)   # ~130 floats per slice: several slices, launched in order
+    assert len(red.slices) >= 4
+    ok = True
+    for step in range(3):
+        g = torch.Generator().manual_seed(10 * step + rank)
+        x = torch.randn(2, 3, 6, 6, generator=g)
+        for m in (a, b):
+            for p in m.parameters():
+                p.grad = None
+        skip_last = step == 1 and rank == 1      # this rank's last layer gets no gradient in step 1: zeros are contributed
+        for m in (a, b):
+            h = m[:5](x)
+            (h.sum() if skip_last else m[5](h).square().sum()).backward()
+        scale = red.finalize()
+        assert scale == 1.0 / world
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            local = pb.grad if pb.grad is not None else torch.zeros_like(pb)
+            gathered = [torch.zeros_like(local) for _ in range(world)]
+            dist.all_gather(gathered, local.contiguous())
+            want = sum(gathered) / world
+            ok &= torch.allclose(pa.grad * scale, want, rtol=1e-6, atol=1e-7) and pa.grad.stride() == pa.stride()
+    torch.save({"ok": bool(ok)}, os.path.join(out_dir, f"red{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_averages_in_slices_with_missing_gradients(tmp_path):
+    """coin_amd.parallel.GradReducer on 2 gloo ranks: the reduced gradient is the mean of the ranks' local gradients, slices are
+    launched in the same order on every rank even when one rank has no gradient for some parameters, layouts are preserved."""
+    world, port = 2, _free_port()
+    mp.start_processes(_reducer_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    assert all(torch.load(tmp_path / f"red{r}.pt")["ok"] for r in range(world))

@@ -1,0 +1,60 @@
+"""The collective path on the MI355X with ONE rank (``-m gpu``): RCCL process group, gradient slices all-reduced from the backward
+hooks (coin_amd.parallel.GradReducer), SGD from the arena views.  With one rank the all-reduce is the identity, so the losses of
+a run with the reducer must equal those of a run without it.  (No N > 1 number exists for this repo: 8-GPU runs are the driver's.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+_SCRIPT = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+force = os.environ.get("COIN_FORCE_DDP") == "1"
+if force:
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from coin_amd.config import get_cfg
+from coin_amd.engine import PRETrainer
+cfg = get_cfg()
+cfg.merge_from_file(os.path.join({root!r}, "configs", "coin", "PRETRAINS", "CLIPDET_synthetic.yaml"))
+cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", 1, "AMD.SYNTHETIC.NUM_IMAGES", 1, "AMD.SYNTHETIC.HEIGHT", 384, "AMD.SYNTHETIC.WIDTH", 640,
+                     "AMD.TEXT_TEMPLATES", 2, "MODEL.DEVICE", "cuda:0", "AMD.COMPUTE_DTYPE", "fp32"])
+torch.manual_seed(5)
+tr = PRETrainer(cfg)
+assert (tr.reducer is not None) == force
+with torch.no_grad():
+    for n, p in tr.model.named_parameters():
+        if n.endswith("bn3.weight"):
+            p.fill_(0.5)
+torch.manual_seed(6)
+out = []
+for _ in range(3):
+    rec = tr.run_step()
+    out.append({{k: float(v) for k, v in rec.items()}})
+if force:
+    assert all(p.grad is not None and any(p.grad.data_ptr() == v.data_ptr() for s in tr.reducer.slices for v in s.views) for p in tr.optimizer.params)
+    dist.destroy_process_group()
+print("RESULT " + json.dumps(out))
+"""
+
+
+def _run(force):
+    env = dict(os.environ, COIN_FORCE_DDP="1" if force else "0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-c", _SCRIPT.format(root=ROOT)], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-2500:]
+    return json.loads([l for l in res.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+
+
+def test_one_rank_rccl_reducer_reproduces_the_plain_run():
+    plain, reduced = _run(False), _run(True)
+    for a, b in zip(plain, reduced):
+        assert set(a) == set(b)
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-5 * max(1.0, abs(a[k])), (k, a[k], b[k])
+    assert plain[0] != plain[2]  # the steps did train
