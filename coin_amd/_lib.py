@@ -48,6 +48,7 @@ SIGNATURES = {
     "coin_gemm_nt": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _F, _I, _I, _P],
     "coin_conv_gemm_bf16": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P],
     "coin_conv_gemm_stats_finalize": [_P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P],
+    "coin_conv_wgrad_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "coin_transpose2d": [_P, _P, _I, _I, _I, _P],
     "coin_bias_act_bwd": [_P, _P, _P, _I, _I, _I, _P, _I, _F, _I, _P],
     "coin_cosine_logits_fwd": [_P, _I, _P, _I, _I, _I, _F, _P, _P, _I, _P],
@@ -111,6 +112,8 @@ def lib() -> ctypes.CDLL:
     l.coin_nms_workspace_bytes.restype = ctypes.c_size_t
     l.coin_conv_gemm_stats_bytes.argtypes = [c_int, c_int]
     l.coin_conv_gemm_stats_bytes.restype = ctypes.c_size_t
+    l.coin_conv_wgrad_workspace_bytes.argtypes = [c_int, c_int, c_int]
+    l.coin_conv_wgrad_workspace_bytes.restype = ctypes.c_size_t
     l.coin_abi_version.restype = c_int
     l.coin_build_arch.restype = c_char_p
     _lib = l

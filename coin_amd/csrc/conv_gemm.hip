@@ -447,6 +447,143 @@ __global__ __launch_bounds__(512) void conv_gemm256_bf16_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight gradient ("TN" contraction over the pixels):  dW[co][(tap, ci)] = sum_m gy[m][co] * xcol[m][(tap, ci)]
+// Both operands are stored pixel-major (the NHWC activations), i.e. the contraction index is the ROW index of both: the MFMA
+// fragments (8 consecutive k per lane) are columns of the staged tiles, read with ds_read_b64_tr_b16 (the LDS transpose read).
+// Block = 256 output channels x 256 input channels of ONE tap x one slice of the pixels; 8 waves (2 x 4), 128 x 64 per wave;
+// K-step = 32 pixels: gy[32][256] and x[32][256] rows (512 B each) arrive by LDS-DMA into a 4-deep ring; 16-byte chunk c of row r
+// lands at chunk c ^ ((r & 7) << 1) (source-side swizzle), which spreads the 8 rows a half-wave reads per transpose read over
+// all 64 banks.  Fragment element j of lane group g is pixel 4g + j (j < 4) / 16 + 4g + j - 4 (j >= 4) of the step -- the same
+// permutation for both operands, so the contraction is unchanged.  Pixels beyond M and 3x3 taps outside the image read a zero
+// page.  Each slice writes an fp32 slab; a second kernel sums the slabs in slice order (bit-reproducible, no atomics).
+// ------------------------------------------------------------------------------------------
+constexpr int WB = 256, WK = 32, WROW = 512, WTILE = WK * WROW;  // 16 KiB per operand tile
+constexpr int WNSTAGE = 4;
+
+__device__ __attribute__((aligned(512))) unsigned char coin_zero_row[512];
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int col0, int lane) {
+  // columns col0 .. col0+15 (lane & 15) x this lane group's 8 pixels
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int col = col0 + 4 * p;
+  const int r0 = 4 * g + q, r1 = 16 + 4 * g + q;
+  const int chunk = col >> 3, sub = (col & 7) * 2;
+  const char* a0 = tile + r0 * WROW + ((chunk ^ ((r0 & 7) << 1)) << 4) + sub;
+  const char* a1 = tile + r1 * WROW + ((chunk ^ ((r1 & 7) << 1)) << 4) + sub;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool GATHER3>
+__global__ __launch_bounds__(512) void conv_wgrad_bf16_kernel(
+    const bf16_t* __restrict__ GY, const bf16_t* __restrict__ X, float* __restrict__ slab, int M, int Cout, int Cin, int Ktot, int H, int W,
+    int tiles_co, int tiles_k, int m_chunk) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = blockIdx.x % (tiles_co * tiles_k), slice = blockIdx.x / (tiles_co * tiles_k);
+  const int tco = tile / tiles_k, tk = tile - tco * tiles_k;
+  const int co0 = tco * WB, k0 = tk * WB;
+  const int tap = GATHER3 ? k0 / Cin : 0, ci0 = GATHER3 ? k0 - tap * Cin : k0;
+  const long long shift = GATHER3 ? ((long long)(tap / 3 - 1) * W + (tap % 3 - 1)) * Cin : 0;
+  const int m_begin = slice * m_chunk, m_end = (m_begin + m_chunk) < M ? (m_begin + m_chunk) : M;
+  const int wr = wave >> 2, wc = wave & 3;  // 2 x 4 waves: 128 (co) x 64 (ci) each
+
+  // staging: one DMA instruction = 2 rows x 512 B; this wave stages rows 4*wave .. 4*wave+3 of each operand tile per step
+  const int srow = lane >> 5;  // row within the instruction
+  const int pch = lane & 31;   // physical 16-byte chunk within the row
+
+  auto stage = [&](int step, int slot) {
+    char* sg = lds + slot * 2 * WTILE;
+    char* sx = sg + WTILE;
+    const int mb = m_begin + step * WK;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = wave * 4 + j * 2 + srow;      // row of the tile
+      const int m = mb + r;
+      const int lch = pch ^ ((r & 7) << 1);        // logical chunk that must land at physical chunk pch
+      const bool in = m < m_end;
+      const bf16_t* gsrc = in ? GY + (size_t)m * Cout + co0 + lch * 8 : reinterpret_cast<const bf16_t*>(coin_zero_row) + lch * 8;
+      glds16(gsrc, sg + (wave * 4 + j * 2) * WROW);
+      bool ok = in;
+      if (GATHER3 && in) {
+        const int hw = H * W;
+        const int rem = m % hw;
+        const int oy = rem / W, ox = rem - oy * W;
+        const int yy = oy + tap / 3 - 1, xx = ox + tap % 3 - 1;
+        ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      }
+      const bf16_t* xsrc = ok ? X + ((long long)m * Cin + shift) + ci0 + lch * 8 : reinterpret_cast<const bf16_t*>(coin_zero_row) + lch * 8;
+      glds16(xsrc, sx + (wave * 4 + j * 2) * WROW);
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nsteps = (m_end - m_begin + WK - 1) / WK;
+  if (nsteps > 0) stage(0, 0);
+  if (nsteps > 1) stage(1, 1);
+  if (nsteps > 2) stage(2, 2);
+  for (int t = 0; t < nsteps; ++t) {
+    if (t + 2 < nsteps)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (t + 1 < nsteps)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 3 < nsteps) stage(t + 3, (t + 3) % WNSTAGE);
+    const char* lg = lds + (t % WNSTAGE) * 2 * WTILE;
+    const char* lx = lg + WTILE;
+    bf16x8 af[8], bfr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = tr_frag(lx, wc * 64 + j * 16, lane);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = tr_frag(lg, wr * 128 + i * 16, lane);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  }
+  // D[row = co][col = ci]: col = lane & 15, row = (lane >> 4) * 4 + reg
+  float* __restrict__ out = slab + (size_t)slice * Cout * Ktot;
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = k0 + wc * 64 + j * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = co0 + wr * 128 + i * 16 + fq * 4 + r;
+        out[(size_t)row * Ktot + col] = acc[i][j][r];
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n, int slices) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  f32x4 a = *reinterpret_cast<const f32x4*>(slab + i);
+  for (int s = 1; s < slices; ++s) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(slab + (size_t)s * n + i);
+    a += b;
+  }
+  *reinterpret_cast<f32x4*>(dw + i) = a;
+}
+
 // mean / rstd (+ running statistics) from the per-row-tile pivoted partials: tile t holds n_t = clamp(rows - 256 t, 0, 256) values
 // per channel as (pivot p, S1 = sum(x - p), S2 = sum((x - p)^2)) -> (mean_t, M2_t) -> Chan's pairwise update, in a fixed order.
 __global__ __launch_bounds__(1024) void conv_stats_finalize_kernel(const float* __restrict__ part, int tiles_m, int N, int64_t rows,
@@ -568,5 +705,44 @@ extern "C" int coin_conv_gemm_stats_finalize(const float* partials, int M, int N
   if ((running_mean == nullptr) != (running_var == nullptr)) return COIN_EINVAL;
   conv_stats_finalize_kernel<<<(N + 63) / 64, 1024, 0, (hipStream_t)stream>>>(partials, (M + GM - 1) / GM, N, rows, eps, momentum, mean, rstd,
                                                                              running_mean, running_var);
+  return coin_launch_status();
+}
+
+static int wgrad_slices(int M, int tiles) {
+  int s = (768 + tiles - 1) / tiles;  // ~3 blocks per CU
+  const int max_s = (M + 4095) / 4096; // at least 4096 pixels per slice
+  s = s < max_s ? s : max_s;
+  return s < 1 ? 1 : (s > 64 ? 64 : s);
+}
+
+extern "C" size_t coin_conv_wgrad_workspace_bytes(int M, int Cout, int Ktot) {
+  if (M <= 0 || Cout <= 0 || Ktot <= 0 || Cout % WB || Ktot % WB) return 0;
+  return (size_t)wgrad_slices(M, (Cout / WB) * (Ktot / WB)) * Cout * (size_t)Ktot * sizeof(float);
+}
+
+extern "C" int coin_conv_wgrad_bf16(const void* GY, const void* X, int mode, int H, int W, int Cin, int M, int Cout, int Ktot, float* dW,
+                                    void* workspace, void* stream) {
+  if (!GY || !X || !dW || !workspace || M <= 0 || Cout <= 0 || Cin <= 0 || (mode != 0 && mode != 1)) return COIN_EINVAL;
+  if (Cout % WB || Cin % WB) return COIN_ESHAPE;
+  if (mode == 0 ? Ktot != Cin : (Ktot != 9 * Cin || H <= 0 || W <= 0 || M % (H * W))) return COIN_EINVAL;
+  if (((uintptr_t)GY & 15) || ((uintptr_t)X & 15) || ((uintptr_t)dW & 15) || ((uintptr_t)workspace & 15)) return COIN_EALIGN;
+  const int tco = Cout / WB, tk = Ktot / WB;
+  const int slices = wgrad_slices(M, tco * tk);
+  int m_chunk = (M + slices - 1) / slices;
+  m_chunk = (m_chunk + WK - 1) / WK * WK;
+  const size_t lds = (size_t)WNSTAGE * 2 * WTILE;
+  hipStream_t st = (hipStream_t)stream;
+  float* slab = (float*)workspace;
+  if (mode == 1) {
+    static bool set3 = false;
+    if (!set3) { (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set3 = true; }
+    conv_wgrad_bf16_kernel<true><<<tco * tk * slices, 512, lds, st>>>((const bf16_t*)GY, (const bf16_t*)X, slab, M, Cout, Cin, Ktot, H, W, tco, tk, m_chunk);
+  } else {
+    static bool set1 = false;
+    if (!set1) { (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set1 = true; }
+    conv_wgrad_bf16_kernel<false><<<tco * tk * slices, 512, lds, st>>>((const bf16_t*)GY, (const bf16_t*)X, slab, M, Cout, Cin, Ktot, H, W, tco, tk, m_chunk);
+  }
+  const long long n = (long long)Cout * Ktot;
+  wgrad_reduce_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(slab, dW, n, slices);
   return coin_launch_status();
 }

@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, COIN_BF16, COIN_F32, COIN_NCHW, COIN_NHWC, CoinHipError, check
 
 __all__ = [
-    "roi_align_fwd", "roi_align_bwd", "gemm_nt", "conv_gemm", "conv_stats_finalize", "transpose2d", "bias_act_bwd", "cosine_logits_fwd",
+    "roi_align_fwd", "roi_align_bwd", "gemm_nt", "conv_gemm", "conv_wgrad", "conv_stats_finalize", "transpose2d", "bias_act_bwd", "cosine_logits_fwd",
     "cosine_logits_bwd", "bn_stats", "bn_apply_fwd", "bn_bwd", "avgpool2_fwd", "avgpool2_bwd", "nms_batched", "mil_ce", "mil_focal", "kl_div", "box_reg_l1", "l1_mean", "rpn_losses", "normalize_pad",
     "SgdTable", "EmaTable",
 ]
@@ -204,6 +204,35 @@ def conv_gemm(a: torch.Tensor, w: torch.Tensor, spatial: Optional[Tuple[int, int
         check(_lib.lib().coin_conv_gemm_bf16(_p(a), a.stride(0), mode, h, wd, cin, _p(w), w.stride(0), _p(out), out.stride(0), m, n, k,
                                              _p(part), int(stats_rows or 0), _stream()), "coin_conv_gemm_bf16")
     return out, part
+
+
+_WGRAD_WS: dict = {}
+
+
+def conv_wgrad_ok(cout: int, cin: int) -> bool:
+    return cout % 256 == 0 and cin % 256 == 0
+
+
+def conv_wgrad(gy: torch.Tensor, x: torch.Tensor, spatial: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
+    """dW [Cout, Ktot] fp32 = gy[M, Cout]^T . Acol[M, Ktot] (coin_conv_wgrad_bf16); `spatial=(H, W, Cin)` selects the implicit 3x3 /
+    pad 1 form (Ktot = 9*Cin, (ky, kx, ci) order), else the 1x1 form (x is [M, Cin])."""
+    _dev(gy, x)
+    if gy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or not gy.is_contiguous() or not x.is_contiguous() or gy.shape[0] != x.shape[0]:
+        raise CoinHipError("conv_wgrad needs contiguous bf16 [M, Cout] / [M, Cin] operands")
+    m, cout, cin = gy.shape[0], gy.shape[1], x.shape[1]
+    mode, h, w = (0, 0, 0) if spatial is None else (1, spatial[0], spatial[1])
+    ktot = cin if spatial is None else 9 * cin
+    nbytes = _lib.lib().coin_conv_wgrad_workspace_bytes(m, cout, ktot)
+    if nbytes == 0:
+        raise CoinHipError("conv_wgrad: Cout and Cin must be multiples of 256")
+    key = (gy.device, nbytes)
+    ws = _WGRAD_WS.get(key)  # one slab buffer per size, reused (calls on one stream are ordered)
+    if ws is None:
+        ws = _WGRAD_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=gy.device)
+    dw = torch.empty((cout, ktot), dtype=torch.float32, device=gy.device)
+    with _timed("coin_conv_wgrad_bf16", 2 * m * cout * ktot):
+        check(_lib.lib().coin_conv_wgrad_bf16(_p(gy), _p(x), mode, h, w, cin, m, cout, ktot, _p(dw), _p(ws), _stream()), "coin_conv_wgrad_bf16")
+    return dw
 
 
 def conv_stats_finalize(part: torch.Tensor, m: int, n: int, rows: int, eps: float, momentum: float,

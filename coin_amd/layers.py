@@ -110,7 +110,7 @@ def conv2d(x: torch.Tensor, conv: torch.nn.Conv2d) -> torch.Tensor:
 # roofline and its 3x3 convolutions implicit GEMMs; forward and data-gradient go through coin_conv_gemm_bf16 (with the BatchNorm
 # statistics of the output taken in the epilogue), the weight gradient stays a library contraction.  bf16 compute mode only: the
 # fp32 parity mode keeps the library's fp32 convolutions.
-CONV_GEMM = {"enabled": False, "min_rows": 32768}
+CONV_GEMM = {"enabled": False, "min_rows": 32768, "wgrad": False}
 
 
 def _conv_gemm_ok(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
@@ -160,8 +160,13 @@ class _ConvGemm(Function):
             gx, _ = K.conv_gemm(gyn.reshape(n * h * w, co), wd, spatial=(h, w, co) if ks == 3 else None)
             dx = gx.view(n, h, w, ci).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            dw = torch.ops.aten.convolution_backward(gyn.permute(0, 3, 1, 2), x, wq, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
-                                                     [False, True, False])[1].float()
+            if CONV_GEMM["wgrad"] and K.conv_wgrad_ok(co, ci):
+                xn = _as_nhwc(x)
+                dw2 = K.conv_wgrad(gyn.reshape(n * h * w, co), xn.reshape(n * h * w, ci), spatial=(h, w, ci) if ks == 3 else None)
+                dw = dw2.view(co, ks, ks, ci).permute(0, 3, 1, 2)  # fp32, already in the parameter's channels-last layout
+            else:
+                dw = torch.ops.aten.convolution_backward(gyn.permute(0, 3, 1, 2), x, wq, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
+                                                         [False, True, False])[1].float()
         return dx, dw, None, None
 
 

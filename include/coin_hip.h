@@ -175,6 +175,15 @@ int coin_conv_gemm_bf16(const void* A, int lda, int mode, int H, int W, int Cin,
 int coin_conv_gemm_stats_finalize(const float* partials, int M, int N, int64_t rows, float eps, float momentum,
                                   float* mean, float* rstd, float* running_mean, float* running_var, void* stream);
 
+/* Weight gradient of the same convolutions: dW[Cout][Ktot] (fp32, OVERWRITTEN) = gy[M,Cout]^T . Acol[M,Ktot] with Acol as in
+ * coin_conv_gemm_bf16 (mode 0: Ktot = Cin; mode 1: Ktot = 9*Cin, (ky, kx, ci) = the channels-last weight layout).  gy and x are the
+ * NHWC tensors of the forward pass (bf16, row strides Cout / Cin); Cout % 256 == 0 and Cin % 256 == 0.  The contraction over the M
+ * pixels is cut into slices whose fp32 partial results go to `workspace` (coin_conv_wgrad_workspace_bytes) and are summed in slice
+ * order (no atomics: bit-reproducible). */
+size_t coin_conv_wgrad_workspace_bytes(int M, int Cout, int Ktot);
+int coin_conv_wgrad_bf16(const void* gy, const void* x, int mode, int H, int W, int Cin, int M, int Cout, int Ktot,
+                         float* dW, void* workspace, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused losses: each computes the scalar loss AND the gradient w.r.t. its differentiable
  * input for a unit upstream gradient, in one launch.  `loss` is a single float32 that is

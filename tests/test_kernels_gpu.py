@@ -224,6 +224,22 @@ def test_conv_gemm_3x3_vs_torch(K, nb, h, w, cin, cout):
         torch.testing.assert_close(gx.reshape(nb, h, w, cin).permute(0, 3, 1, 2).cpu().double(), gref, rtol=1e-2, atol=1e-2 * float(gref.abs().max()))
 
 
+@pytest.mark.parametrize("nb,h,w,cin,cout,ks", [(40, 7, 7, 256, 256, 1), (9, 14, 14, 512, 256, 1), (33, 7, 7, 256, 512, 3), (6, 14, 14, 256, 256, 3), (700, 7, 7, 512, 256, 1)])
+def test_conv_wgrad_vs_fp64(K, nb, h, w, cin, cout, ks):
+    """coin_conv_wgrad_bf16 (transposed-LDS-read MFMA contraction over the pixels, sliced, slabs summed in order) vs the fp64 weight
+    gradient of F.conv2d on the same bf16 tensors; two runs agree bit for bit."""
+    g = torch.Generator().manual_seed(nb + cin + ks)
+    x = torch.randn(nb, cin, h, w, generator=g).to(torch.bfloat16)
+    gy = torch.randn(nb, cout, h, w, generator=g).to(torch.bfloat16)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, ks, ks), gy.double(), padding=ks // 2)
+    xa = dev(x.permute(0, 2, 3, 1).contiguous().reshape(-1, cin))
+    ga = dev(gy.permute(0, 2, 3, 1).contiguous().reshape(-1, cout))
+    dw = K.conv_wgrad(ga, xa, spatial=(h, w, cin) if ks == 3 else None)
+    got = dw.view(cout, ks, ks, cin).permute(0, 3, 1, 2).cpu().double()
+    torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-3 * float(ref.abs().max()))  # fp32 accumulation of exact bf16 products
+    assert torch.equal(dw, K.conv_wgrad(ga, xa, spatial=(h, w, cin) if ks == 3 else None))
+
+
 def test_gemm_rejects_bad_shapes(K):
     from coin_amd._lib import CoinHipError
 

@@ -50,11 +50,19 @@ for name, n, h, w, ci, co, ks in [("l4.0.conv1", 2048, 14, 14, 1024, 512, 1), ("
     t_f = timeit(lambda: K.conv_gemm(xa, wk, spatial=sp, out=out))
     t_fs = timeit(lambda: K.conv_gemm(xa, wk, spatial=sp, out=out, stats_rows=m))
     t_d = timeit(lambda: K.conv_gemm(ga, wd, spatial=spd, out=gx))
+    t_w = timeit(lambda: K.conv_wgrad(ga, xa, spatial=sp)) if K.conv_wgrad_ok(co, ci) else float("nan")
+    if K.conv_wgrad_ok(co, ci):
+        wref = torch.ops.aten.convolution_backward(gy, x, wt, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False])[1].float()
+        wgot = K.conv_wgrad(ga.contiguous(), xa.contiguous(), spatial=sp).view(co, ks, ks, ci).permute(0, 3, 1, 2)
+        werr = float((wgot - wref).abs().max() / wref.abs().max())
+    else:
+        werr = float("nan")
     ref = F.conv2d(x, wt, padding=pad).permute(0, 2, 3, 1).reshape(m, co).float()
     err = float((out.float() - ref).abs().max() / ref.abs().max())
     res[name] = {"M": m, "K": ks * ks * ci, "N": co, "lib_fwd_ms": t_lib, "lib_fwd_TF": flop / t_lib / 1e9, "ours_fwd_ms": t_f, "ours_fwd_TF": flop / t_f / 1e9,
                  "ours_fwd_stats_ms": t_fs, "lib_dgrad_ms": t_lib_d, "lib_dgrad_TF": flop / t_lib_d / 1e9, "ours_dgrad_ms": t_d, "ours_dgrad_TF": flop / t_d / 1e9,
-                 "lib_wgrad_ms": t_lib_w, "lib_wgrad_TF": flop / t_lib_w / 1e9, "rel_err_vs_lib": err}
+                 "lib_wgrad_ms": t_lib_w, "lib_wgrad_TF": flop / t_lib_w / 1e9, "ours_wgrad_ms": t_w, "ours_wgrad_TF": flop / t_w / 1e9,
+                 "wgrad_rel_err_vs_lib": werr, "rel_err_vs_lib": err}
     print(name, json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in res[name].items()}), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(res, open("gpurun_out/gemmbench.json", "w"), indent=1)
