@@ -36,23 +36,29 @@ FLOP_PER_VIEW = 4.259e12     # fwd 1449 + bwd 2811 GFLOP per 800
 # C-ABI entry point -> the device kernels one call launches (rocprofv3 lists these; their average durations add up to the
 # entry point's `mean_launch_ms`)
 ENTRY_KERNELS = {
-    "coin_roi_align_fwd": ["roi_align_fwd_nhwc_kernel"], "coin_roi_align_bwd": ["roi_align_bwd_tiled_kernel"],
+    "coin_roi_align_fwd": ["roi_align_fwd_nhwc_kernel"], "coin_roi_align_bwd": ["roi_align_bwd_gather_kernel"],
     "coin_bn_stats": ["bn_stats_kernel", "bn_finalize_kernel"], "coin_bn_apply_fwd": ["bn_apply_kernel | bn_apply_mean_kernel"],
     "coin_bn_bwd": ["bn_bwd_reduce_kernel", "bn_bwd_finalize_kernel", "bn_bwd_dx_kernel"], "coin_gemm_nt": ["gemm_nt_bf16_kernel"],
+    "coin_conv_gemm_bf16": ["conv_gemm256_bf16_kernel | conv_gemm_bf16_kernel  (<GATHER3, STATS> instantiations)"],
+    "coin_conv_wgrad_bf16": ["conv_wgrad_bf16_kernel", "wgrad_reduce_kernel"],
+    "coin_conv_gemm_stats_finalize": ["conv_stats_finalize_kernel"],
 }
+MFMA_ENTRIES = ("coin_gemm_nt", "coin_conv_gemm_bf16", "coin_conv_wgrad_bf16")   # their `units` slot carries FLOPs, not bytes
 
 
 def pmc_traffic(entry: str, alg_bytes: float):
-    """HBM bytes per launch from the committed PMC passes (profiles/r1_pmc_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB
-    units, MI355X_MICROARCH.md) -- only when that pass measured this entry point at this launch size, else None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
-            table = json.load(f)
-        rec = table.get(entry)
-        if rec and abs(rec["alg_bytes"] - alg_bytes) <= 0.01 * alg_bytes:
-            return rec["hbm_bytes"]
-    except (OSError, ValueError, KeyError):
-        pass
+    """HBM bytes per launch from the committed PMC passes (profiles/r2_pmc_traffic.json, else r1's: FETCH_SIZE x2 on gfx950 +
+    WRITE_SIZE, KB units, MI355X_MICROARCH.md) -- only when that pass measured this entry point at this launch size (for the MFMA
+    entry points: at this mean FLOP count per launch), else None."""
+    for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                table = json.load(f)
+            rec = table.get(entry)
+            if rec and abs(rec["alg_bytes"] - alg_bytes) <= 0.01 * alg_bytes:
+                return rec["hbm_bytes"]
+        except (OSError, ValueError, KeyError):
+            pass
     return None
 
 
@@ -225,7 +231,8 @@ def main():
     for _ in range(args.warmup):
         trainer.run_step()
     sync()
-    timed = ["coin_roi_align_fwd", "coin_roi_align_bwd", "coin_gemm_nt", "coin_bn_stats", "coin_bn_apply_fwd", "coin_bn_bwd"]
+    timed = ["coin_roi_align_fwd", "coin_roi_align_bwd", "coin_gemm_nt", "coin_bn_stats", "coin_bn_apply_fwd", "coin_bn_bwd",
+             "coin_conv_gemm_bf16", "coin_conv_wgrad_bf16"]
     K.timing_begin(timed)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -247,17 +254,19 @@ def main():
         roofline = None
         detail = {}
         for name, (n, ms, units) in ktimes.items():
-            if name == "coin_gemm_nt":
-                detail[name] = {"launches": n, "mean_ms": ms, "total_ms_per_step": n * ms / args.steps, "TFLOP/s": units / (ms * 1e-3) / 1e12}
+            if name in MFMA_ENTRIES:
+                detail[name] = {"launches": n, "mean_ms": ms, "total_ms_per_step": n * ms / args.steps, "TFLOP/s": units / (ms * 1e-3) / 1e12,
+                                "alg_flop": units, "device_kernels": ENTRY_KERNELS.get(name)}
             else:
                 detail[name] = {"launches": n, "mean_ms": ms, "total_ms_per_step": n * ms / args.steps, "GB/s": units / (ms * 1e-3) / 1e9,
                                 "alg_bytes": units, "device_kernels": ENTRY_KERNELS.get(name)}
         if best is not None:
             name, (n, ms, units) = best
-            if name == "coin_gemm_nt":
+            if name in MFMA_ENTRIES:
                 ach = units / (ms * 1e-3) / 1e12
                 roofline = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None}
+                            "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(name, units), "alg_flop_per_launch": units,
+                            "device_kernels": ENTRY_KERNELS.get(name)}
             else:
                 ach = units / (ms * 1e-3) / 1e9
                 roofline = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

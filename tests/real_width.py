@@ -129,9 +129,32 @@ def fill_head(bp, z):
     return bp
 
 
-def check_head(z, scores, deltas, losses, gx, grads, proto, tol, tol_g, what="", exact=None):
+def leaky_ties(pre_product, pre_exact, atol=2e-5):
+    """LeakyReLU decisions of `trans.0` that differ between the product's fp32 pre-activations and the fp64 ones.  Only a
+    pre-activation within fp32 rounding of zero may differ (asserted); such an element multiplies its incoming gradient by 1 in one
+    run and by 0.01 in the other, in ANY fp32 implementation (the reference's run has its own).  -> (rows, columns) of the flips."""
+    a, b = _d(pre_product), _d(pre_exact)
+    flip = (a > 0) != (b > 0)
+    assert int(flip.sum()) <= 8, f"{int(flip.sum())} LeakyReLU decisions differ from fp64"
+    assert float(b[flip].abs().max()) <= atol if flip.any() else True, f"a LeakyReLU decision differs at |pre-activation| = {float(b[flip].abs().max()):.2e}"
+    r, c = flip.nonzero(as_tuple=True)
+    return sorted(set(r.tolist())), sorted(set(c.tolist()))
+
+
+def check_head(z, scores, deltas, losses, gx, grads, proto, tol, tol_g, what="", exact=None, ties=None):
     """`exact` = (gx, grads) of an fp64 run of the oracle: gradients are then measured against fp64 and held to
-    max(tol_g, 2 x the largest error of the reference's own fp32 gradients against fp64 over these tensors)."""
+    max(tol_g, 2 x the largest error of the reference's own fp32 gradients against fp64 over these tensors).
+    `ties` = leaky_ties(...) of trans.0: the output channels whose LeakyReLU decision flipped are left out of trans.0.weight /
+    trans.0.bias, the RoI rows out of gx (the three tensors a trans.0 decision feeds directly)."""
+    if ties is not None and exact is not None and (ties[0] or ties[1]):
+        rows_, cols_ = ties
+        print(f"{what}LeakyReLU ties at trans.0: RoI rows {rows_}, output channels {cols_} (left out of trans.0.weight/bias and gx)")
+        gx, grads = gx.clone(), dict(grads)
+        gx[rows_] = exact[0][rows_].to(gx.dtype)
+        for n, idx in (("trans.0.weight", cols_), ("trans.0.bias", cols_)):
+            g = grads[n].clone()
+            g[idx] = exact[1][n][idx].to(g.dtype)
+            grads[n] = g
     close(scores, z["scores"], tol, what + "scores")
     close(deltas, z["deltas"], tol, what + "deltas")
     ref = {k[6:]: float(z[k]) for k in z.files if k.startswith("loss::")}

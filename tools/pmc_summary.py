@@ -6,7 +6,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 with open(src) as f:
     for row in csv.DictReader(f):
         n = row["Kernel_Name"]
-        if any(k in n for k in ("roi_align", "bn_", "avgpool2", "gemm_nt", "nms_")):
+        if any(k in n for k in ("roi_align", "bn_", "avgpool2", "gemm_nt", "nms_", "conv_gemm", "conv_wgrad", "wgrad_reduce", "conv_stats")):
             agg[n][row["Counter_Name"]].append(float(row["Counter_Value"]))
 with open(out, "w") as f:
     w = csv.writer(f)
