@@ -49,7 +49,8 @@ struct ARows {             // the 4 A-tile rows this thread stages (fixed for th
 template <bool GATHER3, bool STATS>
 __global__ __launch_bounds__(512) void conv_gemm_bf16_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, bf16_t* __restrict__ Cmat, int ldc, int M, int N,
-    int K, int H, int W, int Cin, float* __restrict__ stats, int64_t stats_rows, int tiles_m, int tiles_n) {
+    int K, int H, int W, int Cin, float* __restrict__ stats, int64_t stats_rows, int tiles_m, int tiles_n,
+    const bf16_t* __restrict__ Rmat, int ldr) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -188,7 +189,12 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16_kernel(
   for (int p = 0; p < GM / 32; ++p) {
     const int row = p * 32 + rsub;
     const int grow = m0 + row;
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(ct + row * C_ROW_BYTES + chunk * 16);
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(ct + row * C_ROW_BYTES + chunk * 16);
+    if (Rmat != nullptr && grow < M && gcol < N) {  // C = A.B^T + R: bf16 product, then a bf16 add (what two separate launches store)
+      const bf16x8 r = *reinterpret_cast<const bf16x8*>(Rmat + (size_t)grow * ldr + gcol);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (bf16_t)((float)v[i] + (float)r[i]);
+    }
     if (grow < M && gcol < N) *reinterpret_cast<bf16x8*>(Cmat + (size_t)grow * ldc + gcol) = v;
     if (STATS && (int64_t)grow < stats_rows) {
 #pragma unroll
@@ -257,7 +263,8 @@ __device__ __forceinline__ bf16x8 qfrag(const char* tile, int row, int chunk) {
 template <bool GATHER3, bool STATS>
 __global__ __launch_bounds__(512) void conv_gemm256_bf16_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, bf16_t* __restrict__ Cmat, int ldc, int M, int N,
-    int K, int H, int W, int Cin, float* __restrict__ stats, int64_t stats_rows, int tiles_m, int tiles_n) {
+    int K, int H, int W, int Cin, float* __restrict__ stats, int64_t stats_rows, int tiles_m, int tiles_n,
+    const bf16_t* __restrict__ Rmat, int ldr) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -400,7 +407,12 @@ __global__ __launch_bounds__(512) void conv_gemm256_bf16_kernel(
     for (int p = 0; p < QM / 32; ++p) {
       const int row = p * 32 + rsub;
       const int grow = m0 + row;
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(ct + row * C_ROW_BYTES + chunk * 16);
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(ct + row * C_ROW_BYTES + chunk * 16);
+      if (Rmat != nullptr && grow < M && gcol < N) {
+        const bf16x8 r = *reinterpret_cast<const bf16x8*>(Rmat + (size_t)grow * ldr + gcol);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (bf16_t)((float)v[i] + (float)r[i]);
+      }
       if (grow < M && gcol < N) *reinterpret_cast<bf16x8*>(Cmat + (size_t)grow * ldc + gcol) = v;
       if (STATS && (int64_t)grow < stats_rows) {
 #pragma unroll
@@ -641,12 +653,13 @@ extern "C" size_t coin_conv_gemm_stats_bytes(int M, int N) {
 }
 
 extern "C" int coin_conv_gemm_bf16(const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb, void* C, int ldc,
-                                   int M, int N, int K, float* stats, int64_t stats_rows, void* stream) {
+                                   const void* R, int ldr, int M, int N, int K, float* stats, int64_t stats_rows, void* stream) {
   if (!A || !B || !C) return COIN_EINVAL;
-  if (M < 0 || N < 0 || K <= 0 || ldb < K || ldc < N || (mode != 0 && mode != 1)) return COIN_EINVAL;
+  if (M < 0 || N < 0 || K <= 0 || ldb < K || ldc < N || (mode != 0 && mode != 1) || (R && ldr < N)) return COIN_EINVAL;
   if (M == 0 || N == 0) return COIN_OK;
-  if (K % GK || ldb % 8 || ldc % 8 || N % 8) return COIN_ESHAPE;  // GK = 64 is also a multiple of the square tile's K-step
-  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15)) return COIN_EALIGN;
+  if (K % GK || ldb % 8 || ldc % 8 || N % 8 || (R && ldr % 8)) return COIN_ESHAPE;  // GK = 64 is also a multiple of the square tile's K-step
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15) || ((uintptr_t)R & 15)) return COIN_EALIGN;
+  const bf16_t* rm = (const bf16_t*)R;
   if (mode == 0) {
     if (lda < K) return COIN_EINVAL;
     if (lda % 8) return COIN_ESHAPE;
@@ -669,7 +682,7 @@ extern "C" int coin_conv_gemm_bf16(const void* A, int lda, int mode, int H, int 
       (void)hipFuncSetAttribute((const void*)conv_gemm256_bf16_kernel<G3, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       attr_set = true;                                                                                                         \
     }                                                                                                                          \
-    conv_gemm256_bf16_kernel<G3, ST><<<tm * tn, 512, lds, st>>>(a, lda, b, ldb, c, ldc, M, N, K, H, W, Cin, stats, stats_rows, tm, tn); \
+    conv_gemm256_bf16_kernel<G3, ST><<<tm * tn, 512, lds, st>>>(a, lda, b, ldb, c, ldc, M, N, K, H, W, Cin, stats, stats_rows, tm, tn, rm, ldr); \
   } while (0)
     if (mode == 1) {
       if (stats) COIN_LAUNCH_Q(true, true); else COIN_LAUNCH_Q(true, false);
@@ -688,7 +701,7 @@ extern "C" int coin_conv_gemm_bf16(const void* A, int lda, int mode, int H, int 
       (void)hipFuncSetAttribute((const void*)conv_gemm_bf16_kernel<G3, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       attr_set = true;                                                                                                        \
     }                                                                                                                         \
-    conv_gemm_bf16_kernel<G3, ST><<<tm * tn, 512, lds, st>>>(a, lda, b, ldb, c, ldc, M, N, K, H, W, Cin, stats, stats_rows, tm, tn); \
+    conv_gemm_bf16_kernel<G3, ST><<<tm * tn, 512, lds, st>>>(a, lda, b, ldb, c, ldc, M, N, K, H, W, Cin, stats, stats_rows, tm, tn, rm, ldr); \
   } while (0)
   if (mode == 1) {
     if (stats) COIN_LAUNCH(true, true); else COIN_LAUNCH(true, false);

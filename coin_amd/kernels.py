@@ -174,13 +174,14 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
 
 
 def conv_gemm(a: torch.Tensor, w: torch.Tensor, spatial: Optional[Tuple[int, int, int]] = None, stats_rows: Optional[int] = None,
-              out: Optional[torch.Tensor] = None):
+              out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None):
     """bf16 GEMM / implicit-GEMM convolution (coin_conv_gemm_bf16).
     a: [M, K] row-major (1x1 convolution on NHWC rows, nn.Linear) or, with ``spatial=(H, W, Cin)``, the NHWC activation flattened
     to [M, Cin] for the implicit 3x3 / pad 1 convolution (M = NB*H*W);  w: [N, K] with K = Cin or 9*Cin (ky, kx, ci).
     -> C [M, N] bf16, and -- when ``stats_rows`` is given -- the per-row-tile statistics partials of the stored outputs over the
-    first ``stats_rows`` rows (input of `conv_stats_finalize`)."""
-    _dev(a, w, out)
+    first ``stats_rows`` rows (input of `conv_stats_finalize`).  ``residual`` [M, N] bf16 is added to the (bf16-rounded) product in
+    the epilogue."""
+    _dev(a, w, out, residual)
     if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or a.dim() != 2 or w.dim() != 2 or a.stride(1) != 1 or w.stride(1) != 1:
         raise CoinHipError("conv_gemm needs 2-D K-contiguous bf16 operands")
     m, n, k = a.shape[0], w.shape[0], w.shape[1]
@@ -197,11 +198,14 @@ def conv_gemm(a: torch.Tensor, w: torch.Tensor, spatial: Optional[Tuple[int, int
         out = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
     elif out.shape != (m, n) or out.stride(1) != 1 or out.dtype != torch.bfloat16:
         raise CoinHipError("conv_gemm: bad `out`")
+    if residual is not None and (residual.shape != (m, n) or residual.stride(1) != 1 or residual.dtype != torch.bfloat16):
+        raise CoinHipError("conv_gemm: `residual` must be a bf16 [M, N] matrix with contiguous rows")
     part = None
     if stats_rows is not None:
         part = torch.empty(_lib.lib().coin_conv_gemm_stats_bytes(m, n) // 4, dtype=torch.float32, device=a.device)
     with _timed("coin_conv_gemm_bf16", 2 * m * n * k):  # "bytes" slot carries FLOPs for the MFMA entry point
-        check(_lib.lib().coin_conv_gemm_bf16(_p(a), a.stride(0), mode, h, wd, cin, _p(w), w.stride(0), _p(out), out.stride(0), m, n, k,
+        check(_lib.lib().coin_conv_gemm_bf16(_p(a), a.stride(0), mode, h, wd, cin, _p(w), w.stride(0), _p(out), out.stride(0),
+                                             _p(residual), residual.stride(0) if residual is not None else 0, m, n, k,
                                              _p(part), int(stats_rows or 0), _stream()), "coin_conv_gemm_bf16")
     return out, part
 

@@ -129,7 +129,7 @@ class _ConvGemm(Function):
     channels-last bf16 activations."""
 
     @staticmethod
-    def forward(ctx, x, weight, wq, stats_rows):
+    def forward(ctx, x, weight, wq, stats_rows, fork=False):
         xn = _as_nhwc(x)
         n, h, w, c = xn.shape
         co, ks = wq.shape[0], wq.shape[2]
@@ -141,11 +141,14 @@ class _ConvGemm(Function):
         if part is None:
             part = out.new_zeros(0, dtype=torch.float32)
         ctx.mark_non_differentiable(part)
-        return out.view(n, h, w, co).permute(0, 3, 1, 2), part
+        y = out.view(n, h, w, co).permute(0, 3, 1, 2)
+        # fork: also hand the input back as the tap of the block's OTHER consumer (identity / downsample branch), so that this
+        # node receives both gradients of x and forms their sum in the dgrad epilogue instead of autograd's separate add pass
+        return (y, part, x.view_as(x)) if fork else (y, part)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, gy, _gpart):
+    def backward(ctx, gy, _gpart, g_tap=None):
         x, wq = ctx.saved_tensors
         ks, pad = ctx.ks, ctx.ks // 2
         gyn = _as_nhwc(gy)
@@ -157,7 +160,11 @@ class _ConvGemm(Function):
         if ctx.needs_input_grad[0]:
             # dgrad = the same contraction over (flipped tap, Cout): weight re-laid [Cin][ky'][kx'][Cout] (a few MB, once per call)
             wd = wq.flip(2, 3).permute(1, 2, 3, 0).contiguous().reshape(ci, ks * ks * co)
-            gx, _ = K.conv_gemm(gyn.reshape(n * h * w, co), wd, spatial=(h, w, co) if ks == 3 else None)
+            res = None
+            if g_tap is not None:
+                res = _as_nhwc(g_tap)
+                res = (res if res.dtype == torch.bfloat16 else res.to(torch.bfloat16)).reshape(n * h * w, ci)
+            gx, _ = K.conv_gemm(gyn.reshape(n * h * w, co), wd, spatial=(h, w, co) if ks == 3 else None, residual=res)
             dx = gx.view(n, h, w, ci).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             if CONV_GEMM["wgrad"] and K.conv_wgrad_ok(co, ci):
@@ -167,30 +174,41 @@ class _ConvGemm(Function):
             else:
                 dw = torch.ops.aten.convolution_backward(gyn.permute(0, 3, 1, 2), x, wq, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
                                                          [False, True, False])[1].float()
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
-def conv2d_gemm(x: torch.Tensor, conv: torch.nn.Conv2d, stats_rows: Optional[int] = None):
-    """-> (conv(x), statistics partials or None); caller checked `_conv_gemm_ok`."""
+def conv2d_gemm(x: torch.Tensor, conv: torch.nn.Conv2d, stats_rows: Optional[int] = None, fork: bool = False):
+    """-> (conv(x), statistics partials or None [, tap of x for the block's identity branch]); caller checked `_conv_gemm_ok`."""
     if x.dtype != torch.bfloat16:
         x = x.to(torch.bfloat16)
     wq = _shadow_entry(conv.weight, torch.bfloat16).tensor
+    if fork:
+        y, part, tap = _ConvGemm.apply(x, conv.weight, wq, stats_rows, True)
+        return y, (part if stats_rows is not None else None), tap
     y, part = _ConvGemm.apply(x, conv.weight, wq, stats_rows)
     return y, (part if stats_rows is not None else None)
 
 
 def conv_bn_act(x: torch.Tensor, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, relu: bool, residual: Optional[torch.Tensor] = None,
-                pool: int = 1) -> torch.Tensor:
+                pool: int = 1, fork: bool = False):
     """conv -> train-mode BatchNorm (+ identity) (+ ReLU) (+ pool): with the hand-written GEMM the BatchNorm statistics come out of
-    the convolution's epilogue (no statistics pass over the activation)."""
+    the convolution's epilogue (no statistics pass over the activation).
+    fork=True -> (result, tap): `tap` is x for the block's other consumer (identity / downsample branch); when the convolution runs
+    on the hand-written GEMM and x needs a gradient, the two gradients of x are summed in the dgrad epilogue (coin_conv_gemm_bf16's
+    R operand) instead of by a separate elementwise pass."""
     if _conv_gemm_ok(x, conv):
+        do_fork = fork and torch.is_grad_enabled() and x.requires_grad
         if bn.training and bn.momentum is not None:
             nv = _VALID_ROWS[0]
             rows = (x.shape[0] if nv is None or nv >= x.shape[0] else int(nv)) * x.shape[2] * x.shape[3]
-            y, part = conv2d_gemm(x, conv, stats_rows=rows)
-            return bn_act(y, bn, relu, residual, pool, stats_part=(part, rows))
-        return bn_act(conv2d_gemm(x, conv)[0], bn, relu, residual, pool)
-    return bn_act(conv2d(x, conv), bn, relu, residual, pool)
+            y, part, *tap = conv2d_gemm(x, conv, stats_rows=rows, fork=do_fork)
+            out = bn_act(y, bn, relu, residual, pool, stats_part=(part, rows))
+        else:
+            y, _, *tap = conv2d_gemm(x, conv, fork=do_fork)
+            out = bn_act(y, bn, relu, residual, pool)
+        return (out, tap[0] if tap else x) if fork else out
+    out = bn_act(conv2d(x, conv), bn, relu, residual, pool)
+    return (out, x) if fork else out
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -341,6 +359,37 @@ def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm2d, relu: bool, residual: Opti
     if pool == 0:
         return y.mean(dim=[2, 3], keepdim=True)
     return avg_pool2(y) if pool == 2 else y
+
+
+_FROZEN_CONSTS: dict = {}
+
+
+def frozen_bn_fusable(x: torch.Tensor, channels: int) -> bool:
+    """The frozen stages in the throughput mode: no gradient flows through them and the channel count fits the streaming kernels'
+    thread mapping (coin_bn_apply_fwd: 8 bf16 channels per lane, a row of channel groups divides or is a multiple of a workgroup)."""
+    if not x.is_cuda or x.dtype != torch.bfloat16 or (torch.is_grad_enabled() and x.requires_grad):
+        return False
+    ncg = channels // 8
+    return channels % 8 == 0 and (256 % ncg == 0 if ncg <= 256 else ncg % 256 == 0)
+
+
+def frozen_bn_act(x: torch.Tensor, bn: torch.nn.Module, relu: bool, residual: Optional[torch.Tensor] = None, pool: int = 1) -> torch.Tensor:
+    """detectron2 FrozenBatchNorm2d (+ identity) (+ ReLU) (+ nn.AvgPool2d(2)) of a frozen CLIP stage (coin/modeling/utils.py:77-90 with
+    the norms converted, :243-284) as ONE pass over the convolution's output: the statistics slots of coin_bn_apply_fwd carry the
+    frozen running statistics.  Replaces the library's bias add, ReLU, residual add and ReLU launches (4 passes) on the largest
+    activations of the network.  Caller checked `frozen_bn_fusable`."""
+    src = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    key = tuple((t.data_ptr(), t._version) for t in src)
+    hit = _FROZEN_CONSTS.get(id(bn))
+    if hit is None or hit[0] != key or hit[1]() is not bn:
+        with torch.no_grad():
+            consts = (bn.running_mean.float().contiguous(), (bn.running_var.float() + bn.eps).rsqrt().contiguous(),
+                      bn.weight.float().contiguous(), bn.bias.float().contiguous())
+        hit = (key, weakref.ref(bn, lambda _r, k=id(bn): _FROZEN_CONSTS.pop(k, None)), consts)
+        _FROZEN_CONSTS[id(bn)] = hit
+    mean, rstd, g, b = hit[2]
+    y = K.bn_apply_fwd(_as_nhwc(x), mean, rstd, g, b, _as_nhwc(residual) if residual is not None else None, relu, pool)
+    return y.permute(0, 3, 1, 2)
 
 
 class _AvgPool2(Function):

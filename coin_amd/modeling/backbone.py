@@ -63,9 +63,18 @@ class FrozenBatchNorm2d(nn.Module):
         return module
 
 
-def _conv_bn(x, conv: nn.Conv2d, bn: nn.Module, relu: bool):
-    """conv -> norm (-> relu).  In the bf16 throughput mode a frozen norm is folded into the convolution; the fp32
-    parity mode keeps the reference's operation order (conv, then x*scale + shift)."""
+def _conv_bn(x, conv: nn.Conv2d, bn: nn.Module, relu: bool, residual=None, pool: int = 1):
+    """conv -> norm (+ identity) (-> relu) (-> 2x2 average pool).  In the bf16 throughput mode a frozen norm and the whole
+    elementwise tail are one fused pass over the convolution's output (coin_amd.layers.frozen_bn_act) -- or, where that kernel's
+    thread mapping does not fit the width, the norm is folded into the convolution; the fp32 parity mode keeps the reference's
+    operation order (conv, then x*scale + shift)."""
+    if isinstance(bn, FrozenBatchNorm2d) and L.frozen_bn_fusable(x, conv.out_channels):
+        return L.frozen_bn_act(L.conv2d(x, conv), bn, relu, residual, pool)
+    if residual is not None or pool != 1:
+        y = _conv_bn(x, conv, bn, False)
+        y = y + residual if residual is not None else y
+        y = F.relu(y) if relu else y
+        return F.avg_pool2d(y, pool) if pool != 1 else y
     if isinstance(bn, FrozenBatchNorm2d) and x.dtype != torch.float32:
         w, b = _folded(conv, bn, x.dtype)
         y = F.conv2d(x, w, b, conv.stride, conv.padding)
@@ -120,15 +129,14 @@ class Bottleneck(nn.Module):
             return self.forward(x).mean(dim=[2, 3], keepdim=True)
         if isinstance(self.bn1, FrozenBatchNorm2d):  # frozen stage (layer1 at FREEZE_AT=2): plain inference ops
             y = _conv_bn(x, self.conv1, self.bn1, True)
-            y = _conv_bn(y, self.conv2, self.bn2, True)
-            y = _conv_bn(self.avgpool(y), self.conv3, self.bn3, False)
+            y = _conv_bn(y, self.conv2, self.bn2, True, pool=self.stride)
             if self.downsample is not None:
                 x = _conv_bn(self.downsample[0](x), self.downsample[1], self.downsample[2], False)
-            return F.relu(y + x)
+            return _conv_bn(y, self.conv3, self.bn3, True, residual=x)
         # trainable stage: every BatchNorm + elementwise tail is a fused HIP stream (coin_amd.layers.bn_act)
         pool = 2 if self.stride > 1 else 1
         assert self.stride in (1, 2)
-        y = L.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        y, x = L.conv_bn_act(x, self.conv1, self.bn1, relu=True, fork=True)            # x: the identity branch's tap (gradient fan-in fused)
         y = L.conv_bn_act(y, self.conv2, self.bn2, relu=True, pool=pool)               # ReLU and the anti-aliasing avg-pool fused in
         if self.downsample is not None:
             sx = L.avg_pool2(x) if pool == 2 else x
@@ -182,9 +190,9 @@ class ModifiedResNet(nn.Module):
         return self
 
     def _stem(self, x):
-        for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)):
-            x = _conv_bn(x, conv, bn, True)
-        return self.avgpool(x)
+        x = _conv_bn(x, self.conv1, self.bn1, True)
+        x = _conv_bn(x, self.conv2, self.bn2, True)
+        return _conv_bn(x, self.conv3, self.bn3, True, pool=2)   # self.avgpool = nn.AvgPool2d(2) fused into the last pass
 
     def forward(self, x, frozen_done: bool = False) -> Dict[str, torch.Tensor]:
         """frozen_done: `x` is already the output of `frozen_forward` (the stages without trainable parameters)."""

@@ -164,6 +164,8 @@ int coin_cosine_logits_bwd(const float* d_scores, const void* feats, int ldf, co
  *   mode 1: implicit 3x3 / pad 1 / stride 1 convolution: A = NHWC activation [M/(H*W), H, W, Cin], K = 9*Cin ordered
  *           (ky, kx, ci) = the channels-last weight layout [Cout][3][3][Cin]; taps outside the image read zeros.
  * The data-gradient is the same contraction with the weight re-laid as [Cin][flipped tap][Cout].
+ * R (optional, bf16 [M,N], row stride ldr): C = bf16(bf16(Aop.B^T) + R) -- the other branch's gradient where a Bottleneck's input
+ *   fans out to conv1 and to the identity path (coin/modeling/utils.py:77-90): the sum autograd would form with a separate pass.
  * stats (optional): per (256-row tile, column) statistics of the STORED bf16 outputs over rows < stats_rows, as
  *   stats[tile][0][n] = pivot (the tile's first row), [1][n] = sum(x - pivot), [2][n] = sum((x - pivot)^2);
  *   coin_conv_gemm_stats_bytes(M, N) bytes.  coin_conv_gemm_stats_finalize turns them into the train-mode BatchNorm
@@ -171,7 +173,8 @@ int coin_cosine_logits_bwd(const float* d_scores, const void* feats, int ldf, co
  *   statistics pass over the activation (coin_bn_stats) is not needed after a convolution run through this entry point. */
 size_t coin_conv_gemm_stats_bytes(int M, int N);
 int coin_conv_gemm_bf16(const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb,
-                        void* C, int ldc, int M, int N, int K, float* stats, int64_t stats_rows, void* stream);
+                        void* C, int ldc, const void* R, int ldr, int M, int N, int K, float* stats, int64_t stats_rows,
+                        void* stream);
 int coin_conv_gemm_stats_finalize(const float* partials, int M, int N, int64_t rows, float eps, float momentum,
                                   float* mean, float* rstd, float* running_mean, float* running_var, void* stream);
 

@@ -67,7 +67,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.coin_gemm_nt(None, 8, None, 8, None, 8, 1, 1, 8, None, 0, 0.0, 0, 0, None) == -1
     assert lib.coin_mil_ce_fwd_bwd(None, 9, None, None, None, 4, 9, 1, 1, None, None, None) == -1
     assert lib.coin_nms_batched(None, None, 1, 20000, 0.5, 10, None, None, None, None) == -1
-    assert lib.coin_conv_gemm_bf16(None, 64, 0, 0, 0, 0, None, 64, None, 8, 256, 8, 64, None, 0, None) == -1
+    assert lib.coin_conv_gemm_bf16(None, 64, 0, 0, 0, 0, None, 64, None, 8, None, 0, 256, 8, 64, None, 0, None) == -1
     assert lib.coin_conv_gemm_stats_bytes(401408, 512) == 1568 * 3 * 512 * 4
 
 

@@ -63,7 +63,7 @@ def main():
         strong, weak = next(tr._data_loader_iter)
         strong, weak = tr.set_boxes([strong, weak])
         strong.extend(weak)
-        rec, h1, d1 = phase(lambda: tr.ddp_model(strong, branch="pre_train", update_prototype=False))
+        rec, h1, d1 = phase(lambda: tr.model(strong, branch="pre_train", update_prototype=False))
         loss = sum(rec.values())
         _, h0, d0 = phase(lambda: tr.optimizer.zero_grad())
         _, h2, d2 = phase(lambda: loss.backward())
@@ -79,6 +79,15 @@ def main():
     ka = prof.key_averages(group_by_input_shape=True)
     lines.append(ka.table(sort_by="self_cuda_time_total", row_limit=90, max_name_column_width=60, max_shapes_column_width=90))
     lines.append(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=40, max_name_column_width=60))
+    # elementwise glue by (op, input shapes): what the fused kernels do not cover yet
+    glue = [e for e in ka if e.key.startswith("aten::") and not any(t in e.key for t in ("conv", "mm", "linear", "matmul", "attention", "layer_norm"))]
+    dev_t = lambda e: getattr(e, "self_device_time_total", None) if hasattr(e, "self_device_time_total") else e.self_cuda_time_total
+    glue.sort(key=lambda e: -dev_t(e))
+    lines.append("\nelementwise / copy glue by input shape (self device time over %d steps):" % args.steps)
+    for e in glue[:60]:
+        if dev_t(e) <= 0:
+            break
+        lines.append(f"{dev_t(e) / 1e3 / args.steps:8.3f} ms/step  n/step={e.count / args.steps:6.1f}  {e.key:28s} {str(e.input_shapes)[:150]}")
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     with open(args.out, "w") as f:
         f.write("\n".join(lines))

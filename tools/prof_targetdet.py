@@ -16,7 +16,7 @@ from coin_amd.engine import CoinTrainer
 step_two = "--step-two" in sys.argv
 cfg = get_cfg()
 cfg.merge_from_file(os.path.join(ROOT, "configs", "coin", "GDINO", "foggy_synthetic.yaml"))
-cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", 2, "AMD.SYNTHETIC.NUM_IMAGES", 2, "AMD.TEXT_TEMPLATES", 2, "MODEL.DEVICE", "cuda:0",
+cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", 3, "AMD.SYNTHETIC.NUM_IMAGES", 3, "AMD.TEXT_TEMPLATES", 4, "MODEL.DEVICE", "cuda:0",
                      "CLOUD.BURN_UP_STEP", 0 if step_two else 10 ** 9, "CLOUD.PROTOTYPE_UPDATE_START", 0])
 torch.manual_seed(cfg.SEED)
 tr = CoinTrainer(cfg)
@@ -29,13 +29,18 @@ def teacher(batched_inputs, branch=None, **kw):
 
 
 tr.offline_teacher.forward = teacher
+tr.max_iter = 10 ** 9
 for _ in range(3):
     tr.run_step()
+    tr.prepare_next()
 torch.cuda.synchronize()
 pr = cProfile.Profile()
 pr.enable()
-tr.run_step()
+for _ in range(3):
+    tr.run_step()
+    tr.prepare_next()
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("cumulative").print_stats(45)
+st.sort_stats("cumulative").print_stats(70)
+st.sort_stats("tottime").print_stats(40)
