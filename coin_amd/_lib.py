@@ -49,6 +49,8 @@ SIGNATURES = {
     "coin_conv_gemm_bf16": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P],
     "coin_conv_gemm_stats_finalize": [_P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P],
     "coin_conv_wgrad_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "coin_anchor_match": [_P, _P, _I, _P, _I, _F, _F, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "coin_sample_labels": [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P],
     "coin_transpose2d": [_P, _P, _I, _I, _I, _P],
     "coin_bias_act_bwd": [_P, _P, _P, _I, _I, _I, _P, _I, _F, _I, _P],
     "coin_cosine_logits_fwd": [_P, _I, _P, _I, _I, _I, _F, _P, _P, _I, _P],

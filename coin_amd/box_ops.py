@@ -40,6 +40,23 @@ class Matcher:
             labels = torch.where((iou == best_per_gt).any(dim=0), torch.ones_like(labels), labels)
         return matches, labels
 
+    def match_boxes(self, gt_boxes: Sequence[torch.Tensor], pred_boxes: torch.Tensor, empty_label=None, want_boxes: bool = True):
+        """`self(pairwise_iou(gt_i, pred))` for a batch of images against one shared set of boxes, as one HIP launch sequence
+        (coin_anchor_match: IoU, arg-max, threshold bands and the low-quality rule fused; bit-exact with the composed ops).
+        -> (matched index [N, P] int64, label [N, P] int8, matched gt box [N, P, 4] or None).  An image without boxes gets index 0 and
+        `empty_label` (default: the Matcher's own answer for an empty IoU matrix, its lowest band's label)."""
+        th, lb = self.thresholds[1:-1], self.labels
+        if len(th) == 1:
+            lo = hi = th[0]
+            bands = (lb[0], lb[0], lb[1])
+        elif len(th) == 2:
+            lo, hi = th
+            bands = (lb[0], lb[1], lb[2])
+        else:
+            raise NotImplementedError("Matcher.match_boxes: one or two IoU thresholds")
+        return K.anchor_match(list(gt_boxes), pred_boxes, lo, hi, bands, lb[0] if empty_label is None else empty_label,
+                              self.allow_low_quality_matches, want_boxes)
+
 
 def subsample_labels(labels: torch.Tensor, num_samples: int, positive_fraction: float, bg_label: int):
     """Random fg / bg index subsets: two randperm draws, positives first (detectron2 sampling.py)."""
@@ -52,25 +69,21 @@ def subsample_labels(labels: torch.Tensor, num_samples: int, positive_fraction: 
     return positive[p1], negative[p2]
 
 
-def sample_masks(cls: torch.Tensor, num_samples: int, positive_fraction: float, bg_label: int):
-    """Sync-free form of `subsample_labels` for a batch: cls [N, M] (-1 = ignore, bg_label = negative, else positive) ->
-    boolean masks (chosen_pos, chosen_neg), each row a uniformly random subset with
+def sample_labels(cls: torch.Tensor, num_samples: int, positive_fraction: float, bg_label: int) -> torch.Tensor:
+    """Sync-free form of `subsample_labels` for a batch: cls [N, M] int8 / int64 (-1 = ignore, bg_label = negative, else positive)
+    -> int8 [N, M]: 1 = chosen positive, 0 = chosen negative, -1 = not chosen; each row a uniformly random subset with
     |pos| = min(#pos, int(num_samples*positive_fraction)), |neg| = min(#neg, num_samples - |pos|).
-    One random key per element and ONE sort; no data-dependent shapes, so nothing is read back to the host.  The random
+    One uniform key per element (torch.rand) and a radix select per class in ONE launch (coin_sample_labels: the elements an
+    ascending stable sort by key would rank first); no data-dependent shapes, so nothing is read back to the host.  The random
     stream differs from torch.randperm's (the reference's), the distribution does not."""
-    n, m = cls.shape
-    pos = (cls != -1) & (cls != bg_label)
-    neg = cls == bg_label
-    tier = torch.where(pos, 0.0, torch.where(neg, 2.0, 4.0))
-    keys = torch.rand((n, m), device=cls.device) + tier
-    order = keys.argsort(dim=1)
-    rank = torch.empty_like(order)
-    rank.scatter_(1, order, torch.arange(m, device=cls.device).expand(n, m))
-    cnt_pos = pos.sum(dim=1, keepdim=True)
-    n_pos = cnt_pos.clamp(max=int(num_samples * positive_fraction))
-    chosen_pos = pos & (rank < n_pos)
-    chosen_neg = neg & ((rank - cnt_pos) < (num_samples - n_pos))
-    return chosen_pos, chosen_neg
+    keys = torch.rand(cls.shape, device=cls.device)
+    return K.sample_labels(cls.contiguous(), keys, bg_label, num_samples, int(num_samples * positive_fraction))
+
+
+def sample_masks(cls: torch.Tensor, num_samples: int, positive_fraction: float, bg_label: int):
+    """`sample_labels` as boolean masks (chosen_pos, chosen_neg)."""
+    out = sample_labels(cls, num_samples, positive_fraction, bg_label)
+    return out == 1, out == 0
 
 
 class Box2BoxTransform:

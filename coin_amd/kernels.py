@@ -518,6 +518,49 @@ def nms_batched(boxes: torch.Tensor, counts: torch.Tensor, iou_threshold: float,
     return keep, num
 
 
+# --------------------------------------------------------------------------- anchor / proposal labelling
+def anchor_match(gt_boxes: Sequence[torch.Tensor], anchors: torch.Tensor, lo: float, hi: float, labels: Tuple[int, int, int],
+                 empty_label: int, allow_low_quality: bool, want_boxes: bool = True):
+    """detectron2 Matcher(thresholds [lo, hi], labels) over pairwise_iou(gt_i, anchors) for a batch of images in one launch
+    sequence (coin_anchor_match).  gt_boxes: per image a [G_i, 4] float32 tensor (G_i may be 0); anchors [A, 4].
+    -> matched gt index [N, A] int64, label [N, A] int8, matched gt box [N, A, 4] (or None)."""
+    anchors = _f32c(anchors, "anchors")
+    _dev(anchors, *gt_boxes)
+    n, a = len(gt_boxes), anchors.shape[0]
+    offs = [0]
+    for g in gt_boxes:
+        offs.append(offs[-1] + int(g.shape[0]))
+    total = offs[-1]
+    if total:
+        nz = [g.reshape(-1, 4).float() for g in gt_boxes if g.shape[0]]
+        cat = (nz[0] if len(nz) == 1 else torch.cat(nz)).contiguous()
+    else:
+        cat = None
+    matched = torch.empty((n, a), dtype=torch.int64, device=anchors.device)
+    lab = torch.empty((n, a), dtype=torch.int8, device=anchors.device)
+    mb = torch.empty((n, a, 4), dtype=torch.float32, device=anchors.device) if want_boxes else None
+    ws = torch.empty(max(total, 1), dtype=torch.int32, device=anchors.device) if allow_low_quality else None
+    c_offs = (ctypes.c_int * (n + 1))(*offs)
+    check(_lib.lib().coin_anchor_match(_p(cat), c_offs, n, _p(anchors), a, float(lo), float(hi), int(labels[0]), int(labels[1]), int(labels[2]),
+                                       int(empty_label), int(bool(allow_low_quality)), _p(matched), _p(lab), _p(mb), _p(ws), _stream()),
+          "coin_anchor_match")
+    return matched, lab, mb
+
+
+def sample_labels(cls: torch.Tensor, keys: torch.Tensor, bg_label: int, num_samples: int, pos_cap: int) -> torch.Tensor:
+    """cls [N, M] int8 / int64 (-1 ignore, bg_label negative, else positive), keys [N, M] float32 in [0, 1) -> int8 [N, M]:
+    1 for the min(#pos, pos_cap) positives and 0 for the min(#neg, num_samples - #chosen pos) negatives with the smallest keys
+    (ties: lowest index), -1 elsewhere (coin_sample_labels)."""
+    _dev(cls, keys)
+    if cls.dim() != 2 or keys.shape != cls.shape or cls.dtype not in (torch.int8, torch.int64) or not cls.is_contiguous():
+        raise CoinHipError("sample_labels: cls must be a contiguous [N, M] int8 / int64 tensor and keys float32 of the same shape")
+    keys = _f32c(keys, "keys")
+    out = torch.empty(cls.shape, dtype=torch.int8, device=cls.device)
+    check(_lib.lib().coin_sample_labels(_p(cls), int(cls.dtype == torch.int64), _p(keys), cls.shape[0], cls.shape[1], int(bg_label), int(num_samples),
+                                        int(pos_cap), _p(out), _stream()), "coin_sample_labels")
+    return out
+
+
 # --------------------------------------------------------------------------- streams of bytes
 def normalize_pad(images: Sequence[torch.Tensor], mean: Sequence[float], std: Sequence[float],
                   size_divisibility: int = 0, layout: int = COIN_NCHW, dtype: torch.dtype = torch.float32):

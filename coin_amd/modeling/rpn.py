@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import layers as L
-from ..box_ops import Box2BoxTransform, Matcher, cell_anchors, find_top_rpn_proposals, grid_anchors, sample_masks, subsample_labels
+from ..box_ops import Box2BoxTransform, Matcher, cell_anchors, find_top_rpn_proposals, grid_anchors, sample_labels, sample_masks, subsample_labels
 from ..registry import PROPOSAL_GENERATOR_REGISTRY
 from ..structures import Boxes, ImageList, Instances, pairwise_iou
 
@@ -158,46 +158,33 @@ class DualTeacherRPN(nn.Module):
 
     @torch.no_grad()
     def label_and_sample_anchors_sync_free(self, anchors: List[Boxes], gt_instances):
-        """pre_train labelling (rpn.py:139-197) without host round trips: same matcher, sampling via `sample_masks`."""
+        """pre_train labelling (rpn.py:139-197) without host round trips: the same matcher (one fused launch sequence for the batch:
+        coin_anchor_match), sampling via `sample_labels`.  An image without boxes: every anchor ignored, matched boxes zero (:190-193)."""
         a = Boxes.cat(anchors)
-        labs, boxes = [], []
-        for g in gt_instances:
-            gb = g.gt_boxes
-            if len(gb) == 0:
-                labs.append(torch.full((len(a),), -1, dtype=torch.int8, device=a.tensor.device))
-                boxes.append(torch.zeros_like(a.tensor))
-                continue
-            idx, lab = self.anchor_matcher(pairwise_iou(gb, a))
-            labs.append(lab)
-            boxes.append(gb.tensor[idx])
-        lab = torch.stack(labs)                                    # [N, A] in {-1, 0, 1}
-        pos, neg = sample_masks(lab.to(torch.int64), self.batch_size_per_image, self.positive_fraction, 0)
-        out = torch.where(pos, 1, torch.where(neg, 0, -1)).to(torch.int8)
-        return list(out), boxes
+        _, lab, mb = self.anchor_matcher.match_boxes([g.gt_boxes.tensor for g in gt_instances], a.tensor, empty_label=-1)
+        out = sample_labels(lab, self.batch_size_per_image, self.positive_fraction, 0)
+        return list(out), list(mb)
 
     @torch.no_grad()
     def label_and_sample_anchors(self, anchors: List[Boxes], gt_instances, branch):
         anchors = Boxes.cat(anchors)
         labels_out, boxes_out = [], []
         if branch == "pre_train":
-            for g in gt_instances:
-                gb = g.gt_boxes
-                idx, lab = self.anchor_matcher(pairwise_iou(gb, anchors))
+            _, labs, mbs = self.anchor_matcher.match_boxes([g.gt_boxes.tensor for g in gt_instances], anchors.tensor)
+            for g, lab, mb in zip(gt_instances, labs, mbs):
                 lab = self._subsample_labels(lab)
-                if len(gb) == 0:
-                    mb = torch.zeros_like(anchors.tensor)
+                if len(g.gt_boxes) == 0:
                     lab[:] = -1
-                else:
-                    mb = gb.tensor[idx]
                 labels_out.append(lab)
                 boxes_out.append(mb)
             return labels_out, boxes_out
         ga, gc = gt_instances
         midx_out, dist_out = [], []
-        for a, c in zip(ga, gc):
+        idxs, labs, _ = self.anchor_matcher.match_boxes([torch.cat([a.gt_boxes.tensor.reshape(-1, 4), c.gt_boxes.tensor.reshape(-1, 4)])
+                                                         for a, c in zip(ga, gc)], anchors.tensor, want_boxes=False)
+        for a, c, idx, lab in zip(ga, gc, idxs, labs):
             ba, bc = a.gt_boxes, c.gt_boxes
             both = Boxes.cat([ba, bc])
-            idx, lab = self.anchor_matcher(pairwise_iou(both, anchors))
             in_c = (idx >= len(ba)) & (idx < len(both))
             is_bg = lab == 0
             fg_c = in_c & ~is_bg
@@ -228,7 +215,9 @@ class DualTeacherRPN(nn.Module):
         a = Boxes.cat(anchors)
         ga, gc = gt_instances
         labs, boxes, midx, dlabs = [], [], [], []
-        for ta, tc in zip(ga, gc):
+        idxs, labs_m, _ = self.anchor_matcher.match_boxes([torch.cat([ta.gt_boxes.tensor.reshape(-1, 4), tc.gt_boxes.tensor.reshape(-1, 4)])
+                                                           for ta, tc in zip(ga, gc)], a.tensor, want_boxes=False)
+        for i, (ta, tc) in enumerate(zip(ga, gc)):
             ba, bc = ta.gt_boxes, tc.gt_boxes
             la, lc = len(ba), len(bc)
             if la + lc == 0:
@@ -238,7 +227,7 @@ class DualTeacherRPN(nn.Module):
                 midx.append(z)
                 dlabs.append(z.to(torch.int8))
                 continue
-            idx, lab = self.anchor_matcher(pairwise_iou(Boxes.cat([ba, bc]), a))
+            idx, lab = idxs[i], labs_m[i]
             in_c = (idx >= la) & (idx < la + lc)
             is_bg = lab == 0
             fg_c = in_c & ~is_bg

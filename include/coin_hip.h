@@ -270,6 +270,34 @@ int coin_nms_batched(const float* boxes, const int* counts, int B, int n_max, fl
                      int max_keep, void* workspace, int* keep, int* num_keep, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Anchor / proposal labelling  (replaces detectron2 Matcher(pairwise_iou(gt, anchors)) and the fg/bg subsampling under
+ *                               DualTeacherRPN.label_and_sample_anchors, coin/modeling/proposal_generator/rpn.py:120-254,
+ *                               and label_and_sample_proposals, coin/modeling/roi_heads/clip_roi_heads.py:283-399)
+ * coin_anchor_match: for every image i and anchor a
+ *   matched[i][a] = argmax_g IoU(gt_i[g], anchor_a)  (lowest g among equal maxima, as torch.max), and labels[i][a] =
+ *   label_lo if max < lo, label_mid if lo <= max < hi, label_hi if max >= hi (pass lo == hi for a single threshold);
+ *   with allow_low_quality: labels = 1 where IoU(gt_i[g], anchor_a) == max_a' IoU(gt_i[g], anchor_a') for some g.
+ *   IoU in fp32 with individually rounded operations in pairwise_iou's order: labels and indices are bit-exact with the
+ *   composed torch ops.  An image without boxes gets matched = 0, labels = empty_label, matched_boxes = 0.
+ * gt_boxes        : [sum G_i, 4] float32 xyxy (device), the images' boxes concatenated;
+ * gt_offsets_host : HOST array of num_images + 1 ints, image i owns rows [off[i], off[i+1]); G_i <= 512, num_images <= 64
+ * anchors         : [A, 4] float32 (device), shared by the images
+ * matched         : [num_images, A] int64;  labels: [num_images, A] int8;  matched_boxes (optional): [num_images, A, 4]
+ * workspace       : 4 * sum G_i bytes of device memory when allow_low_quality (contents undefined), else may be NULL.
+ *
+ * coin_sample_labels: per image the k_pos = min(#pos, pos_cap) positives and k_neg = min(#neg, num_samples - k_pos)
+ *   negatives with the smallest random key (ties: lowest index) -- the subsets an ascending stable sort by key would rank
+ *   first, found by a radix select.  cls [num_images, M] int8 or int64: -1 ignore, bg_label negative, else positive;
+ *   keys [num_images, M] float32 >= 0;  out [num_images, M] int8 = 1 (chosen positive) / 0 (chosen negative) / -1.
+ * ---------------------------------------------------------------------------------------- */
+int coin_anchor_match(const float* gt_boxes, const int* gt_offsets_host, int num_images, const float* anchors, int A,
+                      float lo, float hi, int label_lo, int label_mid, int label_hi, int empty_label,
+                      int allow_low_quality, int64_t* matched, int8_t* labels, float* matched_boxes, void* workspace,
+                      void* stream);
+int coin_sample_labels(const void* cls, int cls_is_int64, const float* keys, int num_images, int M, int bg_label,
+                       int num_samples, int pos_cap, int8_t* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Input normalisation  (replaces OpenVocabularyRCNN.preprocess_image, clip_rcnn.py:287-298:
  *                       ToTensor + Normalize + ImageList.from_tensors zero padding)
  * img   : [3,h,w] uint8 (CHW, as the dataset mapper emits); mean/std_ are HOST arrays of 3 floats

@@ -125,6 +125,43 @@ def _nms_batched(boxes, counts, iou_threshold, max_keep):
     return keep, num
 
 
+def _anchor_match(gt_boxes, anchors, lo, hi, labels, empty_label, allow_low_quality, want_boxes=True):
+    """coin_anchor_match from the oracle's Matcher + pairwise_iou (oracle/d2.py), image by image."""
+    if lo == hi:
+        m = d2.Matcher([lo], [labels[0], labels[2]], allow_low_quality_matches=allow_low_quality)
+    else:
+        m = d2.Matcher([lo, hi], list(labels), allow_low_quality_matches=allow_low_quality)
+    idxs, labs, mbs = [], [], []
+    for g in gt_boxes:
+        g = g.reshape(-1, 4).float()
+        if g.shape[0] == 0:
+            idxs.append(torch.zeros(anchors.shape[0], dtype=torch.int64))
+            labs.append(torch.full((anchors.shape[0],), empty_label, dtype=torch.int8))
+            mbs.append(torch.zeros_like(anchors))
+            continue
+        idx, lab = m(d2.pairwise_iou(d2.Boxes(g), d2.Boxes(anchors)))
+        idxs.append(idx)
+        labs.append(lab.to(torch.int8))
+        mbs.append(g[idx])
+    return torch.stack(idxs), torch.stack(labs), (torch.stack(mbs) if want_boxes else None)
+
+
+def _sample_labels(cls, keys, bg_label, num_samples, pos_cap):
+    """coin_sample_labels as its definition: rank by an ascending STABLE sort of the keys inside each class."""
+    n, m = cls.shape
+    pos = (cls != -1) & (cls != bg_label)
+    neg = cls == bg_label
+    tier = torch.where(pos, 0.0, torch.where(neg, 2.0, 4.0)).double()
+    order = (keys.double() + tier).argsort(dim=1, stable=True)
+    rank = torch.empty_like(order)
+    rank.scatter_(1, order, torch.arange(m).expand(n, m))
+    cnt_pos = pos.sum(dim=1, keepdim=True)
+    n_pos = cnt_pos.clamp(max=pos_cap)
+    chosen_pos = pos & (rank < n_pos)
+    chosen_neg = neg & ((rank - cnt_pos) < (num_samples - n_pos))
+    return torch.where(chosen_pos, 1, torch.where(chosen_neg, 0, -1)).to(torch.int8)
+
+
 class _CpuSgdTable:
     def __init__(self, params, lrs, wds, shadows=None):
         self.params, self.lrs, self.wds = list(params), list(lrs), list(wds)
@@ -161,7 +198,8 @@ def cpu_kernels():
         L: dict(linear_act=_linear_act, cosine_logits=_cosine_logits, mil_cross_entropy=_mil, mil_focal_loss=_mil_focal, kl_div_from_logits=_kl_logits,
                 kl_div_from_probs=_kl_probs, kl_div_binary=_kl_binary, box_reg_l1=_box_reg, l1_mean=lambda a, b: F.l1_loss(a, b),
                 rpn_losses=_rpn_losses, roi_align=_roi_align, bn_act=_bn_act, avg_pool2=lambda x: F.avg_pool2d(x, 2)),
-        K: dict(normalize_pad=_normalize_pad, nms_batched=_nms_batched, SgdTable=_CpuSgdTable, EmaTable=_CpuEmaTable),
+        K: dict(normalize_pad=_normalize_pad, nms_batched=_nms_batched, SgdTable=_CpuSgdTable, EmaTable=_CpuEmaTable, anchor_match=_anchor_match,
+                sample_labels=_sample_labels),
     }
     saved = {mod: {k: getattr(mod, k) for k in d} for mod, d in patches.items()}
     try:

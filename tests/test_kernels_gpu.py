@@ -618,6 +618,71 @@ def test_frozen_stage_fused_tail_vs_fp64(monkeypatch):
     assert float((old.double().cpu() - ref).norm() / ref.norm()) < 1.5e-2
 
 
+# ------------------------------------------------------------------------------------------ anchor labelling / subsampling
+@pytest.mark.parametrize("low_quality,thresholds,labels", [(True, (0.3, 0.7), (0, -1, 1)), (False, (0.5,), (0, 1))])
+def test_anchor_match_bit_exact_vs_oracle_matcher(K, low_quality, thresholds, labels):
+    """coin_anchor_match = detectron2 Matcher(pairwise_iou(gt, anchors)) (oracle/d2.py) per image: indices and labels bit-exact,
+    including equal maxima (lowest index), IoUs that sit exactly on a threshold, the low-quality rule's quirk for a box that
+    overlaps nothing, an image without boxes and duplicated boxes; at the benchmark's 62 250 anchors."""
+    from oracle import d2
+
+    from coin_amd.box_ops import Matcher, cell_anchors, grid_anchors
+
+    g = torch.Generator().manual_seed(11)
+    cells = cell_anchors((32, 64, 128, 256, 512), (0.5, 1.0, 2.0))
+    anchors = grid_anchors(cells, (50, 83), 16, 0.0, "cpu")
+    a = anchors.shape[0]
+    assert a == 50 * 83 * 15
+    def boxes(n):
+        xy = torch.rand(n, 2, generator=g) * torch.tensor([1100.0, 600.0])
+        wh = torch.rand(n, 2, generator=g) * 300 + 8
+        return torch.cat([xy, xy + wh], dim=1)
+    imgs = [boxes(32), torch.zeros(0, 4), boxes(1), boxes(200)]
+    imgs[0][5] = anchors[12345]                      # IoU exactly 1 with one anchor
+    imgs[0][6] = imgs[0][5]                          # duplicate box: equal maxima -> lowest index
+    imgs[0][7] = torch.tensor([5000.0, 5000.0, 5100.0, 5100.0])   # overlaps no anchor: best IoU 0
+    imgs[3][9] = anchors[777] + torch.tensor([0.0, 0.0, 16.0, 0.0])
+    m = Matcher(list(thresholds), list(labels), allow_low_quality_matches=low_quality)
+    idx, lab, mb = m.match_boxes([dev(b) for b in imgs], dev(anchors))
+    ref = d2.Matcher(list(thresholds), list(labels), allow_low_quality_matches=low_quality)
+    for i, b in enumerate(imgs):
+        if b.shape[0] == 0:
+            assert int(idx[i].abs().max()) == 0 and bool((lab[i] == labels[0]).all()) and float(mb[i].abs().max()) == 0.0
+            continue
+        ri, rl = ref(d2.pairwise_iou(d2.Boxes(b), d2.Boxes(anchors)))
+        assert torch.equal(idx[i].cpu(), ri), (i, int((idx[i].cpu() != ri).sum()))
+        assert torch.equal(lab[i].cpu(), rl.to(torch.int8)), (i, int((lab[i].cpu() != rl).sum()))
+        assert torch.equal(mb[i].cpu(), b[ri])
+    if low_quality:
+        assert bool((lab[0] == 1).sum() > a // 2)    # the quirk: the box that overlaps nothing marks every IoU-0 anchor positive
+    _, lab2, none = m.match_boxes([dev(b) for b in imgs], dev(anchors), empty_label=-1, want_boxes=False)
+    assert none is None and bool((lab2[1] == -1).all()) and torch.equal(lab2[0], lab[0])
+
+
+def test_sample_labels_is_the_stable_sort_definition(K):
+    """coin_sample_labels (radix select per class) picks exactly the elements an ascending stable sort by key ranks first
+    (tests/cpu_shim.py:_sample_labels), with repeated keys, a class smaller / larger than its quota, empty classes, int8 and int64."""
+    from cpu_shim import _sample_labels
+
+    g = torch.Generator().manual_seed(3)
+    n, m = 7, 62250
+    cls = torch.randint(-1, 3, (n, m), generator=g)              # bg label = 0
+    cls[0] = -1
+    cls[1] = 0
+    cls[2, :100] = 2
+    cls[2, 100:] = -1
+    cls[3] = torch.where(torch.rand(m, generator=g) < 0.001, 1, 0)
+    keys = torch.rand(n, m, generator=g)
+    keys[4] = (keys[4] * 64).floor() / 64                        # heavy ties: 64 distinct keys
+    keys[5, ::2] = 0.0
+    for dt in (torch.int64, torch.int8):
+        out = K.sample_labels(dev(cls.to(dt)), dev(keys), 0, 256, 128)
+        ref = _sample_labels(cls, keys, 0, 256, 128)
+        assert torch.equal(out.cpu(), ref), [int((out[i].cpu() != ref[i]).sum()) for i in range(n)]
+    out = K.sample_labels(dev(cls[:, :300].contiguous()), dev(keys[:, :300].contiguous()), 0, 64, 16)
+    assert torch.equal(out.cpu(), _sample_labels(cls[:, :300], keys[:, :300], 0, 64, 16))
+
+
 # ------------------------------------------------------------------------------------------ NMS
 def test_nms_batched_vs_oracle(K):
     from oracle import d2

@@ -19,6 +19,11 @@ def test_sample_masks_counts_and_membership():
     cls[1, :290] = -1                                             # almost everything ignored
     cls[2] = torch.where(torch.rand(300, generator=g) < 0.9, torch.tensor(1), torch.tensor(4))  # more positives than the cap
     torch.manual_seed(1)
+    with cpu_kernels():  # coin_sample_labels by its definition (tests/cpu_shim.py); the kernel itself: tests/test_kernels_gpu.py
+        _check_sample_masks(sample_masks, cls)
+
+
+def _check_sample_masks(sample_masks, cls):
     pos, neg = sample_masks(cls, 64, 0.25, 4)
     is_pos, is_neg = (cls != -1) & (cls != 4), cls == 4
     assert not (pos & ~is_pos).any() and not (neg & ~is_neg).any()
