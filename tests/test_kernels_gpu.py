@@ -275,8 +275,9 @@ def test_bottleneck_gradient_fan_in_fused_in_dgrad_epilogue(monkeypatch, inplane
         res.append((y.detach().clone(), x.grad.clone(), blk.conv1.weight.grad.clone()))
     assert torch.equal(res[0][0], res[1][0]), "forward differs"
     assert torch.equal(res[0][1], res[1][1]), float((res[0][1].float() - res[1][1].float()).abs().max())
-    # the weight gradient comes from the library's split-K contraction (atomic accumulation: not bit-reproducible run to run)
-    torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-3, atol=1e-3 * float(res[1][2].abs().max()))
+    # the weight gradient comes from the library's split-K contraction (atomic accumulation, bf16 result: not bit-reproducible run
+    # to run, one bf16 ulp = 0.4 %)
+    torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-2, atol=1e-2 * float(res[1][2].abs().max()))
 
 
 def test_gemm_rejects_bad_shapes(K):
