@@ -18,6 +18,7 @@ gradients away (``optimizer.zero_grad()``, trainer.py:199); bf16 autocast needs 
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Dict, List, Optional
 
 import torch
@@ -93,11 +94,12 @@ class CoinTrainer(BASE_Trainer):
 
     # ------------------------------------------------------------------ targets (trainer.py:463-485)
     @torch.no_grad()
-    def match_boxes(self, batched_input: List[Dict], offline_results: List[Dict]):
+    def match_boxes(self, batched_input: List[Dict], offline_results: List[Dict], to_device: bool = True):
+        """to_device=False leaves the (A, B, C) targets on the host (`_targets_to_device` moves them on the consumer's stream)."""
         rcnn, rpn = [], []
         thr = self.cfg.CLOUD.MATCHER.IOU_THRESHOLDS
         for data, off in zip(batched_input, offline_results):
-            dev = off["instances"].pred_boxes.tensor.device
+            dev = off["instances"].pred_boxes.tensor.device if to_device else None
             online = self.model_CLOUD(data["file_name"])
             net = tuple(data["image"].shape[1:])
             off_i = self.process(off["instances"].to("cpu"), (data["height"], data["width"]), net, "no")
@@ -109,17 +111,43 @@ class CoinTrainer(BASE_Trainer):
 
     # ------------------------------------------------------------------ one step (trainer.py:160-218)
     def _teacher_targets(self, weak):
-        """Steps 1-3 of the iteration `self.iter`: EMA of the teacher when due, teacher inference on the weak views, matching."""
+        """Steps 1-3 of the iteration `self.iter`: EMA of the teacher when due, teacher inference on the weak views, matching.
+
+        On the GPU (cfg.AMD.TEACHER_STREAM) the three run on the teacher's own HIP stream.  The read-back of the detections then
+        waits for the teacher's kernels only -- not for the student's backward that `prepare_next` left queued on the main stream --
+        so the host walks through the matcher while the device is still busy with the student, and the teacher's (small,
+        low-occupancy) inference kernels share the GPU with that backward.  The only cross-stream dependency is the EMA, which reads
+        the weights the optimizer has just written: the teacher stream waits for the main stream when an EMA is due.  The targets
+        stay on the host until `run_step` uploads them on the main stream (no tensor crosses streams)."""
         cfg, burn = self.cfg, self.cfg.CLOUD.BURN_UP_STEP
-        if self.iter >= burn and (self.iter - burn) % cfg.CLOUD.OFFLINE_TEACHER_UPDATE_ITER == 0:
-            self.update_teacher(cfg.CLOUD.EMA_KEEP_RATE_OFFLINE)
-        with torch.no_grad():
-            self.offline_teacher.eval()
-            offline_results = self.offline_teacher(weak, branch="test")
-            self.offline_teacher.train()
-            return self.match_boxes(weak, offline_results)
+        ema_due = self.iter >= burn and (self.iter - burn) % cfg.CLOUD.OFFLINE_TEACHER_UPDATE_ITER == 0
+        side = None
+        if self.device.type == "cuda" and cfg.AMD.TEACHER_STREAM:
+            if self._teacher_stream is None:
+                self._teacher_stream = torch.cuda.Stream(device=self.device)
+                ema_due_or_first = True
+            else:
+                ema_due_or_first = ema_due
+            side = self._teacher_stream
+            if ema_due_or_first:
+                side.wait_stream(torch.cuda.current_stream(self.device))
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            if ema_due:
+                self.update_teacher(cfg.CLOUD.EMA_KEEP_RATE_OFFLINE)
+            with torch.no_grad():
+                self.offline_teacher.eval()
+                offline_results = self.offline_teacher(weak, branch="test")
+                self.offline_teacher.train()
+                return self.match_boxes(weak, offline_results, to_device=side is None)
+
+    def _targets_to_device(self, targets):
+        """(A, B, C) tuples of `match_boxes(to_device=False)` -> device, on the current (consumer's) stream."""
+        rcnn, rpn = targets
+        mv = lambda t: tuple(x.to(self.device) if x is not None else None for x in t)
+        return [mv(t) for t in rcnn], [mv(t) for t in rpn]
 
     _pending = None
+    _teacher_stream = None
     reducer = reducer_merge = None  # coin_amd.parallel.GradReducer when world_size > 1
 
     def run_step(self):
@@ -132,6 +160,8 @@ class CoinTrainer(BASE_Trainer):
         else:
             strong, dual_teacher_instances = self._pending
             self._pending = None
+        if self._teacher_stream is not None:
+            dual_teacher_instances = self._targets_to_device(dual_teacher_instances)
         start = cfg.CLOUD.PROTOTYPE_UPDATE_START
         update_prototype = start != -1 and self.iter >= start
         branch = "step_one" if self.iter < burn else "step_two"

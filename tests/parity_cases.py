@@ -290,7 +290,7 @@ def cointrainer_scripted_iteration(device, tol=1e-5):
         student.proposal_generator.label_and_sample_anchors = lambda anchors, gt, branch: (list(lab), list(mb), list(idx), list(dl))
         seen = {}
         match = tr.match_boxes
-        tr.match_boxes = lambda b, o: seen.setdefault("targets", match(b, o))
+        tr.match_boxes = lambda b, o, **kw: seen.setdefault("targets", match(b, o, **kw))
         random.seed(77)
         record = tr.run_step()
     rcnn, rpn = seen["targets"]
