@@ -37,16 +37,24 @@ def _iou_pairs(a: torch.Tensor, b: torch.Tensor, thr: float) -> torch.Tensor:
 def _identical_groups(boxes: torch.Tensor) -> Tuple[List[int], List[List[int]]]:
     """Rows that share their coordinates with another row.  Candidates are rows with an equal coordinate sum (visited in
     ascending order of that sum); a candidate set is a group iff the differences to its first member sum to zero
-    (util.py:436-451).  -> (rows outside every group, ascending; groups)."""
-    sums = boxes.sum(1)
-    in_group = torch.zeros(len(boxes), dtype=torch.bool)
+    (util.py:436-451).  -> (rows outside every group, ascending; groups).
+    One fp32 row sum on the tensor, then plain Python on the few dozen values (a torch call per candidate costs more than the
+    whole bookkeeping)."""
+    sums = boxes.sum(1).tolist()
+    by_sum: Dict[float, List[int]] = {}
+    for i, v in enumerate(sums):
+        by_sum.setdefault(v, []).append(i)
+    in_group = [False] * len(sums)
     groups = []
-    for v in torch.unique(sums).tolist():
-        members = (sums == v).nonzero()[:, 0]
-        if len(members) > 1 and float((boxes[members] - boxes[members[0]]).sum()) == 0.0:
-            groups.append(members.tolist())
-            in_group[members] = True
-    return (~in_group).nonzero()[:, 0].tolist(), groups
+    for v in sorted(by_sum):
+        members = by_sum[v]
+        if len(members) > 1:
+            idx = torch.tensor(members, dtype=torch.long)
+            if float((boxes[idx] - boxes[members[0]]).sum()) == 0.0:
+                groups.append(members)
+                for m in members:
+                    in_group[m] = True
+    return [i for i, g in enumerate(in_group) if not g], groups
 
 
 def _pick(group: Sequence[int]) -> int:
@@ -55,8 +63,10 @@ def _pick(group: Sequence[int]) -> int:
 
 def _overlap_groups(boxes: torch.Tensor, thr: float) -> List[List[int]]:
     """Groups (size > 1) of mutually overlapping boxes, merged transitively the way util.py:459-483 does it."""
-    iou = pairwise_iou(Boxes(boxes), Boxes(boxes)) >= thr
-    sets = [set(iou[i].nonzero()[:, 0].tolist()) for i in range(len(boxes))]
+    iou = (pairwise_iou(Boxes(boxes), Boxes(boxes)) >= thr).tolist()
+    sets = [{j for j, hit in enumerate(row) if hit} for row in iou]
+    if all(len(s_) <= 1 for s_ in sets):
+        return []
 
     def absorb(i: int, visited: List[int]) -> set:
         for j in list(sets[i]):
@@ -71,7 +81,7 @@ def _overlap_groups(boxes: torch.Tensor, thr: float) -> List[List[int]]:
         for j in sets[i]:
             if j != i:
                 sets[j] = set()
-    return [sorted(s) for s in sets if len(s) > 1]
+    return [sorted(s_) for s_ in sets if len(s_) > 1]
 
 
 class _Side:
@@ -136,8 +146,14 @@ def match_dual_teacher(online_result: Dict[str, Instances], offline_result: Inst
         on_only = [i for i in range(len(on)) if i not in used]
 
     sides = {"on": on, "off": off}
-    take = lambda attr, srcs: (torch.stack([getattr(sides[s], attr)[i] for s, i in srcs]) if srcs
-                               else getattr(off if len(off) else on, attr)[:0])
+    both = {attr: torch.cat([getattr(on, attr), getattr(off, attr)]) if len(on) and len(off) else getattr(on if len(on) else off, attr)
+            for attr in ("boxes", "classes", "scores", "probs")}
+    base = {"on": 0, "off": len(on) if len(on) and len(off) else 0}
+
+    def take(attr, srcs):  # rows of the two detection sets in the given order: one gather instead of a tensor index per row
+        if not srcs:
+            return getattr(off if len(off) else on, attr)[:0]
+        return both[attr][torch.tensor([base[s_] + i for s_, i in srcs], dtype=torch.long)]
 
     # ---- C: private boxes (offline-only first, then online-only)
     c_src = [("off", i) for i in off_only] + [("on", i) for i in on_only]
@@ -165,7 +181,8 @@ def match_dual_teacher(online_result: Dict[str, Instances], offline_result: Inst
         inst.gt_probs_online, inst.gt_probs_offline = take("probs", s_on)[sel], take("probs", s_off)[sel]
         return inst
 
-    cls_of = lambda src: int(sides[src[0]].classes[src[1]])
+    cls_list = {"on": on.classes.tolist(), "off": off.classes.tolist()}
+    cls_of = lambda src: cls_list[src[0]][src[1]]
     if tag == "RCNN":
         a = build([r for r in common if cls_of(r[0]) == cls_of(r[1])], False)
         b = build([r for r in common if cls_of(r[0]) != cls_of(r[1])], True)
