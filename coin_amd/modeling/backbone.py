@@ -180,6 +180,7 @@ class ModifiedResNet(nn.Module):
                 p.requires_grad = False
             return FrozenBatchNorm2d.convert(m)
 
+        self.freeze_at = max(int(freeze_at), int(getattr(self, "freeze_at", 0)))
         if freeze_at >= 1:
             for name in ("conv1", "bn1", "conv2", "bn2", "conv3", "bn3"):
                 setattr(self, name, fz(getattr(self, name)))
