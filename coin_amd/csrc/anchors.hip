@@ -120,8 +120,8 @@ __global__ __launch_bounds__(AM_THREADS) void anchor_low_quality_kernel(const fl
 // ------------------------------------------------------------------------------------------ subsampling
 // One workgroup per image.  cls[m]: -1 ignore, bg_label negative, anything else positive.  Chosen = the k_pos positives and k_neg
 // negatives with the smallest (key, index), k_pos = min(#pos, pos_cap), k_neg = min(#neg, num_samples - k_pos): the subsets
-// `rank < k` of an ascending stable sort by key selects (coin_amd/box_ops.py:sample_masks), found by a 4-pass radix select on the
-// key bits instead of sorting all M keys.  out[m] = 1 (chosen positive) / 0 (chosen negative) / -1.
+// `rank < k` of an ascending stable sort by key selects (coin_amd/box_ops.py:sample_masks), found by a 3-pass radix select on the
+// 24-bit keys instead of sorting all M keys.  out[m] = 1 (chosen positive) / 0 (chosen negative) / -1.
 constexpr int SS_THREADS = 1024;
 
 __device__ int block_sum(int v, int* scratch) {  // all threads get the sum
@@ -150,14 +150,24 @@ __device__ int block_excl_scan(int v, int* scratch) {
   return base + inc - v;
 }
 
+// keys are compared at torch.rand's own resolution: k24 = floor(key * 2^24) (exact for torch.rand's multiples of 2^-24); uniform
+// 24-bit integers give evenly filled radix bins, and each wave counts into its own LDS histogram (a shared histogram of raw float
+// bits serialised ~60 000 atomics on the few exponent bins: 0.79 ms per launch, measured)
+__device__ __forceinline__ unsigned key24(float k) {
+  const float v = k * 16777216.0f;
+  return v <= 0.f ? 0u : (v >= 16777215.0f ? 16777215u : (unsigned)v);
+}
+
 template <typename CLS>
 __global__ __launch_bounds__(SS_THREADS) void sample_labels_kernel(const CLS* __restrict__ cls, const float* __restrict__ keys, int M, int bg_label,
                                                                    int num_samples, int pos_cap, int8_t* __restrict__ out) {
+  __shared__ int whist[SS_THREADS / 64][256];
   __shared__ int hist[256];
   __shared__ int scratch[SS_THREADS / 64];
   __shared__ unsigned s_prefix;
   __shared__ int s_k;
   const int img = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const CLS* c = cls + (size_t)img * M;
   const float* ky = keys + (size_t)img * M;
   int8_t* o = out + (size_t)img * M;
@@ -189,19 +199,26 @@ __global__ __launch_bounds__(SS_THREADS) void sample_labels_kernel(const CLS* __
     // radix select: the k-th smallest key (1-based) among the members, most significant byte first
     unsigned prefix = 0, mask = 0;
     int kk = k;
-    for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int shift = 16; shift >= 0; shift -= 8) {
       __syncthreads();
-      if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+      for (int i = lane; i < 256; i += 64) whist[wave][i] = 0;
       __syncthreads();
       for (int m = m0; m < m1; ++m) {
         if (!member(m)) continue;
-        const unsigned u = __float_as_uint(ky[m]);
-        if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1);
+        const unsigned u = key24(ky[m]);
+        if ((u & mask) == prefix) atomicAdd(&whist[wave][(u >> shift) & 255u], 1);
+      }
+      __syncthreads();
+      if (threadIdx.x < 256) {
+        int t = 0;
+#pragma unroll
+        for (int w = 0; w < SS_THREADS / 64; ++w) t += whist[w][threadIdx.x];
+        hist[threadIdx.x] = t;
       }
       __syncthreads();
       if (threadIdx.x == 0) {
         int acc = 0, d = 0;
-        for (; d < 256; ++d) {
+        for (; d < 255; ++d) {
           if (acc + hist[d] >= kk) break;
           acc += hist[d];
         }
@@ -217,11 +234,11 @@ __global__ __launch_bounds__(SS_THREADS) void sample_labels_kernel(const CLS* __
     const unsigned T = prefix;
     int ties = 0;
     for (int m = m0; m < m1; ++m)
-      if (member(m) && __float_as_uint(ky[m]) == T) ++ties;
+      if (member(m) && key24(ky[m]) == T) ++ties;
     int rank = block_excl_scan(ties, scratch);
     for (int m = m0; m < m1; ++m) {
       if (!member(m)) continue;
-      const unsigned u = __float_as_uint(ky[m]);
+      const unsigned u = key24(ky[m]);
       if (u < T) o[m] = mark;
       else if (u == T) {
         if (rank < kk) o[m] = mark;

@@ -598,16 +598,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 // mean / rstd (+ running statistics) from the per-row-tile pivoted partials: tile t holds n_t = clamp(rows - 256 t, 0, 256) values
 // per channel as (pivot p, S1 = sum(x - p), S2 = sum((x - p)^2)) -> (mean_t, M2_t) -> Chan's pairwise update, in a fixed order.
+// Block = 16 channels x 64 tile lanes (thread = channel c16 + 16 * tile lane): a thread folds tiles lane, lane + 64, ... (a serial
+// chain of ~tiles/64 dependent updates; the [401 408, 512] res5 outputs have 1568 tiles), then one thread per channel folds the 64
+// partial results in lane order.  N/16 workgroups (32..128) instead of N/64: the launch was latency-bound at 8 workgroups.
 __global__ __launch_bounds__(1024) void conv_stats_finalize_kernel(const float* __restrict__ part, int tiles_m, int N, int64_t rows,
                                                                     float eps, float momentum, float* __restrict__ mean,
                                                                     float* __restrict__ rstd, float* __restrict__ running_mean,
                                                                     float* __restrict__ running_var) {
-  __shared__ float red[16][3][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
+  __shared__ float red[64][3][16];
+  const int c16 = threadIdx.x & 15, tl = threadIdx.x >> 4;  // tile lane 0..63
+  const int c = blockIdx.x * 16 + c16;
   float n_a = 0.f, mu_a = 0.f, m2_a = 0.f;
   if (c < N) {
-    for (int t = wave; t < tiles_m; t += 16) {
+    for (int t = tl; t < tiles_m; t += 64) {
       const int64_t left = rows - (int64_t)t * GM;
       const float n_b = (float)(left <= 0 ? 0 : (left < GM ? left : GM));
       if (n_b == 0.f) continue;
@@ -621,18 +624,18 @@ __global__ __launch_bounds__(1024) void conv_stats_finalize_kernel(const float* 
       n_a = n;
     }
   }
-  red[wave][0][lane] = n_a;
-  red[wave][1][lane] = mu_a;
-  red[wave][2][lane] = m2_a;
+  red[tl][0][c16] = n_a;
+  red[tl][1][c16] = mu_a;
+  red[tl][2][c16] = m2_a;
   __syncthreads();
-  if (wave != 0 || c >= N) return;
+  if (tl != 0 || c >= N) return;
   n_a = mu_a = m2_a = 0.f;
-  for (int w = 0; w < 16; ++w) {
-    const float n_b = red[w][0][lane];
+  for (int w = 0; w < 64; ++w) {
+    const float n_b = red[w][0][c16];
     if (n_b == 0.f) continue;
-    const float n = n_a + n_b, d = red[w][1][lane] - mu_a;
+    const float n = n_a + n_b, d = red[w][1][c16] - mu_a;
     mu_a += d * (n_b / n);
-    m2_a += red[w][2][lane] + d * d * (n_a * n_b / n);
+    m2_a += red[w][2][c16] + d * d * (n_a * n_b / n);
     n_a = n;
   }
   const float var = n_a > 0.f ? m2_a / n_a : 0.f;
@@ -716,7 +719,7 @@ extern "C" int coin_conv_gemm_stats_finalize(const float* partials, int M, int N
                                              float* rstd, float* running_mean, float* running_var, void* stream) {
   if (!partials || !mean || !rstd || M <= 0 || N <= 0 || rows <= 0 || rows > M) return COIN_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return COIN_EINVAL;
-  conv_stats_finalize_kernel<<<(N + 63) / 64, 1024, 0, (hipStream_t)stream>>>(partials, (M + GM - 1) / GM, N, rows, eps, momentum, mean, rstd,
+  conv_stats_finalize_kernel<<<(N + 15) / 16, 1024, 0, (hipStream_t)stream>>>(partials, (M + GM - 1) / GM, N, rows, eps, momentum, mean, rstd,
                                                                              running_mean, running_var);
   return coin_launch_status();
 }

@@ -287,7 +287,7 @@ int coin_nms_batched(const float* boxes, const int* counts, int B, int n_max, fl
  *
  * coin_sample_labels: per image the k_pos = min(#pos, pos_cap) positives and k_neg = min(#neg, num_samples - k_pos)
  *   negatives with the smallest random key (ties: lowest index) -- the subsets an ascending stable sort by key would rank
- *   first, found by a radix select.  cls [num_images, M] int8 or int64: -1 ignore, bg_label negative, else positive;
+ *   first, found by a radix select.  Keys are compared as floor(key * 2^24) (torch.rand's resolution; keys in [0, 1)).  cls [num_images, M] int8 or int64: -1 ignore, bg_label negative, else positive;
  *   keys [num_images, M] float32 >= 0;  out [num_images, M] int8 = 1 (chosen positive) / 0 (chosen negative) / -1.
  * ---------------------------------------------------------------------------------------- */
 int coin_anchor_match(const float* gt_boxes, const int* gt_offsets_host, int num_images, const float* anchors, int A,

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--step-two", action="store_true")
     ap.add_argument("--config", default="foggy", choices=["foggy", "bdd100k_rn101"])
     ap.add_argument("--sync-free-step", action="store_true", help="cfg.AMD.SYNC_FREE_STEP: fixed-shape samplers + packed losses in the step branches")
+    ap.add_argument("--no-teacher-stream", action="store_true", help="cfg.AMD.TEACHER_STREAM off: teacher pass on the main stream (A/B measurement)")
     args = ap.parse_args()
     import torch
 
@@ -36,7 +37,7 @@ def main():
     cfg.merge_from_file(os.path.join(ROOT, "configs", "coin", "GDINO", "foggy_synthetic.yaml" if args.config == "foggy" else "bdd100k_rn101_synthetic.yaml"))
     cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", args.images, "AMD.SYNTHETIC.NUM_IMAGES", args.images, "AMD.TEXT_TEMPLATES", 4,
                          "MODEL.DEVICE", "cuda:0", "CLOUD.BURN_UP_STEP", 0 if args.step_two else 10 ** 9, "CLOUD.PROTOTYPE_UPDATE_START", 0,
-                         "AMD.SYNC_FREE_STEP", args.sync_free_step])
+                         "AMD.SYNC_FREE_STEP", args.sync_free_step, "AMD.TEACHER_STREAM", not args.no_teacher_stream])
     torch.manual_seed(cfg.SEED)
     tr = CoinTrainer(cfg)
     real_forward, g = tr.offline_teacher.forward, torch.Generator().manual_seed(7)
@@ -57,7 +58,7 @@ def main():
         tr.prepare_next()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    print(json.dumps({"config": args.config, "workload": "targetDET " + ("step_two" if args.step_two else "step_one") + (" sync-free" if args.sync_free_step else ""), "images_per_step": args.images, "ms_per_step": dt * 1e3,
+    print(json.dumps({"config": args.config, "workload": "targetDET " + ("step_two" if args.step_two else "step_one") + (" sync-free" if args.sync_free_step else "") + (" (teacher on the main stream)" if args.no_teacher_stream else ""), "images_per_step": args.images, "ms_per_step": dt * 1e3,
                       "student_views_per_s": args.images / dt, "losses": {k: round(float(v), 4) for k, v in rec.items()}}))
 
 
