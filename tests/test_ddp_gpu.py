@@ -25,6 +25,7 @@ cfg = get_cfg()
 cfg.merge_from_file(os.path.join({root!r}, "configs", "coin", "PRETRAINS", "CLIPDET_synthetic.yaml"))
 cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", 1, "AMD.SYNTHETIC.NUM_IMAGES", 1, "AMD.SYNTHETIC.HEIGHT", 384, "AMD.SYNTHETIC.WIDTH", 640,
                      "AMD.TEXT_TEMPLATES", 2, "MODEL.DEVICE", "cuda:0", "AMD.COMPUTE_DTYPE", "fp32"])
+torch.backends.cudnn.deterministic = True   # ask the convolution library for its reproducible algorithms where it has them
 torch.manual_seed(5)
 tr = PRETrainer(cfg)
 assert (tr.reducer is not None) == force
@@ -52,9 +53,14 @@ def _run(force):
 
 
 def test_one_rank_rccl_reducer_reproduces_the_plain_run():
-    plain, reduced = _run(False), _run(True)
-    for a, b in zip(plain, reduced):
+    """The bound is calibrated by a second plain run: the library convolutions are not bit-reproducible run to run (measured with
+    tools/determinism_probe.py: two forwards from one seed in one process give RPN outputs that differ in the last bits, and a
+    proposal whose IoU crosses 0.5 then changes one of the 1024 sampled labels: |d loss_cls| ~ 5e-4).  The reducer run must stay
+    within 3x the plain-vs-plain spread (or 1e-5 where the plain runs agree)."""
+    plain, again, reduced = _run(False), _run(False), _run(True)
+    for a, a2, b in zip(plain, again, reduced):
         assert set(a) == set(b)
         for k in a:
-            assert abs(a[k] - b[k]) <= 1e-5 * max(1.0, abs(a[k])), (k, a[k], b[k])
+            tol = max(1e-5 * max(1.0, abs(a[k])), 3.0 * abs(a[k] - a2[k]))
+            assert abs(a[k] - b[k]) <= tol and abs(a2[k] - b[k]) <= tol + abs(a[k] - a2[k]), (k, a[k], a2[k], b[k])
     assert plain[0] != plain[2]  # the steps did train
