@@ -35,9 +35,26 @@ with torch.no_grad():
             p.fill_(0.5)
 torch.manual_seed(6)
 out = []
+if force:  # exact check of the collective path: what autograd produced == what the optimizer reads from the arena after the all-reduce
+    stash = {{}}
+    for n, p in tr.model.named_parameters():
+        if p.requires_grad:
+            p.register_hook(lambda g, n=n: stash.__setitem__(n, g.detach().float().clone()))
+    real_step, checked = tr.optimizer.step, []
+    def step(*a, **k):
+        if not checked:
+            torch.cuda.synchronize()
+            for n, p in tr.model.named_parameters():
+                if n in stash:
+                    assert torch.equal(p.grad.float(), stash[n]), "arena gradient of " + n + " differs from autograd's"
+            checked.append(len(stash))
+        return real_step(*a, **k)
+    tr.optimizer.step = step
 for _ in range(3):
     rec = tr.run_step()
     out.append({{k: float(v) for k, v in rec.items()}})
+if force:
+    assert checked and checked[0] > 100, checked
 if force:
     assert all(p.grad is not None and any(p.grad.data_ptr() == v.data_ptr() for s in tr.reducer.slices for v in s.views) for p in tr.optimizer.params)
     dist.destroy_process_group()
