@@ -181,8 +181,9 @@ class OpenVocabularyRCNN(nn.Module):
                 proposals, proposal_losses = self.proposal_generator(images, features, rpn, branch=branch)
             else:
                 proposals, proposal_losses = [x["proposals"].to(dev) for x in batched_inputs], {}
-            _, detector_losses = self.roi_heads(images, features, proposals, self.backbone.layer4, self.backbone.attnpool, branch=branch,
-                                                merge_module=merge_module, targets=rcnn, update_prototype=update_prototype)
+            with self.roi_heads.box_predictor.shared_text():  # step branches classify twice per forward: one text-encoder pass
+                _, detector_losses = self.roi_heads(images, features, proposals, self.backbone.layer4, self.backbone.attnpool, branch=branch,
+                                                    merge_module=merge_module, targets=rcnn, update_prototype=update_prototype)
         losses = {}
         losses.update(detector_losses)
         losses.update(proposal_losses)
