@@ -610,18 +610,29 @@ __global__ __launch_bounds__(1024) void conv_stats_finalize_kernel(const float* 
   const int c = blockIdx.x * 16 + c16;
   float n_a = 0.f, mu_a = 0.f, m2_a = 0.f;
   if (c < N) {
-    for (int t = tl; t < tiles_m; t += 64) {
-      const int64_t left = rows - (int64_t)t * GM;
-      const float n_b = (float)(left <= 0 ? 0 : (left < GM ? left : GM));
-      if (n_b == 0.f) continue;
-      const float* __restrict__ p = part + (size_t)t * 3 * N + c;
-      const float s1 = p[N], s2 = p[2 * (size_t)N];
-      const float mu_b = p[0] + s1 / n_b;
-      const float m2_b = fmaxf(s2 - s1 * s1 / n_b, 0.f);
-      const float n = n_a + n_b, d = mu_b - mu_a;
-      mu_a += d * (n_b / n);
-      m2_a += m2_b + d * d * (n_a * n_b / n);
-      n_a = n;
+    for (int t0 = tl; t0 < tiles_m; t0 += 64 * 4) {  // 4 tiles per round: their 12 loads are in flight together (the chain is latency-bound)
+      float pv[4], s1[4], s2[4], nb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + 64 * u;
+        const int64_t left = rows - (int64_t)t * GM;
+        nb[u] = t < tiles_m ? (float)(left <= 0 ? 0 : (left < GM ? left : GM)) : 0.f;
+        const float* __restrict__ p = part + (size_t)(t < tiles_m ? t : 0) * 3 * N + c;
+        pv[u] = p[0];
+        s1[u] = p[N];
+        s2[u] = p[2 * (size_t)N];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float n_b = nb[u];
+        if (n_b == 0.f) continue;
+        const float mu_b = pv[u] + s1[u] / n_b;
+        const float m2_b = fmaxf(s2[u] - s1[u] * s1[u] / n_b, 0.f);
+        const float n = n_a + n_b, d = mu_b - mu_a;
+        mu_a += d * (n_b / n);
+        m2_a += m2_b + d * d * (n_a * n_b / n);
+        n_a = n;
+      }
     }
   }
   red[tl][0][c16] = n_a;

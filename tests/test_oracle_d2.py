@@ -1,8 +1,9 @@
 """Known-answer tests for oracle/d2.py (the restated detectron2 / torchvision / fvcore arithmetic).
 
 The reference vendors none of these libraries and holds no test for them, so each function is pinned
-here against values worked out BY HAND from the libraries' documented behaviour.  The expected numbers below are
-literals with their derivation in the comment next to them, never the output of the code under test.
+here against values worked out BY HAND from the libraries' documented behaviour, plus the known answers the upstream
+projects publish in their own test suites (`*_upstream_published_values`).  The expected numbers below are literals with
+their derivation or source in the comment next to them, never the output of the code under test.
 """
 import math
 
@@ -163,6 +164,29 @@ def test_roi_align_hand_computed_4x4():
     # y in {0, 1 | 2, 3}; means: bin(0,0) = 4*0.5 + 0.5 = 2.5 ; bin(0,1) = 2 + 2.5 = 4.5 ; bin(1,0) = 10.5 ; bin(1,1) = 12.5
     out = d2.roi_align_forward_np(feat, np.array([[0, 0.0, 0.0, 4.0, 4.0]]), (2, 2), 1.0, 0, True)
     np.testing.assert_allclose(out[0, 0], [[2.5, 4.5], [10.5, 12.5]], rtol=0, atol=1e-12)
+
+
+def test_roi_align_upstream_published_values():
+    """The known answers detectron2 itself tests its ROIAlign against (detectron2 v0.5, tests/layers/test_roi_align.py,
+    `ROIAlignTest.test_forward_output`): a 5x5 ramp, box (1,1,3,3), 4x4 output, with and without the half-pixel correction.
+    These literals come from the upstream project's test, not from this repository."""
+    feat = np.arange(25, dtype=np.float32).reshape(1, 1, 5, 5)
+    rois = np.array([[0, 1.0, 1.0, 3.0, 3.0]], dtype=np.float32)
+    old_results = [[7.5, 8, 8.5, 9], [10, 10.5, 11, 11.5], [12.5, 13, 13.5, 14], [15, 15.5, 16, 16.5]]               # aligned=False
+    correct_results = [[4.5, 5.0, 5.5, 6.0], [7.0, 7.5, 8.0, 8.5], [9.5, 10.0, 10.5, 11.0], [12.0, 12.5, 13.0, 13.5]]  # aligned=True
+    np.testing.assert_allclose(d2.roi_align_forward_np(feat, rois, (4, 4), 1.0, 0, False)[0, 0], old_results, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(d2.roi_align_forward_np(feat, rois, (4, 4), 1.0, 0, True)[0, 0], correct_results, rtol=0, atol=1e-6)
+    got = d2.roi_align_torch(torch.from_numpy(feat), torch.from_numpy(rois), (4, 4), 1.0, 0, True)
+    np.testing.assert_allclose(got[0, 0].numpy(), correct_results, rtol=0, atol=1e-6)
+
+
+def test_matcher_upstream_published_values():
+    """detectron2 v0.5 tests/modeling/test_matcher.py: RPN thresholds [0.3, 0.7], labels [0, -1, 1], low-quality matches on."""
+    m = d2.Matcher([0.3, 0.7], [0, -1, 1], allow_low_quality_matches=True)
+    q = torch.tensor([[0.15, 0.45, 0.2, 0.6], [0.3, 0.65, 0.05, 0.1], [0.05, 0.4, 0.25, 0.4]])
+    matches, labels = m(q)
+    assert matches.tolist() == [1, 1, 2, 0]
+    assert labels.tolist() == [-1, 1, 0, 1]
 
 
 def test_roi_align_border_rules():
