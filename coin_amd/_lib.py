@@ -51,6 +51,9 @@ SIGNATURES = {
     "coin_conv_wgrad_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "coin_anchor_match": [_P, _P, _I, _P, _I, _F, _F, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "coin_sample_labels": [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P],
+    "coin_aug_resize_bilinear_u8": [_P, _I, _I, _P, _I, _I, _I, _P, _P],
+    "coin_aug_point_op_u8": [_P, _P, _I, _I, _I, _F, _I, _P, _I, _P],
+    "coin_aug_gaussian_blur_u8": [_P, _P, _I, _I, _F, _P, _P],
     "coin_transpose2d": [_P, _P, _I, _I, _I, _P],
     "coin_bias_act_bwd": [_P, _P, _P, _I, _I, _I, _P, _I, _F, _I, _P],
     "coin_cosine_logits_fwd": [_P, _I, _P, _I, _I, _I, _F, _P, _P, _I, _P],

@@ -561,6 +561,46 @@ def sample_labels(cls: torch.Tensor, keys: torch.Tensor, bg_label: int, num_samp
     return out
 
 
+# --------------------------------------------------------------------------- two-view input augmentation (uint8 [H, W, 3] images)
+AUG_COPY, AUG_BRIGHTNESS, AUG_CONTRAST, AUG_SATURATION, AUG_HUE, AUG_GRAYSCALE, AUG_SOLARIZE = range(7)
+
+
+def _u8img(t: torch.Tensor, name: str) -> Tuple[int, int]:
+    _dev(t)
+    if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3 or not t.is_contiguous():
+        raise CoinHipError(f"{name} must be a contiguous uint8 [H, W, 3] image")
+    return int(t.shape[0]), int(t.shape[1])
+
+
+def aug_resize_bilinear(img: torch.Tensor, out_h: int, out_w: int, flip_h: bool = False) -> torch.Tensor:
+    """PIL `Image.resize((out_w, out_h), BILINEAR)` (+ `np.flip(axis=1)` when flip_h) of a uint8 [H, W, 3] device image, bit-exact."""
+    h, w = _u8img(img, "img")
+    out = torch.empty((out_h, out_w, 3), dtype=torch.uint8, device=img.device)
+    tmp = torch.empty((h, out_w, 3), dtype=torch.uint8, device=img.device) if (out_h != h and out_w != w) else None
+    check(_lib.lib().coin_aug_resize_bilinear_u8(_p(img), h, w, _p(out), int(out_h), int(out_w), int(bool(flip_h)), _p(tmp), _stream()),
+          "coin_aug_resize_bilinear_u8")
+    return out
+
+
+def aug_point_op(img: torch.Tensor, op: int, fparam: float = 0.0, iparam: int = 0, out_chw: bool = False) -> torch.Tensor:
+    """One COIN_AUG_* point operation (Pillow ImageEnhance / HSV hue shift / convert("L") / solarize arithmetic, bit-exact).
+    out_chw: the result is [3, H, W] (what coin_normalize_pad reads) instead of [H, W, 3]."""
+    h, w = _u8img(img, "img")
+    out = torch.empty((3, h, w) if out_chw else (h, w, 3), dtype=torch.uint8, device=img.device)
+    ws = torch.empty(2, dtype=torch.int64, device=img.device) if op == AUG_CONTRAST else None
+    check(_lib.lib().coin_aug_point_op_u8(_p(img), _p(out), h, w, int(op), float(fparam), int(iparam), _p(ws), int(bool(out_chw)), _stream()),
+          "coin_aug_point_op_u8")
+    return out
+
+
+def aug_gaussian_blur(img: torch.Tensor, radius: float) -> torch.Tensor:
+    """PIL `ImageFilter.GaussianBlur(radius)` (3 + 3 extended box blurs in 8.24 fixed point), bit-exact."""
+    h, w = _u8img(img, "img")
+    out, tmp = torch.empty_like(img), torch.empty_like(img)
+    check(_lib.lib().coin_aug_gaussian_blur_u8(_p(img), _p(out), h, w, float(radius), _p(tmp), _stream()), "coin_aug_gaussian_blur_u8")
+    return out
+
+
 # --------------------------------------------------------------------------- streams of bytes
 def normalize_pad(images: Sequence[torch.Tensor], mean: Sequence[float], std: Sequence[float],
                   size_divisibility: int = 0, layout: int = COIN_NCHW, dtype: torch.dtype = torch.float32):

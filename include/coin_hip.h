@@ -298,6 +298,33 @@ int coin_sample_labels(const void* cls, int cls_is_int64, const float* keys, int
                        int num_samples, int pos_cap, int8_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Two-view input augmentation on the device  (replaces the Pillow calls under DatasetMapperUnsupervised.__call__,
+ *   coin/data/dataset_mapper.py:363-450: detectron2 ResizeShortestEdge / RandomFlip -> PIL.Image.resize(BILINEAR), np.flip;
+ *   coin/data/detection_utils.py:22-45 strong augmentation: torchvision ColorJitter / RandomGrayscale on PIL images ->
+ *   ImageEnhance.{Brightness,Contrast,Color}, HSV round trip, convert("L");  coin/data/transforms/augmentation_impl.py:64-92:
+ *   ImageFilter.GaussianBlur, ImageOps.solarize)
+ * Images are uint8 [H, W, 3] RGB interleaved in device memory.  Byte / integer work: every result is BIT-EXACT with Pillow
+ * (restated and pinned against Pillow 12.2 in oracle/augment.py).
+ * coin_aug_resize_bilinear_u8: Image.resize((out_w, out_h), BILINEAR) (+ horizontal flip of the result when flip_h);
+ *   tmp: H * out_w * 3 bytes, needed when both sizes change.
+ * coin_aug_point_op_u8: one of the COIN_AUG_* point operations; fparam = enhancement factor (brightness / contrast /
+ *   saturation), iparam = hue shift in [0, 255] (= uint8(hue_factor * 255)) or the solarize threshold; contrast needs 16 bytes
+ *   of 8-byte aligned device workspace (the image's mean luma is reduced on the device, no host round trip);
+ *   out_chw != 0 writes [3, H, W] planes (the layout coin_normalize_pad reads) instead of interleaved pixels.
+ * coin_aug_gaussian_blur_u8: ImageFilter.GaussianBlur(radius) = 3 horizontal + 3 vertical extended box blurs;
+ *   tmp: H * W * 3 bytes; src != dst.
+ * ---------------------------------------------------------------------------------------- */
+typedef enum {
+  COIN_AUG_COPY = 0, COIN_AUG_BRIGHTNESS = 1, COIN_AUG_CONTRAST = 2, COIN_AUG_SATURATION = 3, COIN_AUG_HUE = 4,
+  COIN_AUG_GRAYSCALE = 5, COIN_AUG_SOLARIZE = 6
+} coin_aug_op;
+int coin_aug_resize_bilinear_u8(const uint8_t* src, int H, int W, uint8_t* dst, int out_h, int out_w, int flip_h,
+                                uint8_t* tmp, void* stream);
+int coin_aug_point_op_u8(const uint8_t* src, uint8_t* dst, int H, int W, int op, float fparam, int iparam,
+                         void* workspace, int out_chw, void* stream);
+int coin_aug_gaussian_blur_u8(const uint8_t* src, uint8_t* dst, int H, int W, float radius, uint8_t* tmp, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Input normalisation  (replaces OpenVocabularyRCNN.preprocess_image, clip_rcnn.py:287-298:
  *                       ToTensor + Normalize + ImageList.from_tensors zero padding)
  * img   : [3,h,w] uint8 (CHW, as the dataset mapper emits); mean/std_ are HOST arrays of 3 floats

@@ -1,0 +1,61 @@
+"""Host logic of the two-view input pipeline: the random decisions, annotations and batching of
+coin_amd/data/dataset_mapper.py against the oracle's restatement (oracle/augment.py) -- no GPU needed; the pixels are
+tests/test_input_pipeline_gpu.py."""
+import random
+
+import numpy as np
+import torch
+
+from coin_amd.config import get_cfg
+from coin_amd.data import AspectRatioGroupedDatasetTwoCrop, DatasetMapperUnsupervised
+from coin_amd.data.dataset_mapper import shortest_edge_size
+from oracle import augment as A
+
+
+def _cfg(**kw):
+    cfg = get_cfg()
+    cfg.merge_from_list(["INPUT.MIN_SIZE_TRAIN", (600,), "INPUT.MAX_SIZE_TRAIN", 1333, "INPUT.FORMAT", "RGB", "MODEL.DEVICE", "cpu"] +
+                        [x for k, v in kw.items() for x in (k, v)])
+    return cfg
+
+
+def test_draws_follow_the_oracles_order_on_the_same_generators():
+    m = DatasetMapperUnsupervised(_cfg(), np_rng=np.random.RandomState(11), torch_generator=torch.Generator().manual_seed(11), py_rng=random.Random(11))
+    np_rng, gen, py = np.random.RandomState(11), torch.Generator().manual_seed(11), random.Random(11)
+    names = set()
+    for i in range(40):
+        h, w = (375, 500) if i % 2 else (1024, 2048)
+        got = m.draw_params(h, w)
+        ref = A.draw_view_params(h, w, (600,), 1333, "choice", 0.5, np_rng, gen, py)
+        assert got["size"] == ref["size"] and got["flip"] == ref["flip"]
+        assert got["strong_ops"] == ref["strong_ops"]
+        names |= {n for n, _ in got["strong_ops"]}
+    assert names == {"brightness", "contrast", "saturation", "hue", "grayscale", "blur", "solarize"}
+
+
+def test_range_sampling_and_size_rule():
+    m = DatasetMapperUnsupervised(_cfg(**{"INPUT.MIN_SIZE_TRAIN": (480, 800), "INPUT.MIN_SIZE_TRAIN_SAMPLING": "range"}), np_rng=np.random.RandomState(0),
+                                  torch_generator=torch.Generator().manual_seed(0), py_rng=random.Random(0))
+    sizes = {m.draw_params(375, 500)["size"][0] for _ in range(200)}
+    assert min(sizes) >= 480 and max(sizes) <= 800 and len(sizes) > 50
+    assert shortest_edge_size(375, 500, 600, 1333) == (600, 800) and shortest_edge_size(300, 1000, 600, 1333) == (400, 1333)
+
+
+def test_annotations_follow_resize_and_flip():
+    # 100x200 image -> 300x600 (scale 3); box (10, 20, 50, 60) -> (30, 60, 150, 180); flipped: x -> 600 - x: (450, 60, 570, 180)
+    annos = [{"bbox": [10.0, 20.0, 50.0, 60.0], "category_id": 3}, {"bbox": [0.0, 0.0, 0.0, 5.0], "category_id": 1},
+             {"bbox": [150.0, 90.0, 260.0, 140.0], "category_id": 2}, {"bbox": [1.0, 1.0, 9.0, 9.0], "category_id": 0, "iscrowd": 1}]
+    inst = DatasetMapperUnsupervised.transform_annotations(annos, 100, 200, {"size": (300, 600), "flip": False})
+    assert inst.gt_boxes.tensor.tolist() == [[30.0, 60.0, 150.0, 180.0], [450.0, 270.0, 600.0, 300.0]] and inst.gt_classes.tolist() == [3, 2]
+    inst = DatasetMapperUnsupervised.transform_annotations(annos, 100, 200, {"size": (300, 600), "flip": True})
+    assert inst.gt_boxes.tensor.tolist() == [[450.0, 60.0, 570.0, 180.0], [0.0, 270.0, 150.0, 300.0]]
+    assert inst.image_size == (300, 600)
+
+
+def test_two_crop_batches_by_aspect_ratio_group():
+    wide = lambda i: ({"width": 20, "height": 10, "id": i}, {"width": 20, "height": 10, "id": -i})
+    tall = lambda i: ({"width": 10, "height": 20, "id": i}, {"width": 10, "height": 20, "id": -i})
+    stream = [wide(1), tall(2), wide(3), tall(4), tall(5), wide(6), wide(7)]
+    out = list(AspectRatioGroupedDatasetTwoCrop(stream, 2))
+    assert [[d["id"] for d in s] for s, _ in out] == [[1, 3], [2, 4], [6, 7]]
+    assert [[d["id"] for d in w] for _, w in out] == [[-1, -3], [-2, -4], [-6, -7]]
