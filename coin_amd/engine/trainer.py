@@ -161,6 +161,9 @@ class CoinTrainer(BASE_Trainer):
             strong, dual_teacher_instances = self._pending
             self._pending = None
         if self._teacher_stream is not None:
+            # the teacher stream's EMA read the student's weights: nothing queued from here on (this step's optimizer in particular)
+            # may overtake it.  By now its work is finished in practice (the host waited for the detections), so this costs nothing.
+            torch.cuda.current_stream(self.device).wait_stream(self._teacher_stream)
             dual_teacher_instances = self._targets_to_device(dual_teacher_instances)
         start = cfg.CLOUD.PROTOTYPE_UPDATE_START
         update_prototype = start != -1 and self.iter >= start

@@ -12,6 +12,7 @@ The CKG terms (`loss_merge_*`) stay torch-composite: they are tens of rows and n
 from __future__ import annotations
 
 import contextlib
+import os
 
 from typing import Dict, List, Tuple
 
@@ -219,7 +220,7 @@ class FastRCNNOutputLayers(nn.Module):
         its weights do not change inside a forward, so both calls see the same embeddings.  Inside this scope the second call
         reuses the first one's tensor: same values, and the prompt vectors receive the sum of both gradients through ONE backward
         pass of the encoder (≈800 small launches fewer per step)."""
-        self._share_text, self._text_shared = True, None
+        self._share_text, self._text_shared = os.environ.get("COIN_SHARED_TEXT", "1") != "0", None   # env: A/B measurements only
         try:
             yield
         finally:
