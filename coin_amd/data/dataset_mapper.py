@@ -152,7 +152,7 @@ class DatasetMapperUnsupervised:
         d.setdefault("height", h)
         params = self.draw_params(h, w)
         d["random_flip"] = "horizontal" if params["flip"] else "no"
-        dev_img = torch.from_numpy(np.ascontiguousarray(img)).to(self.device, non_blocking=True)
+        dev_img = torch.from_numpy(np.array(img, dtype=np.uint8, order="C")).to(self.device, non_blocking=True)   # own, writable copy (PIL hands out read-only views)
         weak = self.weak_view(dev_img, params)
         if not self.is_train:
             d.pop("annotations", None)

@@ -122,7 +122,7 @@ class CoinTrainer(BASE_Trainer):
         cfg, burn = self.cfg, self.cfg.CLOUD.BURN_UP_STEP
         ema_due = self.iter >= burn and (self.iter - burn) % cfg.CLOUD.OFFLINE_TEACHER_UPDATE_ITER == 0
         side = None
-        if self.device.type == "cuda" and cfg.AMD.TEACHER_STREAM:
+        if self.device.type == "cuda" and getattr(getattr(cfg, "AMD", None), "TEACHER_STREAM", True):
             if self._teacher_stream is None:
                 self._teacher_stream = torch.cuda.Stream(device=self.device)
                 ema_due_or_first = True
