@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import contextlib
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -163,6 +164,30 @@ def _sample_labels(cls, keys, bg_label, num_samples, pos_cap):
     return torch.where(chosen_pos, 1, torch.where(chosen_neg, 0, -1)).to(torch.int8)
 
 
+def _aug_resize(img, out_h, out_w, flip_h=False):
+    from oracle import augment as A
+
+    out = A.resize_bilinear(img.numpy(), out_h, out_w)
+    return torch.from_numpy(A.hflip(out) if flip_h else out)
+
+
+def _aug_point(img, op, fparam=0.0, iparam=0, out_chw=False):
+    from oracle import augment as A
+
+    a = img.numpy()
+    out = {0: lambda: a, 1: lambda: A.adjust_brightness(a, fparam), 2: lambda: A.adjust_contrast(a, fparam), 3: lambda: A.adjust_saturation(a, fparam),
+           4: lambda: A.hsv_to_rgb(np.concatenate([((A.rgb_to_hsv(a)[..., :1].astype(np.int32) + iparam) % 256).astype(np.uint8), A.rgb_to_hsv(a)[..., 1:]], -1)),
+           5: lambda: A.rgb_to_grayscale3(a), 6: lambda: A.solarize(a, iparam)}[op]()
+    out = np.ascontiguousarray(out.transpose(2, 0, 1)) if out_chw else np.ascontiguousarray(out)
+    return torch.from_numpy(out.copy())
+
+
+def _aug_blur(img, radius):
+    from oracle import augment as A
+
+    return torch.from_numpy(np.ascontiguousarray(A.gaussian_blur(img.numpy(), radius)))
+
+
 class _CpuSgdTable:
     def __init__(self, params, lrs, wds, shadows=None):
         self.params, self.lrs, self.wds = list(params), list(lrs), list(wds)
@@ -200,7 +225,7 @@ def cpu_kernels():
                 kl_div_from_probs=_kl_probs, kl_div_binary=_kl_binary, box_reg_l1=_box_reg, l1_mean=lambda a, b: F.l1_loss(a, b),
                 rpn_losses=_rpn_losses, roi_align=_roi_align, bn_act=_bn_act, avg_pool2=lambda x: F.avg_pool2d(x, 2)),
         K: dict(normalize_pad=_normalize_pad, nms_batched=_nms_batched, SgdTable=_CpuSgdTable, EmaTable=_CpuEmaTable, anchor_match=_anchor_match,
-                sample_labels=_sample_labels),
+                sample_labels=_sample_labels, aug_resize_bilinear=_aug_resize, aug_point_op=_aug_point, aug_gaussian_blur=_aug_blur),
     }
     saved = {mod: {k: getattr(mod, k) for k in d} for mod, d in patches.items()}
     try:

@@ -59,3 +59,46 @@ def test_two_crop_batches_by_aspect_ratio_group():
     out = list(AspectRatioGroupedDatasetTwoCrop(stream, 2))
     assert [[d["id"] for d in s] for s, _ in out] == [[1, 3], [2, 4], [6, 7]]
     assert [[d["id"] for d in w] for _, w in out] == [[-1, -3], [-2, -4], [-6, -7]]
+
+
+def test_training_sampler_shards_one_shuffled_stream():
+    from coin_amd.data import TrainingSampler
+    import itertools
+
+    full = list(itertools.islice(iter(TrainingSampler(5, seed=3)), 20))
+    assert sorted(full[:5]) == sorted(full[5:10]) == [0, 1, 2, 3, 4] and full[:5] != full[5:10]       # permutations, reshuffled each epoch
+    r0 = list(itertools.islice(iter(TrainingSampler(5, seed=3, rank=0, world_size=2)), 10))
+    r1 = list(itertools.islice(iter(TrainingSampler(5, seed=3, rank=1, world_size=2)), 10))
+    assert r0 == full[0::2] and r1 == full[1::2]
+
+
+def test_loader_end_to_end_from_files_with_decode_threads(tmp_path):
+    """VOC-style files -> dataset dicts -> sampler -> mapper (kernels shimmed by the oracle on the CPU) -> two-crop batches; the result does
+    not depend on the number of decode threads."""
+    from PIL import Image
+
+    from cpu_shim import cpu_kernels
+    from coin_amd.data import build_detection_unsupervised_train_loader
+
+    dicts = []
+    for i, (h, w) in enumerate([(60, 90), (90, 60), (64, 96), (50, 100), (100, 50)]):
+        a = np.random.default_rng(i).integers(0, 256, (h, w, 3), dtype=np.uint8)
+        Image.fromarray(a, "RGB").save(tmp_path / f"{i}.png")
+        dicts.append({"file_name": str(tmp_path / f"{i}.png"), "image_id": str(i), "height": h, "width": w})
+    outs = []
+    for workers in (0, 3):
+        cfg = _cfg(**{"INPUT.MIN_SIZE_TRAIN": (48,), "INPUT.MAX_SIZE_TRAIN": 80, "SOLVER.IMG_PER_BATCH_UNLABEL": 2, "DATALOADER.NUM_WORKERS": workers, "SEED": 7})
+        m = DatasetMapperUnsupervised(cfg, np_rng=np.random.RandomState(2), torch_generator=torch.Generator().manual_seed(2), py_rng=random.Random(2))
+        with cpu_kernels():
+            it = iter(build_detection_unsupervised_train_loader(cfg, dicts, mapper=m))
+            batches = [next(it) for _ in range(4)]
+        outs.append(batches)
+        for strong, weak in batches:
+            assert len(strong) == len(weak) == 2
+            assert len({d["width"] > d["height"] for d in strong}) == 1                      # one aspect-ratio group per batch
+            for s, w_ in zip(strong, weak):
+                assert s["image_id"] == w_["image_id"] and s["image"].shape == w_["image"].shape and s["image"].dtype == torch.uint8
+                assert min(s["image"].shape[1:]) <= 48 and max(s["image"].shape[1:]) <= 80
+    for (s0, w0), (s1, w1) in zip(*outs):
+        assert [d["image_id"] for d in s0] == [d["image_id"] for d in s1]
+        assert all(torch.equal(a["image"], b["image"]) for a, b in zip(s0 + w0, s1 + w1))

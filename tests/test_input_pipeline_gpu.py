@@ -113,3 +113,37 @@ def test_mapper_reads_a_file_and_feeds_the_detector_preprocessing(tmp_path):
     torch.testing.assert_close(batch[1].permute(2, 0, 1), ref, rtol=1e-6, atol=1e-6)
     with pytest.raises(ValueError):
         m({"file_name": str(tmp_path / "x.png"), "image_id": "x", "height": 121, "width": 160})
+
+
+def test_pretrainer_trains_from_image_files_through_the_gpu_mapper(tmp_path):
+    """The whole row (f)-3 in place: PNG files -> dataset dicts -> TrainingSampler -> decode threads -> two views on the GPU -> two-crop
+    batches -> PRETrainer.run_step with the cached teacher boxes mirrored / rescaled by `random_flip` and the view size (base.py:80-126)."""
+    from PIL import Image
+
+    from coin_amd.config import get_cfg
+    from coin_amd.data import build_detection_unsupervised_train_loader
+    from coin_amd.data.synthetic import SyntheticTeacherCache, synthetic_teacher_result
+    from coin_amd.engine import PRETrainer
+    import os
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "coin", "PRETRAINS", "CLIPDET_synthetic.yaml")
+    cfg = get_cfg()
+    cfg.merge_from_file(root)
+    cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", 2, "AMD.SYNTHETIC.ENABLED", False, "AMD.TEXT_TEMPLATES", 2, "MODEL.DEVICE", "cuda:0",
+                         "INPUT.MIN_SIZE_TRAIN", (256,), "INPUT.MAX_SIZE_TRAIN", 448, "INPUT.FORMAT", "RGB", "DATALOADER.NUM_WORKERS", 2, "SEED", 3])
+    g = torch.Generator().manual_seed(0)
+    cache, dicts = SyntheticTeacherCache(), []
+    for i, (h, w) in enumerate([(300, 500), (320, 480), (375, 500), (333, 500)]):
+        a = _img(40 + i, h, w)
+        fn = str(tmp_path / f"{i:06d}.png")
+        Image.fromarray(a, "RGB").save(fn)
+        dicts.append({"file_name": fn, "image_id": f"{i:06d}", "height": h, "width": w})
+        cache.add(synthetic_teacher_result(fn, f"{i:06d}", h, w, 12, len(cfg.AMD.CLASS_NAMES), g))
+    torch.manual_seed(3)
+    np.random.seed(3)
+    random.seed(3)
+    loader = build_detection_unsupervised_train_loader(cfg, dicts)
+    tr = PRETrainer(cfg, data_loader=loader, collect_model=cache)
+    recs = [{k: float(v) for k, v in tr.run_step().items()} for _ in range(3)]
+    assert all(np.isfinite(v) for r in recs for v in r.values()), recs
+    assert recs[0] != recs[2]
