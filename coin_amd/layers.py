@@ -5,6 +5,7 @@ Reference call sites are cited per class (paths under /root/reference).
 """
 from __future__ import annotations
 
+import contextlib
 import weakref
 from typing import Optional, Sequence, Tuple
 
@@ -112,6 +113,18 @@ def conv2d(x: torch.Tensor, conv: torch.nn.Conv2d) -> torch.Tensor:
 # fp32 parity mode keeps the library's fp32 convolutions.
 CONV_GEMM = {"enabled": False, "min_rows": 32768, "wgrad": False}
 
+# Weight gradients of these convolutions on their own HIP stream: nothing in backward consumes them (only the optimizer does), so
+# they need not sit on the chain dgrad -> BatchNorm backward -> dgrad ...; issued on a second stream they fill the low-occupancy
+# stretches of that chain.  `join_wgrad_stream()` (optimizer step, gradient reducer) makes the consumer's stream wait for them.
+WGRAD_STREAM = {"enabled": False, "stream": None, "dirty": False}
+
+
+def join_wgrad_stream() -> None:
+    st = WGRAD_STREAM["stream"]
+    if st is not None and WGRAD_STREAM["dirty"]:
+        torch.cuda.current_stream().wait_stream(st)
+        WGRAD_STREAM["dirty"] = False
+
 
 def _conv_gemm_ok(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
     if not (CONV_GEMM["enabled"] and x.is_cuda and x.dim() == 4 and compute_dtype_of(x) == torch.bfloat16):
@@ -157,6 +170,14 @@ class _ConvGemm(Function):
         n, h, w, co = gyn.shape
         ci = wq.shape[1]
         dx = dw = None
+        side = None
+        if ctx.needs_input_grad[1] and WGRAD_STREAM["enabled"] and gyn.is_cuda:
+            if WGRAD_STREAM["stream"] is None:
+                WGRAD_STREAM["stream"] = torch.cuda.Stream(device=gyn.device)
+            side = WGRAD_STREAM["stream"]
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())   # gy and x are complete here; the dgrad below is NOT waited for
+            side.wait_event(ready)
         if ctx.needs_input_grad[0]:
             # dgrad = the same contraction over (flipped tap, Cout): weight re-laid [Cin][ky'][kx'][Cout] (a few MB, once per call)
             wd = wq.flip(2, 3).permute(1, 2, 3, 0).contiguous().reshape(ci, ks * ks * co)
@@ -167,13 +188,18 @@ class _ConvGemm(Function):
             gx, _ = K.conv_gemm(gyn.reshape(n * h * w, co), wd, spatial=(h, w, co) if ks == 3 else None, residual=res)
             dx = gx.view(n, h, w, ci).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            if CONV_GEMM["wgrad"] and K.conv_wgrad_ok(co, ci):
-                xn = _as_nhwc(x)
-                dw2 = K.conv_wgrad(gyn.reshape(n * h * w, co), xn.reshape(n * h * w, ci), spatial=(h, w, ci) if ks == 3 else None)
-                dw = dw2.view(co, ks, ks, ci).permute(0, 3, 1, 2)  # fp32, already in the parameter's channels-last layout
-            else:
-                dw = torch.ops.aten.convolution_backward(gyn.permute(0, 3, 1, 2), x, wq, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
-                                                         [False, True, False])[1].float()
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                if CONV_GEMM["wgrad"] and K.conv_wgrad_ok(co, ci):
+                    xn = _as_nhwc(x)
+                    dw2 = K.conv_wgrad(gyn.reshape(n * h * w, co), xn.reshape(n * h * w, ci), spatial=(h, w, ci) if ks == 3 else None)
+                    dw = dw2.view(co, ks, ks, ci).permute(0, 3, 1, 2)  # fp32, already in the parameter's channels-last layout
+                else:
+                    dw = torch.ops.aten.convolution_backward(gyn.permute(0, 3, 1, 2), x, wq, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
+                                                             [False, True, False])[1].float()
+            if side is not None:
+                for t in (gyn, x, wq):
+                    t.record_stream(side)
+                WGRAD_STREAM["dirty"] = True
         return dx, dw, None, None, None
 
 

@@ -82,6 +82,9 @@ class GradReducer:
 
     @torch.no_grad()
     def _launch(self, s: _Slice):
+        from . import layers as L
+
+        L.join_wgrad_stream()   # weight gradients produced on the side stream (layers.WGRAD_STREAM) must be complete before the pack
         have = [(v, p.grad) for v, p in zip(s.views, s.params) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         missing = [v for v, p in zip(s.views, s.params) if p.grad is None]
         if missing:

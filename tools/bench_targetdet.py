@@ -68,8 +68,9 @@ def main():
         groups.append((time.perf_counter() - tg) / n * 1e3)
         done += n
     dt = (time.perf_counter() - t0) / args.steps
+    in_order = [round(g, 1) for g in groups]
     groups.sort()
-    print(json.dumps({"config": args.config, "workload": "targetDET " + ("step_two" if args.step_two else "step_one") + (" sync-free" if args.sync_free_step else "") + (" (teacher on the main stream)" if args.no_teacher_stream else ""), "images_per_step": args.images, "ms_per_step": dt * 1e3, "median_group_ms_per_step": groups[len(groups) // 2], "fastest_group_ms_per_step": groups[0],
+    print(json.dumps({"config": args.config, "workload": "targetDET " + ("step_two" if args.step_two else "step_one") + (" sync-free" if args.sync_free_step else "") + (" (teacher on the main stream)" if args.no_teacher_stream else ""), "images_per_step": args.images, "ms_per_step": dt * 1e3, "median_group_ms_per_step": groups[len(groups) // 2], "fastest_group_ms_per_step": groups[0], "groups_ms_per_step_in_order": in_order,
                       "student_views_per_s": args.images / dt, "losses": {k: round(float(v), 4) for k, v in rec.items()}}))
 
 
