@@ -358,7 +358,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __re
     }
     const size_t coff = (size_t)cg * V;
     if (active) {
-#pragma unroll 2
+#pragma unroll 4
       for (int64_t r = (int64_t)blockIdx.x * rpi + slot; r < M; r += (int64_t)gridDim.x * rpi) {
         float xv[V], g[V];
         Ld<T>::load(x + (size_t)r * C + coff, xv);
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const T* __restri
     kg[i] = dsums[C + c] * invM;
   }
   const size_t coff = (size_t)rw.cg * V;
-#pragma unroll 2
+#pragma unroll 4
   for (int64_t r = rw.row0; r < M; r += rw.rstep) {
     float xv[V], g[V], o[V];
     Ld<T>::load(x + (size_t)r * C + coff, xv);
