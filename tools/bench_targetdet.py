@@ -23,7 +23,8 @@ def main():
     ap.add_argument("--images", type=int, default=2)
     ap.add_argument("--step-two", action="store_true")
     ap.add_argument("--config", default="foggy", choices=["foggy", "bdd100k_rn101"])
-    ap.add_argument("--sync-free-step", action="store_true", help="cfg.AMD.SYNC_FREE_STEP: fixed-shape samplers + packed losses in the step branches")
+    ap.add_argument("--sync-free-step", action="store_true", help="(default since round 2) cfg.AMD.SYNC_FREE_STEP: fixed-shape samplers + packed losses")
+    ap.add_argument("--reference-samplers", action="store_true", help="cfg.AMD.SYNC_FREE_STEP off: the reference-shaped nonzero / randperm samplers")
     ap.add_argument("--no-teacher-stream", action="store_true", help="cfg.AMD.TEACHER_STREAM off: teacher pass on the main stream (A/B measurement)")
     args = ap.parse_args()
     import torch
@@ -37,7 +38,7 @@ def main():
     cfg.merge_from_file(os.path.join(ROOT, "configs", "coin", "GDINO", "foggy_synthetic.yaml" if args.config == "foggy" else "bdd100k_rn101_synthetic.yaml"))
     cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", args.images, "AMD.SYNTHETIC.NUM_IMAGES", args.images, "AMD.TEXT_TEMPLATES", 4,
                          "MODEL.DEVICE", "cuda:0", "CLOUD.BURN_UP_STEP", 0 if args.step_two else 10 ** 9, "CLOUD.PROTOTYPE_UPDATE_START", 0,
-                         "AMD.SYNC_FREE_STEP", args.sync_free_step, "AMD.TEACHER_STREAM", not args.no_teacher_stream])
+                         "AMD.SYNC_FREE_STEP", not args.reference_samplers, "AMD.TEACHER_STREAM", not args.no_teacher_stream])
     torch.manual_seed(cfg.SEED)
     tr = CoinTrainer(cfg)
     real_forward, g = tr.offline_teacher.forward, torch.Generator().manual_seed(7)
@@ -70,7 +71,7 @@ def main():
     dt = (time.perf_counter() - t0) / args.steps
     in_order = [round(g, 1) for g in groups]
     groups.sort()
-    print(json.dumps({"config": args.config, "workload": "targetDET " + ("step_two" if args.step_two else "step_one") + (" sync-free" if args.sync_free_step else "") + (" (teacher on the main stream)" if args.no_teacher_stream else ""), "images_per_step": args.images, "ms_per_step": dt * 1e3, "median_group_ms_per_step": groups[len(groups) // 2], "fastest_group_ms_per_step": groups[0], "groups_ms_per_step_in_order": in_order,
+    print(json.dumps({"config": args.config, "workload": "targetDET " + ("step_two" if args.step_two else "step_one") + (" (reference-shaped samplers)" if args.reference_samplers else "") + (" (teacher on the main stream)" if args.no_teacher_stream else ""), "images_per_step": args.images, "ms_per_step": dt * 1e3, "median_group_ms_per_step": groups[len(groups) // 2], "fastest_group_ms_per_step": groups[0], "groups_ms_per_step_in_order": in_order,
                       "student_views_per_s": args.images / dt, "losses": {k: round(float(v), 4) for k, v in rec.items()}}))
 
 
