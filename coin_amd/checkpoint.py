@@ -232,6 +232,9 @@ def load_cointrainer_weights(trainer, weights: str, resume: bool = False) -> Non
         else:
             trainer.scheduler.last_epoch = trainer.scheduler_merge.last_epoch = blob.get("iteration", -1)
         trainer.start_iter = trainer.iter = blob.get("iteration", -1) + 1
+        if resume:  # the AP50 histories travel with the checkpoint (hooks.py:60-84)
+            trainer.ap_50_student = dict(blob.get("ap_50_student") or {}) or None
+            trainer.ap_50_offline_teacher = dict(blob.get("ap_50_offline_teacher") or {}) or None
         if blob.get("online_results") is not None:
             trainer.model_CLOUD = CloudResults(blob["online_results"], device=trainer.device)
     else:
@@ -245,6 +248,7 @@ def save_cointrainer_checkpoint(trainer, path: str, iteration: Optional[int] = N
         model.update({_PREFIXES[part] + k: v.detach().cpu() for k, v in module.state_dict().items()})
     blob = {"model": model, "optimizer": optimizer_state(trainer.optimizer), "optimizer_merge": optimizer_state(trainer.optimizer_merge),
             "scheduler": scheduler_state(trainer.scheduler), "scheduler_merge": scheduler_state(trainer.scheduler_merge),
-            "iteration": trainer.iter - 1 if iteration is None else iteration, "ap_50_student": {}, "ap_50_offline_teacher": {},
+            "iteration": trainer.iter - 1 if iteration is None else iteration, "ap_50_student": dict(getattr(trainer, "ap_50_student", None) or {}),
+            "ap_50_offline_teacher": dict(getattr(trainer, "ap_50_offline_teacher", None) or {}),
             "online_results": trainer.model_CLOUD.get_results() if hasattr(trainer.model_CLOUD, "get_results") else None}
     save_file(blob, path)

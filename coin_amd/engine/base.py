@@ -72,6 +72,27 @@ class BASE_Trainer:
         model.train(was_training)
         return evaluator.evaluate()
 
+    # ---- periodic evaluation (MyEvalHook, coin/engine/hooks.py:144-190; build_hooks: pre_train.py:300-310, trainer.py:296-318)
+    _eval_items = _eval_factory = None
+
+    def set_evaluation(self, items, evaluator_factory, batch_size: int = 1):
+        """`items`: the test set as dataset-mapper outputs (image / height / width / image_id ...); `evaluator_factory()` builds a fresh
+        evaluator (reset / process / evaluate, e.g. coin_amd.evaluation.PascalVOCEvaluator).  With `TEST.EVAL_PERIOD > 0` `train()` then
+        evaluates after every EVAL_PERIOD-th iteration (BEFORE that iteration's checkpoint, so the file carries the new AP50) and
+        after the last one, exactly like the reference's hook order."""
+        self._eval_items, self._eval_factory, self._eval_batch = list(items), evaluator_factory, batch_size
+
+    def _eval_due(self, start: int = -1) -> bool:
+        """detectron2 EvalHook.after_step / after_train with MyEvalHook's start iteration; `self.iter` = index of the step just done."""
+        if self._eval_factory is None:
+            return False
+        period, nxt = self.cfg.TEST.EVAL_PERIOD, self.iter + 1
+        periodic = period > 0 and nxt % period == 0 and nxt > start and nxt != self.max_iter
+        return periodic or nxt >= self.max_iter
+
+    def _evaluate(self, model) -> Dict:
+        return self.test(model, self._eval_items, self._eval_factory(), batch_size=self._eval_batch)
+
     # ---- metrics without a per-step host sync
     def _write_metrics(self, metrics_dict: Dict[str, torch.Tensor], iteration: int) -> Optional[Dict[str, float]]:
         self._last_metrics = metrics_dict

@@ -111,7 +111,8 @@ class PRETrainer(BASE_Trainer):
 
         results = self.collect_model.get_results() if hasattr(self.collect_model, "get_results") else None
         blob = {"model": {k: v.detach().cpu() for k, v in self.model.state_dict().items()}, "optimizer": optimizer_state(self.optimizer),
-                "scheduler": scheduler_state(self.scheduler), "iteration": self.iter - 1 if iteration is None else iteration, "results": results}
+                "scheduler": scheduler_state(self.scheduler), "iteration": self.iter - 1 if iteration is None else iteration, "results": results,
+                "ap_50": dict(self.ap_50 or {})}   # MyPeriodicCheckpointer(..., ap_50=self.ap_50) (pre_train.py:316-319)
         if not load_models:  # pre_train.py:142: the key exists only when False (the collection run's CLIP_-0000001.pth)
             blob["load_models"] = False
         save_file(blob, path)
@@ -137,6 +138,7 @@ class PRETrainer(BASE_Trainer):
                 self.scheduler.load_state_dict(blob["scheduler"])
         if is_ckpt:
             self.iter = self.start_iter = blob.get("iteration", -1) + 1
+            self.ap_50 = dict(blob.get("ap_50") or {}) or None
             if blob.get("results") is not None:
                 self.collect_model = CloudResults(blob["results"], device=self.device)
         self._next_batch = None
@@ -161,9 +163,26 @@ class PRETrainer(BASE_Trainer):
         for n in names:
             self.save(os.path.join(out, n), iteration=done)
 
+    ap_50: Dict[int, float] = None
+
+    def before_checkpoint(self):
+        """test_and_save_results_student (pre_train.py:300-308): evaluate the student when due and remember its AP50 per iteration
+        (the dict travels in the checkpoints, hooks.py:60-84)."""
+        self.iter -= 1  # hooks see the index of the step just finished
+        try:
+            if self._eval_due():
+                res = self._evaluate(self.model)
+                self._last_eval_results_student = res
+                if self.ap_50 is None:
+                    self.ap_50 = {}
+                self.ap_50[self.iter] = res["bbox"]["AP50"]
+        finally:
+            self.iter += 1
+
     def train(self):
         for _ in range(self.start_iter, self.max_iter):
             rec = self.run_step()
+            self.before_checkpoint()
             self.after_step()
             m = self._write_metrics(rec, self.iter)
             if m is not None and self.rank == 0:

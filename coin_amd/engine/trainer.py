@@ -248,9 +248,40 @@ class CoinTrainer(BASE_Trainer):
         for n in names:
             save_cointrainer_checkpoint(self, os.path.join(self.cfg.OUTPUT_DIR, n), iteration=done)
 
+    ap_50_student: Dict[int, float] = None
+    ap_50_offline_teacher: Dict[int, float] = None
+
+    def before_checkpoint(self):
+        """build_hooks (trainer.py:296-318): the student is evaluated every TEST.EVAL_PERIOD iterations and after the last one; the
+        teacher once at the first evaluation (iteration EVAL_PERIOD - 1), is carried forward while it is frozen (burn-up), and is
+        evaluated itself from BURN_UP_STEP on when it follows the student by EMA (EMA_KEEP_RATE_OFFLINE != 1)."""
+        self.iter -= 1  # hooks see the index of the step just finished
+        try:
+            cfg, period = self.cfg, self.cfg.TEST.EVAL_PERIOD
+            if self.ap_50_student is None:
+                self.ap_50_student, self.ap_50_offline_teacher = {}, {}
+
+            def eval_teacher():
+                self._last_eval_results_teacher = self._evaluate(self.offline_teacher)
+                self.ap_50_offline_teacher[self.iter] = self._last_eval_results_teacher["bbox"]["AP50"]
+
+            if self._eval_due():
+                self._last_eval_results_student = self._evaluate(self.model)
+                self.ap_50_student[self.iter] = self._last_eval_results_student["bbox"]["AP50"]
+                if self.iter == period - 1:
+                    eval_teacher()
+                elif self.iter <= cfg.CLOUD.BURN_UP_STEP and (self.iter - period) in self.ap_50_offline_teacher:
+                    self.ap_50_offline_teacher[self.iter] = self.ap_50_offline_teacher[self.iter - period]
+            teacher_start = cfg.CLOUD.BURN_UP_STEP if cfg.CLOUD.EMA_KEEP_RATE_OFFLINE != 1.0 else 10 ** 10
+            if self._eval_due(start=teacher_start) and self.iter not in self.ap_50_offline_teacher:
+                eval_teacher()
+        finally:
+            self.iter += 1
+
     def train(self):
         for _ in range(self.start_iter, self.max_iter):
             rec = self.run_step()
+            self.before_checkpoint()
             self.after_step()
             self.prepare_next()
             m = self._write_metrics(rec, self.iter)

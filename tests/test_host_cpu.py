@@ -871,3 +871,55 @@ def test_pretrainer_resume_and_load_models_flag(tmp_path):
         assert c.iter == 0
         for k, v in fresh.items():
             assert torch.equal(c.model.state_dict()[k], v), k
+
+
+def test_eval_hooks_follow_the_reference_schedule(tmp_path):
+    """MyEvalHook (hooks.py:144-190) as wired by build_hooks (pre_train.py:300-310, trainer.py:296-318): the student is evaluated after every
+    EVAL_PERIOD-th iteration -- before that iteration's checkpoint, so the file carries the new AP50 -- and after the last one; the
+    CoinTrainer's teacher once at the first evaluation, carried forward while frozen, then evaluated itself once it follows by EMA."""
+    from coin_amd.checkpoint import load_file
+    from coin_amd.data.synthetic import synthetic_offline_detections
+    from coin_amd.engine import CoinTrainer, PRETrainer
+
+    class Stub:  # evaluator protocol: reset / process / evaluate
+        calls = 0
+
+        def reset(self):
+            self.n = 0
+
+        def process(self, inputs, outputs):
+            assert len(inputs) == len(outputs) and "instances" in outputs[0]
+            self.n += len(inputs)
+
+        def evaluate(self):
+            Stub.calls += 1
+            return {"bbox": {"AP50": 10.0 * Stub.calls + self.n}}
+
+    with cpu_kernels():
+        cfg = _tiny_trainer_cfg(("PRETRAINS", "CLIPDET_synthetic.yaml"), ["SOLVER.MAX_ITER", 4, "TEST.EVAL_PERIOD", 2, "SOLVER.CHECKPOINT_PERIOD", 2,
+                                                                         "OUTPUT_DIR", str(tmp_path / "pre")])
+        torch.manual_seed(0)
+        tr = PRETrainer(cfg)
+        items = [dict(d) for d in next(iter(tr._data_loader_iter))[1]]
+        tr.set_evaluation(items, Stub)
+        tr.train()
+        assert sorted(tr.ap_50) == [1, 3] and tr.ap_50[1] == 11.0 and tr.ap_50[3] == 21.0       # iteration 1 (next_iter % 2 == 0) and the last one
+        assert load_file(str(tmp_path / "pre" / "CLIP_0000001.pth"))["ap_50"] == {1: 11.0}       # evaluated BEFORE the checkpoint of that iteration
+        assert load_file(str(tmp_path / "pre" / "CLIP_final.pth"))["ap_50"] == {1: 11.0, 3: 21.0}
+
+        Stub.calls = 0
+        cfg = _tiny_trainer_cfg(("GDINO", "foggy_synthetic.yaml"), ["SOLVER.MAX_ITER", 6, "TEST.EVAL_PERIOD", 2, "CLOUD.BURN_UP_STEP", 2,
+                                                                  "CLOUD.PROTOTYPE_UPDATE_START", 0, "OUTPUT_DIR", str(tmp_path / "coin")])
+        torch.manual_seed(0)
+        tr = CoinTrainer(cfg)
+        g = torch.Generator().manual_seed(7)
+        fwd = tr.offline_teacher.forward
+        teacher = lambda bi, branch=None, **kw: [synthetic_offline_detections(tr.model_CLOUD.entry(d["file_name"]), g) for d in bi]
+        tr.offline_teacher.forward = lambda bi, branch=None, **kw: (fwd(bi, branch=branch, **kw), teacher(bi))[1]
+        tr.set_evaluation(items, Stub)
+        tr.train()
+        assert sorted(tr.ap_50_student) == [1, 3, 5]
+        # teacher: evaluated with the first student evaluation (iteration EVAL_PERIOD - 1), then by its own hook from BURN_UP_STEP on
+        assert sorted(tr.ap_50_offline_teacher) == [1, 3, 5]
+        blob = load_file(str(tmp_path / "coin" / "model_final.pth"))
+        assert blob["ap_50_student"] == tr.ap_50_student and blob["ap_50_offline_teacher"] == tr.ap_50_offline_teacher
