@@ -33,4 +33,13 @@ def collect_clip_results(clip_model, items: Iterable[Dict], cloud_results: Calla
                 v["instances"] = v["instances"].to("cpu")
         out[res["file_name"]] = res
     clip_model.train(was_training)
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # clip_collector.py:60-63: every rank relabels its shard of the loader, then all ranks hold the union
+        # (`comm.all_gather(self._results)`: a pickled-object gather, once per run, off the training path)
+        parts = [None] * dist.get_world_size()
+        dist.all_gather_object(parts, out)
+        for part in parts:
+            out.update(part)
     return CloudResults({dataset_name: out}, device=device)

@@ -189,3 +189,36 @@ def test_grad_reducer_averages_in_slices_with_missing_gradients(tmp_path):
     world, port = 2, _free_port()
     mp.start_processes(_reducer_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
     assert all(torch.load(tmp_path / f"red{r}.pt")["ok"] for r in range(world))
+
+
+def _collect_worker(rank, world, port, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from coin_amd.engine.collect import collect_clip_results
+    from coin_amd.structures import Boxes, Instances
+
+    class Relabel(torch.nn.Module):  # stands in for the CLIP teacher: (inputs, cached cloud result) -> relabelled result
+        def forward(self, inputs, pre):
+            inst = Instances((4, 4))
+            inst.pred_boxes = Boxes(torch.tensor([[0.0, 0.0, 1.0 + rank, 2.0]]))
+            return {"file_name": inputs[0]["file_name"], "image_id": inputs[0]["image_id"], "height": 4, "width": 4, "rank": rank,
+                    "RCNN": {"instances": inst}, "RPN": {"instances": inst}}
+
+    names = [f"img{i}.png" for i in range(5)]
+    mine = [{"file_name": n, "image_id": n} for n in names[rank::world]]     # each rank's shard of the loader
+    res = collect_clip_results(Relabel(), mine, lambda fn: {"file_name": fn}, dataset_name="d")
+    got = res.get_results()["d"]
+    ok = sorted(got) == names and all(got[n]["rank"] == i % world for i, n in enumerate(names))
+    torch.save({"ok": bool(ok)}, os.path.join(out_dir, f"col{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collection_loop_unions_the_ranks_shards(tmp_path):
+    """CLIP_COLLECTOR.collect (clip_collector.py:46-63): every rank relabels its shard, all ranks end with the union."""
+    world, port = 2, _free_port()
+    mp.start_processes(_collect_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    assert all(torch.load(tmp_path / f"col{r}.pt")["ok"] for r in range(world))
