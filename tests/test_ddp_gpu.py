@@ -70,14 +70,16 @@ def _run(force):
 
 
 def test_one_rank_rccl_reducer_reproduces_the_plain_run():
-    """The bound is calibrated by a second plain run: the library convolutions are not bit-reproducible run to run (measured with
-    tools/determinism_probe.py: two forwards from one seed in one process give RPN outputs that differ in the last bits, and a
-    proposal whose IoU crosses 0.5 then changes one of the 1024 sampled labels: |d loss_cls| ~ 5e-4).  The reducer run must stay
-    within 3x the plain-vs-plain spread (or 1e-5 where the plain runs agree)."""
-    plain, again, reduced = _run(False), _run(False), _run(True)
-    for a, a2, b in zip(plain, again, reduced):
+    """Two checks.  EXACT (inside the reducer run, see _SCRIPT): after backward + all-reduce the arena views the optimizer reads equal the
+    gradients autograd produced, for every parameter.  LOOSE: the losses of 3 steps against a run without the reducer.  The loose bound
+    is what run-to-run reproducibility allows: the library convolutions are not bit-reproducible (tools/determinism_probe.py: two
+    forwards from one seed in one process give RPN outputs that differ in the last bits), and a proposal whose IoU crosses 0.5 then
+    changes one of the 1024 sampled RoI labels -- measured spread between two PLAIN runs: up to 1.2e-3 on loss_cls / loss_box_reg,
+    <= 1e-6 on the RPN and text losses, which do not depend on the sampled RoIs."""
+    plain, reduced = _run(False), _run(True)
+    for a, b in zip(plain, reduced):
         assert set(a) == set(b)
         for k in a:
-            tol = max(1e-5 * max(1.0, abs(a[k])), 3.0 * abs(a[k] - a2[k]))
-            assert abs(a[k] - b[k]) <= tol and abs(a2[k] - b[k]) <= tol + abs(a[k] - a2[k]), (k, a[k], a2[k], b[k])
+            tol = (5e-3 if k in ("loss_cls", "loss_box_reg") else 1e-5) * max(1.0, abs(a[k]))
+            assert abs(a[k] - b[k]) <= tol, (k, a[k], b[k])
     assert plain[0] != plain[2]  # the steps did train

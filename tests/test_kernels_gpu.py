@@ -228,6 +228,46 @@ def test_conv_gemm_3x3_vs_torch(K, nb, h, w, cin, cout):
         torch.testing.assert_close(gx.reshape(nb, h, w, cin).permute(0, 3, 1, 2).cpu().double(), gref, rtol=1e-2, atol=1e-2 * float(gref.abs().max()))
 
 
+@pytest.mark.parametrize("nb,h,w,cin,cout,ks", [(2048, 14, 14, 1024, 512, 1), (2048, 14, 14, 512, 512, 3), (2048, 7, 7, 512, 2048, 1),
+                                                (2048, 7, 7, 2048, 512, 1), (2048, 7, 7, 512, 512, 3)])
+def test_conv_gemm_at_the_timed_shapes_vs_fp64_on_sampled_pixels(K, nb, h, w, cin, cout, ks):
+    """coin_conv_gemm_bf16 at the benchmark's own res5 launch shapes (2048 RoIs: M = 401 408 / 100 352 pixels): 4096 random output
+    pixels against an fp64 evaluation of the same bf16 operands (forward and data gradient), and the fused BatchNorm statistics
+    against fp64 statistics of the stored output."""
+    g = torch.Generator(device="cuda").manual_seed(nb + cin + ks)
+    x = (torch.randn((nb, h, w, cin), generator=g, device="cuda") * 0.7).to(torch.bfloat16)
+    wt = (torch.randn((cout, ks, ks, cin), generator=g, device="cuda") * (2.0 / (cin * ks * ks)) ** 0.5).to(torch.bfloat16)
+    m = nb * h * w
+    out, part = K.conv_gemm(x.reshape(m, cin), wt.reshape(cout, ks * ks * cin), spatial=(h, w, cin) if ks == 3 else None, stats_rows=m)
+    pix = torch.randint(0, m, (4096,), generator=g, device="cuda")
+
+    def gather_rows(src, c):   # im2col rows of the sampled pixels: [4096, ks*ks*c] in (ky, kx, c) order, zeros outside the image
+        n_, r = pix // (h * w), pix % (h * w)
+        oy, ox = r // w, r % w
+        cols = []
+        for ky in range(ks):
+            for kx in range(ks):
+                yy, xx = oy + ky - ks // 2, ox + kx - ks // 2
+                ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+                v = src[n_, yy.clamp(0, h - 1), xx.clamp(0, w - 1)].double()
+                cols.append(v * ok.unsqueeze(1))
+        return torch.cat(cols, dim=1)
+
+    ref = gather_rows(x, cin) @ wt.reshape(cout, -1).double().t()
+    got = out[pix].double()
+    assert float((got - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) + 1e-3     # one bf16 rounding of the stored value
+    mean, rstd = K.conv_stats_finalize(part, m, cout, m, 1e-5, 0.1, None, None)
+    y = out.double()
+    torch.testing.assert_close(mean.double(), y.mean(0), rtol=1e-5, atol=1e-5 * float(y.abs().max()))
+    torch.testing.assert_close(rstd.double(), (y.var(0, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4, atol=0)
+    # data gradient = the same contraction with the re-laid weight
+    gy = (torch.randn((nb, h, w, cout), generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    wd = wt.flip(1, 2).permute(3, 1, 2, 0).contiguous()                                     # [cin, ky', kx', cout]
+    gx, _ = K.conv_gemm(gy.reshape(m, cout), wd.reshape(cin, ks * ks * cout), spatial=(h, w, cout) if ks == 3 else None)
+    gref = gather_rows(gy, cout) @ wd.reshape(cin, -1).double().t()
+    assert float((gx[pix].double() - gref).abs().max()) <= 2.0 ** -8 * float(gref.abs().max()) + 1e-3
+
+
 @pytest.mark.parametrize("nb,h,w,cin,cout,ks", [(40, 7, 7, 256, 256, 1), (9, 14, 14, 512, 256, 1), (33, 7, 7, 256, 512, 3), (6, 14, 14, 256, 256, 3), (700, 7, 7, 512, 256, 1)])
 def test_conv_wgrad_vs_fp64(K, nb, h, w, cin, cout, ks):
     """coin_conv_wgrad_bf16 (transposed-LDS-read MFMA contraction over the pixels, sliced, slabs summed in order) vs the fp64 weight
