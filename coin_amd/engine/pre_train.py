@@ -37,8 +37,9 @@ class PRETrainer(BASE_Trainer):
         self.optimizer = build_optimizer(cfg, self.model, name="all")
         # data parallelism (pre_train.py:59-62): replicas synchronised once, gradients averaged per step (coin_amd.parallel)
         force_ddp = os.environ.get("COIN_FORCE_DDP") == "1" and dist.is_available() and dist.is_initialized()  # 1-rank dry run of the collective path
+        arena_only = os.environ.get("COIN_FORCE_DDP") == "arena"   # measurements: the gradient arena + hooks without any collective
         self.reducer = None
-        if self.world_size > 1 or force_ddp:
+        if self.world_size > 1 or force_ddp or arena_only:
             from ..parallel import GradReducer, broadcast_parameters, force_collectives
 
             force_collectives(force_ddp)
