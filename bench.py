@@ -19,6 +19,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime starts: see coin_amd/__init__.py
 import subprocess
 import sys
 import time
@@ -208,7 +210,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
     torch.cuda.set_device(local_rank)
-    if world > 1 or os.environ.get("COIN_FORCE_DDP") == "1":  # COIN_FORCE_DDP: exercise the DDP / RCCL path with a single rank
+    if world > 1 or os.environ.get("COIN_FORCE_DDP") == "1" or os.environ.get("COIN_INIT_PG") == "1":  # COIN_FORCE_DDP: exercise the RCCL path with a single rank
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")

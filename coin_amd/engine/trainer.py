@@ -19,6 +19,7 @@ gradients away (``optimizer.zero_grad()``, trainer.py:199); bf16 autocast needs 
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -51,7 +52,8 @@ class CoinTrainer(BASE_Trainer):
         self.optimizer_merge = build_optimizer(cfg, self.merge, name="all")
         self.ddp_model, self.ddp_merge = self.model, self.merge  # kept for callers of the reference's attribute names
         self.reducer = self.reducer_merge = None
-        if self.world_size > 1:  # trainer.py:66-72: the student AND the CKG module are data parallel
+        # trainer.py:66-72: the student AND the CKG module are data parallel; on one GPU the same gradient arenas run without a collective
+        if self.world_size > 1 or (cfg.AMD.GRAD_ARENA and self.device.type == "cuda" and os.environ.get("COIN_GRAD_ARENA", "1") != "0"):
             from ..parallel import GradReducer, broadcast_parameters
 
             broadcast_parameters(self.model)

@@ -38,6 +38,9 @@ class GradReducer:
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.slices: List[_Slice] = []
         self._slice_of = {}
+        import os
+
+        slice_mb = float(os.environ.get("COIN_REDUCER_SLICE_MB", slice_mb))   # measurements
         cap = max(int(slice_mb * (1 << 20) // 4), 1)
         cur: List[torch.nn.Parameter] = []
         n = 0

@@ -1,6 +1,6 @@
 """The collective path on the MI355X with ONE rank (``-m gpu``): RCCL process group, gradient slices all-reduced from the backward
 hooks (coin_amd.parallel.GradReducer), SGD from the arena views.  With one rank the all-reduce is the identity, so the losses of
-a run with the reducer must equal those of a run without it.  (No N > 1 number exists for this repo: 8-GPU runs are the driver's.)"""
+a run with the collectives must equal those of a run without them (the gradient arena itself is used in both).  (No N > 1 number exists for this repo: 8-GPU runs are the driver's.)"""
 import json
 import os
 import subprocess
@@ -28,7 +28,8 @@ cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", 1, "AMD.SYNTHETIC.NUM_IMAGE
 torch.backends.cudnn.deterministic = True   # ask the convolution library for its reproducible algorithms where it has them
 torch.manual_seed(5)
 tr = PRETrainer(cfg)
-assert (tr.reducer is not None) == force
+import coin_amd.parallel as PAR
+assert tr.reducer is not None and PAR._FORCE[0] == force   # the gradient arena is always there; the collectives only in the forced run
 with torch.no_grad():
     for n, p in tr.model.named_parameters():
         if n.endswith("bn3.weight"):

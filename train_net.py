@@ -14,6 +14,8 @@ from __future__ import annotations
 
 import argparse
 import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime starts: see coin_amd/__init__.py
 import subprocess
 import sys
 
