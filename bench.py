@@ -249,6 +249,8 @@ def main():
     views_per_step = IMAGES_PER_GPU * VIEWS_PER_IMAGE * world
     value = views_per_step * args.steps / dt
     loss = float(sum(rec.values()))
+    if not (loss == loss and abs(loss) < 1e6):
+        raise SystemExit(f"bench.py: the training loss is not finite ({loss}) after {args.warmup + args.steps} steps: the run is invalid")
 
     if rank == 0:
         # dominant hand-written kernel by total time inside the timed region

@@ -28,7 +28,7 @@ import torch.distributed as dist
 
 
 class _Slice:
-    __slots__ = ("params", "views", "flat", "arrived", "launched", "work")
+    __slots__ = ("params", "views", "flat", "arrived", "launched", "work", "events")
 
 
 class GradReducer:
@@ -66,16 +66,25 @@ class GradReducer:
             # optimizer sees the layout it expects
             s.views.append(s.flat[off:off + p.numel()].as_strided(p.shape, p.stride()) if _dense(p) else s.flat[off:off + p.numel()].view(p.shape))
             off += p.numel()
-        s.arrived, s.launched, s.work = 0, False, None
+        s.arrived, s.launched, s.work, s.events = 0, False, None, []
         idx = len(self.slices)
         self.slices.append(s)
         for p in params:
             self._slice_of[id(p)] = idx
 
     # ---- backward hooks
+    # Autograd runs a backward node on the stream its forward ran on, and this package puts part of the forward on side streams (text
+    # encoder, anchor labelling: OpenVocabularyRCNN._overlap_side_work).  A hook may therefore fire on ANY of those streams, and the
+    # slice it completes holds gradients produced on others.  Every arrival leaves an event on its stream; the stream that packs a
+    # slice waits for the events of that slice first.  (Found when GPU_MAX_HW_QUEUES was raised: with 4 hardware queues the streams
+    # happened to serialise and the missing dependency did not show; with 8 the packed gradients were read too early -> NaN.)
     def _on_grad(self, p: torch.nn.Parameter):
         s = self.slices[self._slice_of[id(p)]]
         s.arrived += 1
+        if p.grad is not None and p.grad.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(p.grad.device))
+            s.events.append(ev)
         self._launch_ready()
 
     def _launch_ready(self):
@@ -83,11 +92,18 @@ class GradReducer:
             self._launch(self.slices[self._next])
             self._next += 1
 
+    _pack_events: list = None
+
     @torch.no_grad()
     def _launch(self, s: _Slice):
         from . import layers as L
 
         L.join_wgrad_stream()   # weight gradients produced on the side stream (layers.WGRAD_STREAM) must be complete before the pack
+        if s.events:
+            cur = torch.cuda.current_stream(s.flat.device)
+            for ev in s.events:
+                cur.wait_event(ev)
+            s.events = []
         have = [(v, p.grad) for v, p in zip(s.views, s.params) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         missing = [v for v, p in zip(s.views, s.params) if p.grad is None]
         if missing:
@@ -99,6 +115,12 @@ class GradReducer:
         s.launched = True
         if self.world_size > 1 or _FORCE[0]:
             s.work = dist.all_reduce(s.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if s.flat.is_cuda:   # whoever consumes the arena (finalize, on the caller's stream) waits for this pack
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(s.flat.device))
+            if self._pack_events is None:
+                self._pack_events = []
+            self._pack_events.append(done)
 
     # ---- called by the trainer after backward
     def finalize(self) -> float:
@@ -107,11 +129,16 @@ class GradReducer:
         while self._next < len(self.slices):
             self._launch(self.slices[self._next])
             self._next += 1
+        if self._pack_events:
+            cur = torch.cuda.current_stream()
+            for ev in self._pack_events:
+                cur.wait_event(ev)
+            self._pack_events = []
         for s in self.slices:
             if s.work is not None:
                 s.work.wait()
                 s.work = None
-            s.arrived, s.launched = 0, False
+            s.arrived, s.launched, s.events = 0, False, []
         self._next = 0
         return 1.0 / self.world_size
 
