@@ -9,7 +9,7 @@ import os as _os
 
 # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  This package runs 3-4 streams of its own (main, text encoder /
 # anchor labelling, frozen-stage look-ahead, teacher) and RCCL adds its communicator streams: with the default, streams share queues
-# and the overlap serialises -- measured 98.5 -> 90.5 views/s as soon as an RCCL process group exists, 105 with 8 queues
-# (DESIGN.md section 6).  Must be in the environment before the HIP runtime initialises (the first torch.cuda call); a value set by the
+# and the overlap serialises -- measured 98.5 -> 90.5 views/s as soon as an RCCL process group exists, 95 with 8 queues (what is left
+# is the gradient packing itself).  Must be in the environment before the HIP runtime initialises (the first torch.cuda call); a value set by the
 # user wins.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

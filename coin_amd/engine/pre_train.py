@@ -36,11 +36,10 @@ class PRETrainer(BASE_Trainer):
         self.model.train()
         self.optimizer = build_optimizer(cfg, self.model, name="all")
         # data parallelism (pre_train.py:59-62): replicas synchronised once, gradients averaged per step (coin_amd.parallel)
-        # The gradient arena is used on ONE GPU as well (no collective then): gradients packed into a flat buffer with stable addresses
-        # measured 106 vs 99 views/s against handing autograd's freshly allocated gradient tensors to the optimizer (cfg.AMD.GRAD_ARENA).
+        # cfg.AMD.GRAD_ARENA / COIN_GRAD_ARENA=1: the arena without a collective on ONE GPU (measurements: 97.0 vs 98.6 views/s plain)
         force_ddp = os.environ.get("COIN_FORCE_DDP") == "1" and dist.is_available() and dist.is_initialized()  # 1-rank dry run of the collective path
         self.reducer = None
-        if self.world_size > 1 or force_ddp or (cfg.AMD.GRAD_ARENA and self.device.type == "cuda" and os.environ.get("COIN_GRAD_ARENA", "1") != "0"):
+        if self.world_size > 1 or force_ddp or ((cfg.AMD.GRAD_ARENA or os.environ.get("COIN_GRAD_ARENA") == "1") and self.device.type == "cuda"):
             from ..parallel import GradReducer, broadcast_parameters, force_collectives
 
             force_collectives(force_ddp)

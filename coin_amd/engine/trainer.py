@@ -52,8 +52,8 @@ class CoinTrainer(BASE_Trainer):
         self.optimizer_merge = build_optimizer(cfg, self.merge, name="all")
         self.ddp_model, self.ddp_merge = self.model, self.merge  # kept for callers of the reference's attribute names
         self.reducer = self.reducer_merge = None
-        # trainer.py:66-72: the student AND the CKG module are data parallel; on one GPU the same gradient arenas run without a collective
-        if self.world_size > 1 or (cfg.AMD.GRAD_ARENA and self.device.type == "cuda" and os.environ.get("COIN_GRAD_ARENA", "1") != "0"):
+        # trainer.py:66-72: the student AND the CKG module are data parallel (cfg.AMD.GRAD_ARENA: the same arenas on one GPU, no collective)
+        if self.world_size > 1 or ((cfg.AMD.GRAD_ARENA or os.environ.get("COIN_GRAD_ARENA") == "1") and self.device.type == "cuda"):
             from ..parallel import GradReducer, broadcast_parameters
 
             broadcast_parameters(self.model)

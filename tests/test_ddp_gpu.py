@@ -1,6 +1,6 @@
 """The collective path on the MI355X with ONE rank (``-m gpu``): RCCL process group, gradient slices all-reduced from the backward
 hooks (coin_amd.parallel.GradReducer), SGD from the arena views.  With one rank the all-reduce is the identity, so the losses of
-a run with the collectives must equal those of a run without them (the gradient arena itself is used in both).  (No N > 1 number exists for this repo: 8-GPU runs are the driver's.)"""
+a run with the reducer must equal those of a run without it.  (No N > 1 number exists for this repo: 8-GPU runs are the driver's.)"""
 import json
 import os
 import subprocess
@@ -29,7 +29,7 @@ torch.backends.cudnn.deterministic = True   # ask the convolution library for it
 torch.manual_seed(5)
 tr = PRETrainer(cfg)
 import coin_amd.parallel as PAR
-assert tr.reducer is not None and PAR._FORCE[0] == force   # the gradient arena is always there; the collectives only in the forced run
+assert (tr.reducer is not None) == force and PAR._FORCE[0] == force
 with torch.no_grad():
     for n, p in tr.model.named_parameters():
         if n.endswith("bn3.weight"):
