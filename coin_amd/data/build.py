@@ -18,7 +18,7 @@ from typing import Dict, Iterator, List, Optional, Sequence
 import torch
 
 from .common import AspectRatioGroupedDatasetTwoCrop
-from .dataset_mapper import DatasetMapperUnsupervised, read_image
+from .dataset_mapper import DatasetMapperUnsupervised, TESTMapper, read_image
 
 
 class TrainingSampler:
@@ -78,3 +78,27 @@ def build_detection_unsupervised_train_loader(cfg, dataset_dicts: Sequence[Dict]
     sampler = TrainingSampler(len(dataset_dicts), seed=cfg.SEED if cfg.SEED >= 0 else 0, rank=rank, world_size=world_size)
     return build_unsupervised_batch_data_loader(dataset_dicts, sampler, mapper, cfg.SOLVER.IMG_PER_BATCH_UNLABEL, world_size=world_size,
                                                 aspect_ratio_grouping=cfg.DATALOADER.ASPECT_RATIO_GROUPING, num_workers=cfg.DATALOADER.NUM_WORKERS)
+
+
+class InferenceSampler:
+    """detectron2 ``InferenceSampler``: range(size) cut into contiguous shards, the first size % world_size ranks get one more."""
+
+    def __init__(self, size: int, rank: int = 0, world_size: int = 1):
+        shard, left = size // world_size, size % world_size
+        sizes = [shard + int(r < left) for r in range(world_size)]
+        begin = sum(sizes[:rank])
+        self._range = range(begin, min(begin + sizes[rank], size))
+
+    def __iter__(self):
+        return iter(self._range)
+
+    def __len__(self):
+        return len(self._range)
+
+
+def build_detection_test_loader(cfg, dataset_dicts: Sequence[Dict], mapper=None, rank: int = 0, world_size: int = 1):
+    """coin/data/build.py:28-53: every image of the test set once, in order, sharded over the ranks, batch size 1
+    (`BASE_Trainer.test` consumes the batches)."""
+    mapper = mapper if mapper is not None else TESTMapper(cfg)
+    for i in InferenceSampler(len(dataset_dicts), rank, world_size):
+        yield [mapper(dataset_dicts[i])]

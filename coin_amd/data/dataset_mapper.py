@@ -166,3 +166,11 @@ class DatasetMapperUnsupervised:
         weak_d["image"] = self.to_chw(weak)
         assert d["image"].shape == weak_d["image"].shape
         return d, weak_d
+
+
+class TESTMapper(DatasetMapperUnsupervised):
+    """The evaluation mapper (coin/data/dataset_mapper.py:59-121 = detectron2's DatasetMapper in test mode): shortest edge to
+    ``INPUT.MIN_SIZE_TEST`` (cap ``MAX_SIZE_TEST``), no flip, annotations dropped; one dict with ``image`` uint8 [3, h, w] on the device."""
+
+    def __init__(self, cfg, is_train: bool = False, **kw):
+        super().__init__(cfg, False, **kw)

@@ -102,3 +102,26 @@ def test_loader_end_to_end_from_files_with_decode_threads(tmp_path):
     for (s0, w0), (s1, w1) in zip(*outs):
         assert [d["image_id"] for d in s0] == [d["image_id"] for d in s1]
         assert all(torch.equal(a["image"], b["image"]) for a, b in zip(s0 + w0, s1 + w1))
+
+
+def test_test_loader_maps_every_image_once_in_shards(tmp_path):
+    from PIL import Image
+
+    from cpu_shim import cpu_kernels
+    from coin_amd.data import InferenceSampler, build_detection_test_loader
+    from oracle import augment as A
+
+    assert [list(InferenceSampler(7, r, 3)) for r in range(3)] == [[0, 1, 2], [3, 4], [5, 6]]
+    dicts, imgs = [], []
+    for i, (h, w) in enumerate([(60, 90), (90, 60), (64, 96)]):
+        a = np.random.default_rng(20 + i).integers(0, 256, (h, w, 3), dtype=np.uint8)
+        Image.fromarray(a, "RGB").save(tmp_path / f"{i}.png")
+        imgs.append(a)
+        dicts.append({"file_name": str(tmp_path / f"{i}.png"), "image_id": str(i), "height": h, "width": w, "annotations": [{"bbox": [1, 2, 3, 4], "category_id": 0}]})
+    cfg = _cfg(**{"INPUT.MIN_SIZE_TEST": 48, "INPUT.MAX_SIZE_TEST": 64})
+    with cpu_kernels():
+        got = [b for r in range(2) for b in build_detection_test_loader(cfg, dicts, rank=r, world_size=2)]
+    assert [b[0]["image_id"] for b in got] == ["0", "1", "2"] and all(len(b) == 1 and "annotations" not in b[0] for b in got)
+    for b, a in zip(got, imgs):
+        oh, ow = A.shortest_edge_size(a.shape[0], a.shape[1], 48, 64)
+        assert np.array_equal(b[0]["image"].numpy(), A.resize_bilinear(a, oh, ow).transpose(2, 0, 1)) and b[0]["random_flip"] == "no"
