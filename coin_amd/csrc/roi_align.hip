@@ -391,182 +391,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_nhwc_kernel(
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// backward, NHWC, atomic-free: gather per map tile.
-//   d feat[n][y][x][c] = sum over RoIs r of image n:  sum_py sum_px Wy_r[py][y] * Wx_r[px][x] * gout[r][py][px][c] / count_r
-// A block owns one 8x8-pixel tile of one image's gradient map x 128 channels (lane = 2 channels, wave w = tile rows 2w, 2w+1);
-// the 16 pixel accumulators of a wave live in registers.  The block first compacts (in RoI order) the RoIs whose sample
-// footprint can touch the tile; each wave then walks that list on its own (no block barriers): it computes the RoI's bilinear
-// weights for its 2 rows and the 8 tile columns across its lanes (one (pixel, bin) pair per lane, exactly the arithmetic of
-// the forward), parks them in a wave-private LDS table, and contracts the gradient bins straight from global memory
-// (256 contiguous bytes per wave per bin, a whole bin row = up to 16 loads in flight before the first use).  Every map element is written exactly once with a plain
-// store: no float atomics (the ~1.3 TB/s atomic ceiling bound the per-RoI scatter version), no pre-zeroing, and a fixed
-// summation order (bit-reproducible).  Requires ph, pw <= 16.
-// ------------------------------------------------------------------------------------------
-constexpr int TILE = 8;      // tile edge in map pixels
-constexpr int BINS = 16;     // padded bins per axis
-constexpr int LIST_CAP = 4096;
-constexpr int BWD_TCH = 128;  // channels per block of the tiled backward: lane = 2 adjacent channels
-
-template <typename T> struct Pair;
-template <> struct Pair<float> {
-  typedef float __attribute__((ext_vector_type(2))) type;
-};
-template <> struct Pair<bf16_t> {
-  typedef bf16_t __attribute__((ext_vector_type(2))) type;
-};
-
-template <typename T>
-__global__ __launch_bounds__(256) void roi_align_bwd_tiled_kernel(
-    const T* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gfeat, int C, int H, int W, int R,
-    int ph, int pw, float scale, int sampling_ratio, int aligned, int tiles_x, int tiles_y) {
-  typedef typename Pair<T>::type pair_t;
-  __shared__ unsigned short list[LIST_CAP];
-  __shared__ int wave_cnt[4];
-  __shared__ int list_n;
-  __shared__ __attribute__((aligned(16))) float wxT[4][BINS][TILE];  // [wave][px][tx]
-  __shared__ float wyT[4][2][BINS];                                    // [wave][row][py]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = blockIdx.x;
-  const int tx0 = (tile % tiles_x) * TILE;
-  const int ty0 = ((tile / tiles_x) % tiles_y) * TILE;
-  const int n = tile / (tiles_x * tiles_y);
-  const int c = blockIdx.y * BWD_TCH + 2 * lane;  // this lane's channel pair (C is even on the NHWC path)
-  const bool c_ok = c < C;
-  const int y_a = ty0 + 2 * wave;  // this wave's two map rows: y_a, y_a + 1
-
-  float acc[2][TILE][2];
-#pragma unroll
-  for (int r = 0; r < 2; ++r)
-#pragma unroll
-    for (int t = 0; t < TILE; ++t) acc[r][t][0] = acc[r][t][1] = 0.f;
-
-  for (int base = 0; base < R; base += LIST_CAP) {
-    const int lim = (R - base) < LIST_CAP ? (R - base) : LIST_CAP;
-    // ---- ordered compaction of the RoIs of image n whose footprint may touch this tile
-    if (threadIdx.x == 0) list_n = 0;
-    __syncthreads();
-    for (int i0 = 0; i0 < lim; i0 += 256) {
-      const int i = i0 + threadIdx.x;
-      bool hit = false;
-      if (i < lim) {
-        const RoiGeom g = roi_geom(rois + (size_t)(base + i) * 5, ph, pw, scale, sampling_ratio, aligned);
-        if (g.n == n && g.gh > 0 && g.gw > 0) {
-          // conservative footprint: first / last sample of each axis, +-1 pixel for the bilinear taps (the border rows /
-          // columns also collect the clamped samples from [-1, 0] and [size-1, size])
-          const float ys0 = g.y0 + 0.5f * g.bh / (float)g.gh, ys1 = g.y0 + ((float)(ph - 1) + ((float)g.gh - 0.5f) / (float)g.gh) * g.bh;
-          const float xs0 = g.x0 + 0.5f * g.bw / (float)g.gw, xs1 = g.x0 + ((float)(pw - 1) + ((float)g.gw - 0.5f) / (float)g.gw) * g.bw;
-          const float ylo = fminf(ys0, ys1), yhi = fmaxf(ys0, ys1), xlo = fminf(xs0, xs1), xhi = fmaxf(xs0, xs1);
-          hit = (yhi >= (float)(ty0 - 1)) && (ylo <= (float)(ty0 + TILE)) && (xhi >= (float)(tx0 - 1)) && (xlo <= (float)(tx0 + TILE));
-        }
-      }
-      const unsigned long long m = __ballot(hit);
-      if (lane == 0) wave_cnt[wave] = __popcll(m);
-      __syncthreads();
-      int off = list_n;
-      for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-      if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
-      __syncthreads();
-      if (threadIdx.x == 0) list_n += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-      __syncthreads();
-    }
-    const int nlist = list_n;
-    // ---- each wave walks the list for its own two rows
-    for (int li = 0; li < nlist; ++li) {
-      const int roi = base + (int)list[li];
-      const RoiGeom g = roi_geom(rois + (size_t)roi * 5, ph, pw, scale, sampling_ratio, aligned);
-      // weights: lane -> (px, tx) pairs for the columns, lanes 0..31 -> (row, py) pairs
-#pragma unroll
-      for (int k = 0; k < (TILE * BINS) / 64; ++k) {
-        const int p = lane + 64 * k;
-        const int px = p / TILE, tx = p % TILE;
-        wxT[wave][px][tx] = px < pw ? bin_weight(g.x0, g.bw, g.gw, px, tx0 + tx, W) : 0.f;
-      }
-      if (lane < 2 * BINS) {
-        const int row = lane / BINS, py = lane % BINS;
-        wyT[wave][row][py] = py < ph ? bin_weight(g.y0, g.bh, g.gh, py, y_a + row, H) * g.inv_count : 0.f;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // bins whose weights are not all zero (uniform across the wave)
-      const float wr = lane < BINS ? fabsf(wyT[wave][0][lane]) + fabsf(wyT[wave][1][lane]) : 0.f;
-      const unsigned rowmask = (unsigned)__ballot(wr != 0.f);
-      float wc = 0.f;
-      if (lane < BINS) {
-#pragma unroll
-        for (int t = 0; t < TILE; ++t) wc += fabsf(wxT[wave][lane][t]);
-      }
-      const unsigned colmask = (unsigned)__ballot(wc != 0.f);
-      if (rowmask != 0 && colmask != 0) {
-        const T* __restrict__ go = gout + (size_t)roi * ph * pw * C + (c_ok ? c : 0);
-        for (int py = 0; py < ph; ++py) {
-          if (!((rowmask >> py) & 1u)) continue;
-          const float a0 = wyT[wave][0][py], a1 = wyT[wave][1][py];
-          // all bins of this row that can matter are requested before the first is used (up to 16 x 256 B in flight per wave)
-          pair_t v[BINS];
-#pragma unroll
-          for (int grp = 0; grp < BINS / 4; ++grp) {
-            if ((colmask >> (4 * grp)) & 0xFu) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                int px = 4 * grp + j;
-                px = px < pw ? px : pw - 1;  // padded bins carry zero weight
-                v[4 * grp + j] = *reinterpret_cast<const pair_t*>(go + (size_t)(py * pw + px) * C);
-              }
-            }
-          }
-          float sacc[TILE][2];
-#pragma unroll
-          for (int t = 0; t < TILE; ++t) sacc[t][0] = sacc[t][1] = 0.f;
-#pragma unroll
-          for (int grp = 0; grp < BINS / 4; ++grp) {
-            if ((colmask >> (4 * grp)) & 0xFu) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(&wxT[wave][4 * grp + j][0]);
-                const f32x4 w1 = *reinterpret_cast<const f32x4*>(&wxT[wave][4 * grp + j][4]);
-                const float v0 = (float)v[4 * grp + j][0], v1 = (float)v[4 * grp + j][1];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                  sacc[t][0] += w0[t] * v0;
-                  sacc[t][1] += w0[t] * v1;
-                  sacc[4 + t][0] += w1[t] * v0;
-                  sacc[4 + t][1] += w1[t] * v1;
-                }
-              }
-            }
-          }
-#pragma unroll
-          for (int t = 0; t < TILE; ++t) {
-            acc[0][t][0] += a0 * sacc[t][0];
-            acc[0][t][1] += a0 * sacc[t][1];
-            acc[1][t][0] += a1 * sacc[t][0];
-            acc[1][t][1] += a1 * sacc[t][1];
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();  // the table is rewritten for the next RoI
-    }
-    __syncthreads();  // list is rebuilt for the next chunk of RoIs
-  }
-  if (!c_ok) return;
-  float* __restrict__ gmap = gfeat + (size_t)n * H * W * C + c;
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int y = y_a + r;
-    if (y >= H) continue;
-#pragma unroll
-    for (int t = 0; t < TILE; ++t) {
-      const int x = tx0 + t;
-      if (x < W) {
-        float __attribute__((ext_vector_type(2))) o = {acc[r][t][0], acc[r][t][1]};
-        *reinterpret_cast<float __attribute__((ext_vector_type(2)))*>(gmap + ((size_t)y * W + x) * C) = o;
-      }
-    }
-  }
-}
-
+constexpr int LIST_CAP = 4096;  // RoIs per tile list (ordered compaction)
 
 // ------------------------------------------------------------------------------------------
 // backward, NHWC, atomic-free gather per map tile (the shipped NHWC path for ph, pw <= 16):
@@ -577,8 +402,8 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tiled_kernel(
 //   phase 0: ordered compaction of the RoIs whose footprint may touch the tile;
 //   phase 1 (per 32 list entries, whole block): the bilinear weight tables of those RoIs restricted to the tile -- one thread
 //            per (RoI, axis, bin) walks the bin's samples once (the forward's arithmetic) -- plus bit masks of the non-zero
-//            entries.  The previous kernel recomputed these per wave and per 128-channel block (32x redundant) inside its
-//            load -> use chain; now they are off the critical path and the inner loop is loads + FMAs only;
+//            entries.  Round 1's kernel (8x8 tile, wave-private tables) recomputed these per wave and per 128-channel block
+//            (32x redundant) inside its load -> use chain; now they are off the critical path and the inner loop is loads + FMAs;
 //   phase 2: each wave streams the gradient bins with non-zero weight on its row: 16 bytes per lane per bin (1 KiB per
 //            wave-instruction), four bins in flight, converted once and fanned out to the <= 3 tile columns they touch.
 // ------------------------------------------------------------------------------------------
