@@ -63,7 +63,7 @@ class CoinTrainer(BASE_Trainer):
         self.scheduler = build_lr_scheduler(cfg, self.optimizer)
         self.scheduler_merge = build_lr_scheduler(cfg, self.optimizer_merge)
         if data_loader is None:
-            assert cfg.AMD.SYNTHETIC.ENABLED, "only the synthetic loader is built in (the input pipeline is out of scope)"
+            assert cfg.AMD.SYNTHETIC.ENABLED, "pass data_loader= (coin_amd.data.build_detection_unsupervised_train_loader) when AMD.SYNTHETIC is off"
             per_gpu = cfg.SOLVER.IMG_PER_BATCH_UNLABEL // self.world_size
             assert per_gpu >= 1 and cfg.SOLVER.IMG_PER_BATCH_UNLABEL % self.world_size == 0  # coin/data/build.py:153-157
             data_loader = SyntheticTwoViewLoader(per_gpu, cfg.AMD.SYNTHETIC.HEIGHT, cfg.AMD.SYNTHETIC.WIDTH, len(cfg.AMD.CLASS_NAMES),

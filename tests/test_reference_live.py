@@ -49,3 +49,19 @@ def test_committed_fixtures_are_reproduced_by_the_reference(tmp_path, cases, fil
                 np.testing.assert_allclose(new[k], old[k], rtol=1e-6, atol=1e-7, err_msg=f"{f}:{k}")
             else:
                 assert (new[k] == old[k]).all(), f"{f}:{k}"
+
+
+def test_dataset_catalog_equals_the_references_registration_table():
+    """coin_amd/data/catalog.py against the SPLITS literal and the class tuples of register_all_pascal_voc (builtin.py:121-170), read as
+    text (the module itself imports detectron2 / fvcore, which are absent)."""
+    import ast
+    import re
+
+    sys.path.insert(0, os.path.dirname(HERE))
+    from coin_amd.data.catalog import CLASSES, SPLITS
+
+    src = open(os.path.join(REF, "coin", "data", "datasets", "builtin.py")).read()
+    rows = re.findall(r"\(\s*['\"]([\w\.]+)['\"]\s*,\s*['\"](\w+)['\"]\s*,\s*['\"]([\w\.]+)['\"]\s*,\s*(\d+)\s*,\s*['\"](\w+)['\"]\s*\)", src)
+    assert {r[0]: (r[1], r[2], int(r[3]), r[4]) for r in rows} == SPLITS and len(rows) == 15
+    for n, tup in re.findall(r"cls\s*==\s*(\d+):\s*class_names\s*=\s*(\([^)]*\))", src):
+        assert tuple(ast.literal_eval(tup)) == CLASSES[int(n)], n

@@ -67,7 +67,27 @@ def main(args):
             f.write(args.info)
     torch.backends.cudnn.benchmark = True
     torch.manual_seed(cfg.SEED + (dist.get_rank() if dist.is_initialized() else 0))  # util.py:89-90: per-rank seed
-    trainer = trainers[cfg.CLOUD.Trainer](cfg)
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+    if cfg.AMD.SYNTHETIC.ENABLED:
+        trainer = trainers[cfg.CLOUD.Trainer](cfg)
+    else:
+        # real data (coin/data/build.py:102-176): the unlabelled target set by name -> VOC dataset dicts -> sampler -> image decode threads
+        # -> strong / weak views on the GPU -> two-crop batches; the cached teacher results arrive with MODEL.WEIGHTS (resume_or_load)
+        import os.path as osp
+
+        from coin_amd.data import build_detection_test_loader, build_detection_unsupervised_train_loader
+        from coin_amd.data.catalog import SPLITS, dataset_root, get_detection_dataset_dicts, thing_classes
+        from coin_amd.evaluation import PascalVOCEvaluator
+
+        if not cfg.AMD.CLASS_NAMES:  # the dataset's thing classes (MetadataCatalog.get(name).thing_classes in the reference)
+            cfg.AMD.CLASS_NAMES = list(thing_classes(cfg.DATASETS.TRAIN_UNLABEL[0]))
+        loader = build_detection_unsupervised_train_loader(cfg, get_detection_dataset_dicts(cfg.DATASETS.TRAIN_UNLABEL), rank=rank, world_size=world)
+        trainer = trainers[cfg.CLOUD.Trainer](cfg, data_loader=loader)
+        if cfg.DATASETS.TEST and cfg.TEST.EVAL_PERIOD >= 0:
+            name = cfg.DATASETS.TEST[0]
+            dirname, split = osp.join(dataset_root(), SPLITS[name][0]), SPLITS[name][1]
+            items = [b[0] for b in build_detection_test_loader(cfg, get_detection_dataset_dicts([name]))]
+            trainer.set_evaluation(items, lambda: PascalVOCEvaluator(dirname, split, thing_classes(name), year=2012))
     if hasattr(trainer, "resume_or_load"):
         trainer.resume_or_load(resume=args.resume)
     trainer.train()
