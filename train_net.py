@@ -7,7 +7,8 @@
 Same flags (``--config-file``, ``--resume``, ``--eval-only``, ``--num-gpus``, ``--num-machines``, ``--machine-rank``, ``--dist-url``,
 ``--info``, ``--test_model_role``, trailing ``KEY VALUE`` overrides) and the same dispatch on ``cfg.CLOUD.Trainer``.  Only the
 trainers of the adaptation-training hot path exist here: ``PRETRAIN`` -> PRETrainer, ``CoinTrainer`` -> CoinTrainer; the collectors
-(GDINO / GLIP / CLIP), ORACLE and evaluation-only modes are outside the scope of this build and say so.
+(GDINO / GLIP / CLIP), ORACLE and evaluation-only modes are outside the scope of this build and say so.  With ``AMD.SYNTHETIC.ENABLED``
+off the datasets named in ``DATASETS.TRAIN_UNLABEL`` / ``DATASETS.TEST`` are read from ``$DETECTRON2_DATASETS`` (VOC layout).
 One process per GPU: with ``--num-gpus N > 1`` the script re-launches itself through ``torch.distributed.run`` (RCCL over xGMI).
 """
 from __future__ import annotations
