@@ -189,6 +189,15 @@ def test_matcher_upstream_published_values():
     assert labels.tolist() == [-1, 1, 0, 1]
 
 
+def test_pairwise_iou_upstream_published_values():
+    """detectron2 v0.5 tests/structures/test_boxes.py (`TestBoxIOU.test_pairwise_iou`)."""
+    b1 = d2.Boxes(torch.tensor([[0.0, 0.0, 1.0, 1.0], [0.0, 0.0, 1.0, 1.0]]))
+    b2 = d2.Boxes(torch.tensor([[0.0, 0.0, 1.0, 1.0], [0.0, 0.0, 0.5, 1.0], [0.0, 0.0, 1.0, 0.5], [0.0, 0.0, 0.5, 0.5], [0.5, 0.5, 1.0, 1.0],
+                                [0.5, 0.5, 1.5, 1.5]]))
+    row = [1.0, 0.5, 0.5, 0.25, 0.25, 0.25 / (2 - 0.25)]
+    torch.testing.assert_close(d2.pairwise_iou(b1, b2), torch.tensor([row, row]), rtol=0, atol=1e-6)
+
+
 def test_roi_align_border_rules():
     feat = np.arange(16, dtype=np.float64).reshape(1, 1, 4, 4)
     # one bin, one sample (roi 1x1 -> grid ceil(1/1)=1) at y = x = -0.75 (inside the [-1, H] band: clamped to 0 -> f(0,0) = 0 ..)
