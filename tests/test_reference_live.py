@@ -35,6 +35,14 @@ for name, arrays in captured.items():
     (["case_voc_eval"], ["voc_eval"]),
     (["case_clip_relabel"], ["clip_relabel"]),
     (["case_real_width"], ["real_width_res5", "real_width_box_predictor"]),
+    (["case_rn101"], ["rn101_res4", "rn101_ckg"]),
+    (["case_box_predictor_pretrain"], ["box_predictor_pretrain_a", "box_predictor_pretrain_empty_image", "box_predictor_pretrain_no_fg",
+                                       "box_predictor_pretrain_clipart", "box_predictor_pretrain_focal"]),
+    (["case_rpn", "case_roi_sampling"], ["rpn", "roi_sampling"]),
+    (["case_bottleneck", "case_resnet"], ["bottleneck_layer4", "resnet_res4"]),
+    (["case_box_predictor_step"], ["box_predictor_one", "box_predictor_one_noproto", "box_predictor_two", "box_predictor_two_noB", "box_predictor_two_nobg_noC"]),
+    (["case_text_encoder", "case_lr_and_fusion"], ["text_encoder", "clip_tokens", "lr_fusion_process"]),
+    (["case_e2e_pretrain", "case_e2e_step_and_inference"], ["e2e_pretrain", "e2e_step_two", "inference"]),
 ])
 def test_committed_fixtures_are_reproduced_by_the_reference(tmp_path, cases, files):
     golden = os.path.join(HERE, "golden")
