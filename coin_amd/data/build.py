@@ -58,6 +58,9 @@ class _MappedStream:
                 if len(pending) > self.threads:
                     d0, fut = pending.popleft()
                     yield self.mapper(d0, image=fut.result())
+            while pending:  # a finite sampler: hand out what is still being decoded
+                d0, fut = pending.popleft()
+                yield self.mapper(d0, image=fut.result())
 
 
 def build_unsupervised_batch_data_loader(dataset_dicts: Sequence[Dict], sampler, mapper, total_batch_size_unlabel: int, *, world_size: int = 1,
