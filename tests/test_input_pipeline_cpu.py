@@ -125,3 +125,28 @@ def test_test_loader_maps_every_image_once_in_shards(tmp_path):
     for b, a in zip(got, imgs):
         oh, ow = A.shortest_edge_size(a.shape[0], a.shape[1], 48, 64)
         assert np.array_equal(b[0]["image"].numpy(), A.resize_bilinear(a, oh, ow).transpose(2, 0, 1)) and b[0]["random_flip"] == "no"
+
+
+def test_catalog_names_and_errors(tmp_path):
+    import pytest
+
+    from coin_amd.data.catalog import get_detection_dataset_dicts, thing_classes
+
+    assert thing_classes("foggytrain_0.02") == ("truck", "car", "rider", "person", "train", "motorcycle", "bicycle", "bus")
+    assert thing_classes("BDD100Ktrain")[0] == "person" and len(thing_classes("cliparttrain")) == 20
+    with pytest.raises(KeyError, match="not registered"):
+        get_detection_dataset_dicts(["no_such_set"], root=str(tmp_path))
+
+
+def test_read_image_formats(tmp_path):
+    from PIL import Image
+
+    from coin_amd.data.dataset_mapper import read_image
+
+    a = np.random.default_rng(9).integers(0, 256, (12, 17, 3), dtype=np.uint8)
+    Image.fromarray(a, "RGB").save(tmp_path / "a.png")
+    assert np.array_equal(read_image(str(tmp_path / "a.png"), "RGB"), a)
+    assert np.array_equal(read_image(str(tmp_path / "a.png"), "BGR"), a[:, :, ::-1])
+    Image.fromarray(a[:, :, 0], "L").save(tmp_path / "g.png")                      # a grey file is expanded to three channels
+    g = read_image(str(tmp_path / "g.png"), "RGB")
+    assert g.shape == (12, 17, 3) and np.array_equal(g[..., 0], a[:, :, 0]) and np.array_equal(g[..., 0], g[..., 2])
