@@ -20,6 +20,7 @@
 //     tile) are taken during that store pass -- the separate statistics pass over the activation (coin_bn_stats) disappears.
 #include <stdlib.h>
 #include "common.h"
+#include "conv_gemm_p8.h"
 
 namespace {
 
@@ -661,6 +662,8 @@ __global__ __launch_bounds__(1024) void conv_stats_finalize_kernel(const float* 
 
 }  // namespace
 
+int coin_conv_gemm_force_impl = 0;  // lab hook (tools/gemm_lab.hip): 0 = environment / default, 1 = p8, 2 = sq, 3 = rect
+
 extern "C" size_t coin_conv_gemm_stats_bytes(int M, int N) {
   if (M <= 0 || N <= 0) return 0;
   return (size_t)((M + GM - 1) / GM) * 3 * (size_t)N * sizeof(float);
@@ -685,7 +688,16 @@ extern "C" int coin_conv_gemm_bf16(const void* A, int lda, int mode, int H, int 
   const bf16_t* a = (const bf16_t*)A;
   const bf16_t* b = (const bf16_t*)B;
   bf16_t* c = (bf16_t*)C;
-  static const int force_rect = [] { const char* e = getenv("COIN_CONV_GEMM_TILE"); return e && e[0] == '1' ? 1 : 0; }();  // measurements only
+  // COIN_CONV_GEMM_IMPL (measurements only): "p8" / unset = the persistent 8-phase core where the shape fits it, "sq" = the 256x256x32
+  // kernel of round 2, "rect" = the 256x128x64 kernel
+  static const int env_impl = [] {
+    const char* e = getenv("COIN_CONV_GEMM_IMPL");
+    return !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 'r' ? 2 : 0));
+  }();
+  const int impl = coin_conv_gemm_force_impl ? coin_conv_gemm_force_impl - 1 : env_impl;
+  if (impl == 0 && coin_p8_nt_ok(M, N, K, mode, Cin))
+    return coin_p8_nt_launch(A, lda, mode, H, W, Cin, B, ldb, C, ldc, R, ldr, M, N, K, stats, (long long)stats_rows, 0, st);
+  const int force_rect = impl == 2;
   if (N % QN == 0 && !force_rect) {
     const int tm = (M + QM - 1) / QM, tn = N / QN;
     const size_t lds = (size_t)QNSTAGE * QSTAGE_BYTES;
@@ -744,7 +756,9 @@ static int wgrad_slices(int M, int tiles) {
 
 extern "C" size_t coin_conv_wgrad_workspace_bytes(int M, int Cout, int Ktot) {
   if (M <= 0 || Cout <= 0 || Ktot <= 0 || Cout % WB || Ktot % WB) return 0;
-  return (size_t)wgrad_slices(M, (Cout / WB) * (Ktot / WB)) * Cout * (size_t)Ktot * sizeof(float);
+  const size_t sliced = (size_t)wgrad_slices(M, (Cout / WB) * (Ktot / WB)) * Cout * (size_t)Ktot * sizeof(float);
+  const size_t p8 = coin_p8_tn_workspace_bytes(M, Cout, Ktot);  // either kernel may be selected at launch
+  return sliced > p8 ? sliced : p8;
 }
 
 extern "C" int coin_conv_wgrad_bf16(const void* GY, const void* X, int mode, int H, int W, int Cin, int M, int Cout, int Ktot, float* dW,
@@ -753,6 +767,10 @@ extern "C" int coin_conv_wgrad_bf16(const void* GY, const void* X, int mode, int
   if (Cout % WB || Cin % WB) return COIN_ESHAPE;
   if (mode == 0 ? Ktot != Cin : (Ktot != 9 * Cin || H <= 0 || W <= 0 || M % (H * W))) return COIN_EINVAL;
   if (((uintptr_t)GY & 15) || ((uintptr_t)X & 15) || ((uintptr_t)dW & 15) || ((uintptr_t)workspace & 15)) return COIN_EALIGN;
+  static const int env_old = [] { const char* e = getenv("COIN_CONV_WGRAD_IMPL"); return e && e[0] == 's' ? 1 : 0; }();  // measurements only
+  const bool use_old = coin_conv_gemm_force_impl ? coin_conv_gemm_force_impl != 1 : env_old != 0;
+  if (!use_old && coin_p8_tn_ok(M, Cout, Cin, Ktot, mode))
+    return coin_p8_tn_launch(GY, X, mode, H, W, Cin, M, Cout, Ktot, dW, workspace, (hipStream_t)stream);
   const int tco = Cout / WB, tk = Ktot / WB;
   const int slices = wgrad_slices(M, tco * tk);
   int m_chunk = (M + slices - 1) / slices;

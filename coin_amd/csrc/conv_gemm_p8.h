@@ -1,0 +1,15 @@
+// Internal interface between conv_gemm.hip (the C-ABI entry points) and conv_gemm_p8.hip (the persistent 256x256x64 cores).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define COIN_HIDDEN __attribute__((visibility("hidden")))
+
+COIN_HIDDEN bool coin_p8_nt_ok(int M, int N, int K, int mode, int Cin);
+COIN_HIDDEN int coin_p8_nt_launch(const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb, void* C, int ldc, const void* R,
+                                  int ldr, int M, int N, int K, float* stats, long long stats_rows, int grid_override, hipStream_t st);
+COIN_HIDDEN bool coin_p8_tn_ok(int M, int Cout, int Cin, int Ktot, int mode);
+COIN_HIDDEN size_t coin_p8_tn_workspace_bytes(int M, int Cout, int Ktot);
+COIN_HIDDEN int coin_p8_tn_launch(const void* GY, const void* X, int mode, int H, int W, int Cin, int M, int Cout, int Ktot, float* dW, void* workspace,
+                                  hipStream_t st);
+COIN_HIDDEN extern int coin_conv_gemm_force_impl;
+COIN_HIDDEN extern int coin_p8_debug;

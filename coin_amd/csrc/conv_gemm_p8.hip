@@ -1,0 +1,891 @@
+// Persistent 256 x 256 x 64 bf16 GEMM cores for the res5 convolutions on the RoI tiles (gfx950):
+//   p8 "NT":  C[M, N] = A[M, K] . B[N, K]^T   forward + data gradient of coin/modeling/utils.py:77-90,184-186 (1x1 = NHWC GEMM,
+//             3x3 / pad 1 = implicit GEMM), bf16 output rows + BatchNorm statistics partials + residual add in the epilogue;
+//   p8 "TN":  dW[Cout, Ktot] = gy[M, Cout]^T . xcol[M, Ktot]   the weight gradient of the same convolutions (fp32 output).
+// Entry points: coin_conv_gemm_bf16 / coin_conv_wgrad_bf16 in conv_gemm.hip dispatch here.
+//
+// Schedule (both): 8 waves = 2 groups of 4 (G0 = waves 0-3, G1 = waves 4-7; one wave of each group per SIMD).  A K-tile is 64 deep
+// and consists of four 16 KiB half-tiles (A-lo, A-hi, B-lo, B-hi: 128 rows of the operand each); LDS holds two K-tiles (128 KiB)
+// plus a 32 KiB epilogue image.  Every wave owns a 128 x 64 piece of the output made of four 64 x 32 quadrants, one from each
+// (A half, B half) pair, so that every wave reads every half-tile exactly once per K-tile:
+//   phase 1: read b0 (4 x ds_read_b128) + a0 (8)   -> 16 MFMA  acc[0][0] += a0 . b0
+//   phase 2: read b1 (4)                           -> 16 MFMA  acc[0][1] += a0 . b1
+//   phase 3: read a1 (8)                           -> 16 MFMA  acc[1][1] += a1 . b1
+//   phase 4: -                                     -> 16 MFMA  acc[1][0] += a1 . b0
+// Each phase is  {reads; ONE half-tile of LDS-DMA (2 x global_load_lds_dwordx4 per lane); s_barrier; MFMAs; s_barrier}, and G1 runs
+// one barrier behind G0: while one group's MFMAs occupy the matrix pipes, the other group's LDS reads and DMA issue run beside them.
+// The DMA stream is never drained inside the loop: phase p of K-tile g issues  p=1: A-hi(g+1), p=2: B-lo(g+2), p=3: A-lo(g+2),
+// p=4: B-hi(g+2); each half-tile is waited for in the phase before its first read with `s_waitcnt vmcnt(10)` (five half-tiles = 80 KiB
+// stay in flight; a load has at least five phases to land.  Round 3 measurement: with one `vmcnt(6)` per K-tile the wait came three
+// phases after the issue and the 1x1 layers lost a quarter of their rate to memory latency).
+// LDS hazards: a half-tile is re-staged two phases after the phase that read it (one phase after for B-lo, whose reads are retired by
+// an `lgkmcnt(8)` ahead of phase 1's first barrier); a staged half-tile is first read in the phase after the barrier that follows
+// its wait.  The kernels are persistent (one workgroup per CU) and the K-tile sequence runs across output tiles: the first K-tile of
+// the next tile has landed when the epilogue of the current one starts.
+#include <stdlib.h>
+#include "common.h"
+#include "conv_gemm_p8.h"
+
+namespace {
+
+constexpr int PM = 256, PN = 256, PK = 64;
+constexpr int P_HALF = 128 * PK * 2;   // 16 KiB
+constexpr int P_KT = 4 * P_HALF;       // A-lo | A-hi | B-lo | B-hi
+constexpr int P_IMG = 2 * P_KT;        // epilogue image: 128 rows x 256 B
+constexpr int P_LDS = P_IMG + 128 * 256;
+
+__device__ __attribute__((aligned(256))) unsigned char p8_zero_page[512];  // 3x3 taps outside the image / pixels beyond M
+
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+#define P8_SCHED() __builtin_amdgcn_sched_barrier(0)
+// raw barrier (no counter is waited for: LDS-DMA stays in flight across it) + a compiler-level memory fence
+#define P8_BAR()                      \
+  do {                                \
+    asm volatile("" ::: "memory");    \
+    __builtin_amdgcn_s_barrier();     \
+    asm volatile("" ::: "memory");    \
+  } while (0)
+// epilogue barrier: this wave's LDS accesses are complete, then the workgroup barrier; global loads / stores / DMA are NOT waited for
+#define P8_LDS_SYNC()                                   \
+  do {                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_s_barrier();                       \
+    asm volatile("" ::: "memory");                      \
+    P8_SCHED();                                         \
+  } while (0)
+
+// XCD-aware order of the persistent walk: logical item `it` (block b = it % G in round it / G) -> position in the tile list such
+// that the blocks of one XCD (equal b % 8) work on neighbouring positions (which share operand panels) in every round.
+__device__ __forceinline__ int p8_remap(int it, int G, int ntiles) {
+  const int r = it / G, b = it - r * G;
+  const int left = ntiles - r * G, S = left < G ? left : G;
+  const int x = b & 7, i = b >> 3, q = S >> 3, rr = S & 7;
+  return r * G + (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + i;
+}
+
+struct P8Args {
+  const bf16_t* A; int lda;
+  const bf16_t* B; int ldb;
+  bf16_t* C; int ldc;
+  const bf16_t* R; int ldr;
+  int M, N, K, H, W, Cin;
+  float* stats; long long stats_rows;
+  int tiles_m, tiles_n;
+  int dbg;  // lab only: bit 0 = every A / B DMA reads the zero page
+};
+
+// ---------------------------------------------------------------------------------------------------------------- NT kernel
+// LDS image of a half-tile: 128 rows x 128 B; one DMA instruction writes 8 rows; 16-byte chunk c of row r sits at chunk c ^ (r & 7)
+// (applied on the SOURCE address; the fragment reads apply the same XOR): conflict-free ds_read_b128 for the 16x16x32 operands.
+template <bool GATHER3>
+struct NtCursor {
+  const bf16_t* a[4];  // [A-lo e0, A-lo e1, A-hi e0, A-hi e1]: this lane's source rows (+ swizzled chunk); 3x3: the centre pixel
+  const bf16_t* b[4];
+  unsigned taps[4];
+  int kt, it, buf;
+};
+
+template <bool GATHER3>
+__device__ __forceinline__ void nt_set_tile(NtCursor<GATHER3>& c, const P8Args& p, int tile, int wave, int lane) {
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int rl = lane >> 3, sc = ((lane & 7) ^ rl) * 8;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int rloc = h * 128 + (wave * 2 + e) * 8 + rl;
+      int row = tm * PM + rloc;
+      row = row < p.M ? row : p.M - 1;
+      if (GATHER3) {
+        const int hw = p.H * p.W;
+        const int nb = row / hw, rem = row - nb * hw;
+        const int oy = rem / p.W, ox = rem - oy * p.W;
+        unsigned m = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int yy = oy + t / 3 - 1, xx = ox + t % 3 - 1;
+          m |= (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W ? 1u : 0u) << t;
+        }
+        c.taps[h * 2 + e] = m;
+        c.a[h * 2 + e] = p.A + (size_t)row * p.Cin + sc;
+      } else {
+        c.taps[h * 2 + e] = 0;
+        c.a[h * 2 + e] = p.A + (size_t)row * p.lda + sc;
+      }
+      c.b[h * 2 + e] = p.B + (size_t)(tn * PN + rloc) * p.ldb + sc;  // N % 256 == 0: always inside
+    }
+}
+
+// which: 0 = B-lo, 1 = A-lo, 2 = B-hi, 3 = A-hi of the cursor's K-tile
+template <bool GATHER3, int WHICH>
+__device__ __forceinline__ void nt_stage(const NtCursor<GATHER3>& c, const P8Args& p, char* lds, int wave, int lane) {
+  constexpr bool IS_A = (WHICH & 1) != 0;
+  constexpr int H = WHICH >> 1;
+  char* dst = lds + c.buf * P_KT + (IS_A ? 0 : 2 * P_HALF) + H * P_HALF + wave * 2048;
+  if (IS_A) {
+    if (GATHER3) {
+      const int chunk = c.kt / 9, tap = c.kt - chunk * 9;
+      const long long shift = ((long long)(tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.Cin + chunk * PK;
+      const bf16_t* zp = reinterpret_cast<const bf16_t*>(p8_zero_page) + (((lane & 7) ^ (lane >> 3)) * 8);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const bf16_t* src = ((c.taps[H * 2 + e] >> tap) & 1u) ? c.a[H * 2 + e] + shift : zp;
+        glds16(src, dst + e * 1024);
+      }
+    } else {
+      const bf16_t* zp = reinterpret_cast<const bf16_t*>(p8_zero_page) + (((lane & 7) ^ (lane >> 3)) * 8);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) glds16((p.dbg & 1) ? zp : c.a[H * 2 + e] + c.kt * PK, dst + e * 1024);
+    }
+  } else {
+    int koff = c.kt * PK;
+    if (GATHER3) {
+      const int chunk = c.kt / 9, tap = c.kt - chunk * 9;
+      koff = tap * p.Cin + chunk * PK;
+    }
+    const bf16_t* zpb = reinterpret_cast<const bf16_t*>(p8_zero_page) + (((lane & 7) ^ (lane >> 3)) * 8);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) glds16((p.dbg & 1) ? zpb : c.b[H * 2 + e] + koff, dst + e * 1024);
+  }
+}
+
+template <bool GATHER3, bool STATS>
+__global__ __launch_bounds__(512) void conv_gemm_p8_kernel(const P8Args p) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int G = gridDim.x, ntiles = p.tiles_m * p.tiles_n, nk = p.K / PK;
+  int it_c = blockIdx.x;
+  if (it_c >= ntiles) return;
+  const int my_tiles = (ntiles - 1 - it_c) / G + 1;
+  const int total_kt = my_tiles * nk;
+
+  NtCursor<GATHER3> cur;
+  cur.kt = 0;
+  cur.it = it_c;
+  cur.buf = 0;
+  nt_set_tile<GATHER3>(cur, p, p8_remap(cur.it, G, ntiles), wave, lane);
+  auto advance = [&]() {
+    cur.buf ^= 1;
+    if (++cur.kt == nk) {
+      cur.kt = 0;
+      cur.it += G;
+      if (cur.it < ntiles) nt_set_tile<GATHER3>(cur, p, p8_remap(cur.it, G, ntiles), wave, lane);
+    }
+  };
+
+  // ---- prologue: K-tile 0 (four half-tiles) and three half-tiles of K-tile 1
+  nt_stage<GATHER3, 0>(cur, p, lds, wave, lane);
+  nt_stage<GATHER3, 1>(cur, p, lds, wave, lane);
+  nt_stage<GATHER3, 2>(cur, p, lds, wave, lane);
+  nt_stage<GATHER3, 3>(cur, p, lds, wave, lane);
+  advance();
+  nt_stage<GATHER3, 0>(cur, p, lds, wave, lane);
+  nt_stage<GATHER3, 1>(cur, p, lds, wave, lane);
+  nt_stage<GATHER3, 2>(cur, p, lds, wave, lane);
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // B-lo(0), A-lo(0) have landed; B-hi(0), A-hi(0) are waited for in phases 1, 2
+  P8_BAR();
+
+  // ---- fragment read offsets inside a K-tile buffer
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int sw = ((ks * 4 + fq) ^ (fr & 7)) << 4;
+    a_off[ks] = (wr * 64 + fr) * 128 + sw;
+    b_off[ks] = 2 * P_HALF + (wc * 32 + fr) * 128 + sw;
+  }
+
+  int g = 0;  // K-tile sequence number of this workgroup (buffer g & 1)
+  for (;;) {
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[x][y][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (wr == 1) P8_BAR();  // G1 runs one barrier behind G0
+    for (int kt = 0; kt < nk; ++kt, ++g) {
+      const char* kb = lds + (g & 1) * P_KT;
+      bf16x8 af[4][2], b0[2][2], b1[2][2];
+      // ------------------------------------------------ phase 1
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) b0[j][ks] = *reinterpret_cast<const bf16x8*>(kb + b_off[ks] + j * 2048);
+      P8_SCHED();
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) af[i][ks] = *reinterpret_cast<const bf16x8*>(kb + a_off[ks] + i * 2048);
+      P8_SCHED();
+      if (g + 1 < total_kt) {
+        nt_stage<GATHER3, 3>(cur, p, lds, wave, lane);  // A-hi(g+1)
+        advance();                                       // cursor -> K-tile g+2
+      }
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the B-lo reads are back: B-lo may be re-staged in phase 2
+      if (g + 1 < total_kt)
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // B-hi(g) has landed (read in phase 2)
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      P8_SCHED();
+      P8_BAR();
+      P8_SCHED();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[0][0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j][ks], af[i][ks], acc[0][0][i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      P8_SCHED();
+      P8_BAR();
+      P8_SCHED();
+      // ------------------------------------------------ phase 2
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) b1[j][ks] = *reinterpret_cast<const bf16x8*>(kb + b_off[ks] + P_HALF + j * 2048);
+      P8_SCHED();
+      const bool more = g + 2 < total_kt;
+      if (more) {
+        nt_stage<GATHER3, 0>(cur, p, lds, wave, lane);  // B-lo(g+2)
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // A-hi(g) has landed (read in phase 3)
+      } else if (g + 1 < total_kt) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      P8_SCHED();
+      P8_BAR();
+      P8_SCHED();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[0][1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][ks], af[i][ks], acc[0][1][i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      P8_SCHED();
+      P8_BAR();
+      P8_SCHED();
+      // ------------------------------------------------ phase 3
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) af[i][ks] = *reinterpret_cast<const bf16x8*>(kb + a_off[ks] + P_HALF + i * 2048);
+      P8_SCHED();
+      if (more) nt_stage<GATHER3, 1>(cur, p, lds, wave, lane);  // A-lo(g+2)
+      P8_SCHED();
+      P8_BAR();
+      P8_SCHED();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[1][1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][ks], af[i][ks], acc[1][1][i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      P8_SCHED();
+      P8_BAR();
+      P8_SCHED();
+      // ------------------------------------------------ phase 4
+      if (more) {
+        nt_stage<GATHER3, 2>(cur, p, lds, wave, lane);  // B-hi(g+2)
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // B-lo(g+1), A-lo(g+1) have landed (this wave's part; the barrier publishes it)
+      } else if (g + 1 < total_kt) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      P8_SCHED();
+      P8_BAR();
+      P8_SCHED();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[1][0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j][ks], af[i][ks], acc[1][0][i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      P8_SCHED();
+      P8_BAR();
+      P8_SCHED();
+    }
+    if (wr == 0) P8_BAR();  // both groups aligned again
+
+    // ---- epilogue: four 128 x 128 quadrants through the 32 KiB image -> whole 256-byte rows (+ residual, + statistics)
+    const int tile = p8_remap(it_c, G, ntiles);
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * PM, n0 = tn * PN;
+    char* img = lds + P_IMG;
+    const int chunk = threadIdx.x & 15, rsub = threadIdx.x >> 4;
+#pragma unroll
+    for (int bh = 0; bh < 2; ++bh) {
+      float s1[8], s2[8], piv[8];
+#pragma unroll
+      for (int ah = 0; ah < 2; ++ah) {
+        // (the previous pass's readers are past their barrier below)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = wr * 64 + i * 16 + fr;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int ch = wc * 4 + j * 2 + (fq >> 1);
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[ah][bh][i][j][r];
+            *reinterpret_cast<bf16x4*>(img + row * 256 + ((ch ^ (row & 15)) << 4) + (fq & 1) * 8) = o;
+          }
+        }
+        P8_LDS_SYNC();
+        const int gcol = n0 + bh * 128 + chunk * 8;
+        if (STATS && ah == 0) {
+          const bf16x8 pv = *reinterpret_cast<const bf16x8*>(img + (chunk << 4));  // row 0 of the tile: every thread's pivot
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            piv[i] = (float)pv[i];
+            s1[i] = s2[i] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = q * 32 + rsub;
+          const int grow = m0 + ah * 128 + row;
+          bf16x8 v = *reinterpret_cast<const bf16x8*>(img + row * 256 + ((chunk ^ (row & 15)) << 4));
+          if (p.R != nullptr && grow < p.M) {  // C = bf16(bf16(A.B^T) + R): what two separate launches would store
+            const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.R + (size_t)grow * p.ldr + gcol);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (bf16_t)((float)v[i] + (float)r[i]);
+          }
+          if (grow < p.M) *reinterpret_cast<bf16x8*>(p.C + (size_t)grow * p.ldc + gcol) = v;
+          if (STATS && (long long)grow < p.stats_rows) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const float d = (float)v[i] - piv[i];
+              s1[i] += d;
+              s2[i] += d * d;
+            }
+          }
+        }
+        P8_LDS_SYNC();
+      }
+      if (STATS) {
+        // threads with equal `chunk`: lanes l, l ^ 16, l ^ 32 of a wave, then the 8 waves through the (free) image, fixed order
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          s1[i] += __shfl_xor(s1[i], 16, 64);
+          s2[i] += __shfl_xor(s2[i], 16, 64);
+          s1[i] += __shfl_xor(s1[i], 32, 64);
+          s2[i] += __shfl_xor(s2[i], 32, 64);
+        }
+        float* red = reinterpret_cast<float*>(img);  // [8 waves][16 chunks][16]
+        if (lane < 16) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            red[(wave * 16 + lane) * 16 + i] = s1[i];
+            red[(wave * 16 + lane) * 16 + 8 + i] = s2[i];
+          }
+          if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) red[8 * 16 * 16 + lane * 8 + i] = piv[i];
+          }
+        }
+        P8_LDS_SYNC();
+        if (threadIdx.x < 128) {
+          const int c = threadIdx.x, ch = c >> 3, ci = c & 7;
+          float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+          for (int w = 0; w < 8; ++w) {
+            a1 += red[(w * 16 + ch) * 16 + ci];
+            a2 += red[(w * 16 + ch) * 16 + 8 + ci];
+          }
+          float* __restrict__ part = p.stats + (size_t)tm * 3 * p.N + n0 + bh * 128 + c;
+          part[0] = red[8 * 16 * 16 + c];
+          part[p.N] = a1;
+          part[2 * (size_t)p.N] = a2;
+        }
+        P8_LDS_SYNC();
+      }
+    }
+    it_c += G;
+    if (it_c >= ntiles) break;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------- TN kernel
+// Weight gradient: dW[co][k] = sum over pixels m of gy[m][co] * xcol[m][k], k = tap * Cin + ci.  Output tile = 256 co x 256 k (one
+// tap), K-tile = 64 pixels.  Both operands are pixel-major, so a half-tile is [64 pixels][128 channels] (256-byte rows; one DMA
+// instruction = 4 rows) and the MFMA fragments (8 consecutive pixels of one channel per lane) are read with ds_read_b64_tr_b16.
+// 16-byte chunk c of row r sits at chunk c ^ (((r & 3) << 2) | ((r >> 2) & 3)): the two 4-row blocks a 32-lane half reads per
+// transposed read (8 rows apart) cover all 64 banks.
+// Work split (XCD-coherent): the pixels are cut into 8 segments, one per XCD (workgroups b, b + 8, ... share an XCD's L2); inside an
+// XCD each of the `cpx` workgroups owns ONE output tile and walks the whole segment, all of them at the same pixels at the same
+// time: the gy / x panels they stream are shared 16-fold in L2 (without that the 36 tiles of the 3x3 layer move 14.8 GB and the
+// kernel is HBM-bound).  Tiles left over after the full rounds (T % cpx) are split along the pixels again so that every workgroup
+// stays busy.  A workgroup keeps its accumulators for a whole item and writes one fp32 partial tile per item; tn_reduce_kernel sums
+// the partials of a tile in a fixed order (no atomics: bit-reproducible).
+struct TnArgs {
+  const bf16_t* GY;
+  const bf16_t* X;
+  float* slab;
+  int M, Cout, Cin, Ktot, H, W;
+  int tiles_k, ntiles, nkt, cpx;
+  unsigned magic_w;  // ceil(2^32 / W)
+  int hw, r64, r32;                   // H * W, 64 % hw, 32 % hw
+  unsigned g_bytes, x_bytes, x_bias;  // buffer sizes for the range-checked DMA; x is addressed from X - x_bias
+  int dbg;           // lab only (coin_p8_debug): bit 0 = every DMA returns zeros, bit 1 = no partial-tile stores
+};
+
+// item `idx` of workgroup b -> (tile, [kb, ke)); false = no such item.  Shared by the main kernel and the reduction.
+__host__ __device__ __forceinline__ bool tn_item(int b, int idx, int ntiles, int nkt, int cpx, int& tile, int& kb, int& ke) {
+  const int x = b & 7, j = b >> 3;
+  const int full = ntiles / cpx, r = ntiles - full * cpx;
+  const int sb = (int)((long long)x * nkt / 8), se = (int)((long long)(x + 1) * nkt / 8);
+  if (idx < full) {
+    tile = idx * cpx + j;
+    kb = sb;
+    ke = se;
+    return ke > kb;
+  }
+  if (idx > full || r == 0) return false;
+  const int nsub = cpx / r;
+  if (j >= r * nsub) return false;
+  const int tt = j % r, sub = j / r, len = se - sb;
+  tile = full * cpx + tt;
+  kb = sb + (int)((long long)sub * len / nsub);
+  ke = sb + (int)((long long)(sub + 1) * len / nsub);
+  return ke > kb;
+}
+
+template <bool GATHER3>
+struct TnCursor {
+  unsigned go[2], xo[2];  // byte offsets (into gy / into x - bias) of this lane's two pixels among the K-tile's FIRST 32, incl. the chunk
+  int rem[2];             // 3x3: index of those pixels inside their image
+  int tile, kt, ke, item, buf, dy, dx;
+};
+
+constexpr unsigned TN_OOB = 0x80000000u;  // an offset beyond every buffer (host checks sizes < 2^31): the DMA then writes zeros
+
+__device__ __forceinline__ bool tn_tap_ok(int rem, int dy, int dx, const TnArgs& p) {
+  const int oy = (int)__umulhi((unsigned)rem, p.magic_w);
+  const int ox = rem - oy * p.W;
+  return (unsigned)(oy + dy) < (unsigned)p.H && (unsigned)(ox + dx) < (unsigned)p.W;
+}
+
+// LDS image of a half-tile: [32 pixels][256 channels] = 512-byte rows, one DMA instruction = 2 rows; 16-byte chunk c of row r sits at
+// chunk c ^ (((r & 3) << 2) | (((r >> 3) & 1) << 1)): the two 4-row blocks a 32-lane half reads per transposed read (8 rows apart,
+// 32 bytes wide) cover all 64 banks.
+__device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 2) | (((row >> 3) & 1) << 1); }
+
+template <bool GATHER3>
+__device__ __forceinline__ void tn_set_pos(TnCursor<GATHER3>& c, const TnArgs& p, int tile, int kt, int wave, int lane) {
+  const int tco = tile / p.tiles_k, tk = tile - tco * p.tiles_k;
+  const int co0 = tco * 256, k0 = tk * 256;
+  int tap = 0, ci0 = k0;
+  c.dy = c.dx = 0;
+  if (GATHER3) {
+    tap = k0 / p.Cin;
+    ci0 = k0 - tap * p.Cin;
+    c.dy = tap / 3 - 1;
+    c.dx = tap % 3 - 1;
+  }
+  c.tile = tile;
+  c.kt = kt;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int row = (wave * 2 + e) * 2 + (lane >> 5);
+    const int lc = (lane & 31) ^ tn_swz(row);
+    const long long m = (long long)kt * 64 + row;
+    c.go[e] = (unsigned)((m * p.Cout + co0 + lc * 8) * 2);
+    c.xo[e] = (unsigned)(((m + c.dy * p.W + c.dx) * p.Cin + ci0 + lc * 8) * 2 + p.x_bias);  // >= 0: the bias covers the largest negative shift
+    c.rem[e] = GATHER3 ? (int)(m % (p.H * p.W)) : 0;
+  }
+}
+
+// WHICH: 0 = X-lo, 1 = G-lo (pixels 0-31 of the K-tile), 2 = X-hi, 3 = G-hi (pixels 32-63).  Range-checked buffer LDS-DMA: pixels
+// beyond M (offset >= num_records) and taps outside the image (offset forced to TN_OOB) arrive as zeros, with no address select.
+template <bool GATHER3, int WHICH>
+__device__ __forceinline__ void tn_stage(const TnCursor<GATHER3>& c, const TnArgs& p, __amdgpu_buffer_rsrc_t rg, __amdgpu_buffer_rsrc_t rx, char* lds, int wave) {
+  constexpr bool IS_G = (WHICH & 1) != 0;
+  constexpr int HI = WHICH >> 1;
+  char* dst = lds + c.buf * P_KT + WHICH * P_HALF + wave * 2048;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    unsigned off = IS_G ? c.go[e] + (unsigned)(HI * 64) * p.Cout : c.xo[e] + (unsigned)(HI * 64) * p.Cin;
+    if (!IS_G && GATHER3) {
+      int r = c.rem[e];
+      if (HI) {
+        r += p.r32;  // 32 % (H * W)
+        r = r >= p.hw ? r - p.hw : r;
+      }
+      off = tn_tap_ok(r, c.dy, c.dx, p) ? off : TN_OOB;
+    }
+    if (p.dbg & 1) off = TN_OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(IS_G ? rg : rx, (__attribute__((address_space(3))) void*)(dst + e * 1024), 16, off, 0, 0, 0);
+  }
+}
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// 8 consecutive pixels (rows) of one channel per lane: two transposed reads, rows r .. r+3 and r+4 .. r+7 (2048 bytes on).
+// Issued from inline asm: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the ds_read_tr16_b64 INTRINSIC whenever an LDS-DMA
+// is in flight (it has no memory operand to disambiguate; plain ds_read does not get that wait), which drained the whole DMA
+// pipeline once per K-tile -- measured: the reason the round-2 weight-gradient kernel and the first p8 TN versions sat at 0.8 PF.
+// The compiler neither counts these reads nor waits for them: every consumer sits behind TN_MFMA's `s_waitcnt lgkmcnt(0)` +
+// sched_barrier(0) (guide section 5.7, form iii).
+template <int IMM>
+__device__ __forceinline__ bf16x8 tn_frag(unsigned adr) {
+  s16x4 a, b;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a) : "v"(adr), "i"(IMM) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(b) : "v"(adr), "i"(IMM + 2048) : "memory");
+  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// Phases of a K-tile g (buffer g & 1), one MFMA k-step (32 pixels) x one half of the wave's output channels each:
+//   phase 1: read x (4 tiles) + gy (4 tiles, co half 0) of pixels 0-31 -> 16 MFMA; DMA G-hi(g+1)
+//   phase 2: read gy (co half 1)                                        -> 16 MFMA; DMA X-lo(g+2); wait: pixels 32-63 of g landed
+//   phase 3: the same for pixels 32-63;                                             DMA G-lo(g+2)
+//   phase 4:                                                                        DMA X-hi(g+2); wait: pixels 0-31 of g+1 landed
+// A wave retires its LDS reads (lgkmcnt(0)) BEFORE the phase's first barrier, so a half-tile is re-staged in the phase after its
+// last read; five half-tiles (80 KiB) stay in flight (`s_waitcnt vmcnt(10)`): a load has five to six phases to land.
+// The read / DMA sections run beside the other group's 16-MFMA burst, which leaves them about 30 vector-instruction issue slots:
+// DMA addresses are 32-bit buffer offsets advanced by one add per K-tile, fragment addresses are toggled between the buffers by XOR.
+template <bool GATHER3>
+__global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const TnArgs p) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nitems = p.ntiles / p.cpx + 1;
+  int total_kt = 0, first_item = -1;
+  for (int i = 0; i < nitems; ++i) {
+    int t, kb, ke;
+    if (tn_item(blockIdx.x, i, p.ntiles, p.nkt, p.cpx, t, kb, ke)) {
+      total_kt += ke - kb;
+      if (first_item < 0) first_item = i;
+    }
+  }
+  if (total_kt == 0) return;
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.GY), 0, p.g_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.X) - p.x_bias), 0, p.x_bytes, 0x00020000);
+
+  TnCursor<GATHER3> cur;
+  cur.buf = 0;
+  auto open_item = [&](int from) {  // first non-empty item with index >= from
+    for (int i = from; i < nitems; ++i) {
+      int t, kb, ke;
+      if (tn_item(blockIdx.x, i, p.ntiles, p.nkt, p.cpx, t, kb, ke)) {
+        cur.item = i;
+        cur.ke = ke;
+        tn_set_pos<GATHER3>(cur, p, t, kb, wave, lane);
+        return;
+      }
+    }
+    cur.item = nitems;
+  };
+  open_item(first_item);
+  auto advance = [&]() {
+    cur.buf ^= 1;
+    if (++cur.kt == cur.ke) {
+      open_item(cur.item + 1);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        cur.go[e] += 128u * p.Cout;
+        cur.xo[e] += 128u * p.Cin;
+        if (GATHER3) {
+          const int r = cur.rem[e] + p.r64;  // r64 = 64 % (H * W)
+          cur.rem[e] = r >= p.hw ? r - p.hw : r;
+        }
+      }
+    }
+  };
+
+  tn_stage<GATHER3, 0>(cur, p, rg, rx, lds, wave);
+  tn_stage<GATHER3, 1>(cur, p, rg, rx, lds, wave);
+  tn_stage<GATHER3, 2>(cur, p, rg, rx, lds, wave);
+  tn_stage<GATHER3, 3>(cur, p, rg, rx, lds, wave);
+  if (total_kt > 1) {
+    advance();
+    tn_stage<GATHER3, 0>(cur, p, rg, rx, lds, wave);
+    tn_stage<GATHER3, 1>(cur, p, rg, rx, lds, wave);
+    tn_stage<GATHER3, 2>(cur, p, rg, rx, lds, wave);
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // pixels 0-31 of K-tile 0 have landed
+  } else {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  }
+  P8_BAR();
+
+  // ---- transposed-read addresses inside a half-tile: lane group g4 = lane >> 4 takes pixels 8 g4 .. 8 g4 + 7; per read it supplies
+  // the address of row 8 g4 + q4 (+ 4 for the second read), columns 4 p4 .. 4 p4 + 3 of the tile's 16 channels
+  const int g4 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+  const int trow = 8 * g4 + q4, tsw = tn_swz(trow);
+  const unsigned lds0 = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char*)lds;  // P_KT-aligned (1024-byte aligned, only LDS object)
+  unsigned a_adr[4], b_adr[4];  // G tiles i (co half 0; half 1 = + 256 bytes), X tiles bh * 2 + j;  buffer 0, toggled with ^= P_KT
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_adr[i] = lds0 + P_HALF + trow * 512 + (((wr * 8 + i * 2 + (p4 >> 1)) ^ tsw) << 4) + (p4 & 1) * 8;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) b_adr[t] = lds0 + trow * 512 + ((((t >> 1) * 16 + wc * 4 + (t & 1) * 2 + (p4 >> 1)) ^ tsw) << 4) + (p4 & 1) * 8;
+
+  const int fr = lane & 15, fq = lane >> 4;
+  int item_c = first_item, left_c;  // K-tiles left in the item being accumulated
+  {
+    int t, kb, ke;
+    tn_item(blockIdx.x, item_c, p.ntiles, p.nkt, p.cpx, t, kb, ke);
+    left_c = ke - kb;
+  }
+  f32x4 acc[2][2][4][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[x][y][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#define TN_MFMA(AH)                                                                                                                     \
+  do {                                                                                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* reads retired before the barrier: see the re-staging rule above */           \
+    P8_SCHED();                                                                                                                         \
+    P8_BAR();                                                                                                                           \
+    P8_SCHED();                                                                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int t = 0; t < 4; ++t)                                         \
+        acc[AH][t >> 1][i][t & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t], af[i], acc[AH][t >> 1][i][t & 1], 0, 0, 0);          \
+    __builtin_amdgcn_s_setprio(0);                                                                                                      \
+    P8_SCHED();                                                                                                                         \
+    P8_BAR();                                                                                                                           \
+    P8_SCHED();                                                                                                                         \
+  } while (0)
+
+  if (wr == 1) P8_BAR();  // G1 runs one barrier behind G0
+  for (int g = 0; g < total_kt; ++g) {
+    const bool more1 = g + 1 < total_kt, more2 = g + 2 < total_kt;
+    bf16x8 af[4], bf[4];
+    // ------------------------------------------------ phase 1: pixels 0-31, co half 0
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bf[t] = tn_frag<0>(b_adr[t]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = tn_frag<0>(a_adr[i]);
+    P8_SCHED();
+    if (more1) {
+      tn_stage<GATHER3, 3>(cur, p, rg, rx, lds, wave);  // G-hi(g+1)
+      advance();                                         // cursor -> K-tile g+2
+    }
+    TN_MFMA(0);
+    // ------------------------------------------------ phase 2: pixels 0-31, co half 1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = tn_frag<256>(a_adr[i]);
+    P8_SCHED();
+    if (more2) {
+      tn_stage<GATHER3, 0>(cur, p, rg, rx, lds, wave);  // X-lo(g+2)
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // pixels 32-63 of K-tile g have landed
+    } else if (more1) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    TN_MFMA(1);
+    // ------------------------------------------------ phase 3: pixels 32-63, co half 0
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bf[t] = tn_frag<2 * P_HALF>(b_adr[t]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = tn_frag<2 * P_HALF>(a_adr[i]);
+    P8_SCHED();
+    if (more2) tn_stage<GATHER3, 1>(cur, p, rg, rx, lds, wave);  // G-lo(g+2)
+    TN_MFMA(0);
+    // ------------------------------------------------ phase 4: pixels 32-63, co half 1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = tn_frag<2 * P_HALF + 256>(a_adr[i]);
+    P8_SCHED();
+    if (more2) {
+      tn_stage<GATHER3, 2>(cur, p, rg, rx, lds, wave);  // X-hi(g+2)
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // pixels 0-31 of K-tile g+1 have landed
+    } else if (more1) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    TN_MFMA(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // the next K-tile sits in the other buffer
+      a_adr[i] ^= P_KT;
+      b_adr[i] ^= P_KT;
+    }
+    // ------------------------------------------------ end of an item: partial tile -> slab
+    if (--left_c == 0) {
+      float* __restrict__ out = p.slab + ((size_t)item_c * gridDim.x + blockIdx.x) * 65536;
+      if (!(p.dbg & 2))
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int row = x * 128 + wr * 64 + i * 16 + fr, col = y * 128 + wc * 32 + j * 16 + fq * 4;
+              *reinterpret_cast<f32x4*>(out + row * 256 + col) = acc[x][y][i][j];
+              acc[x][y][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+      for (++item_c; item_c < nitems; ++item_c) {
+        int t, kb2, ke2;
+        if (tn_item(blockIdx.x, item_c, p.ntiles, p.nkt, p.cpx, t, kb2, ke2)) {
+          left_c = ke2 - kb2;
+          break;
+        }
+      }
+    }
+  }
+#undef TN_MFMA
+  if (wr == 0) P8_BAR();
+}
+
+// dW[co][k] = sum of the partial tiles of tile (tco, tk) in a fixed order (XCD segment, then sub-range).  One workgroup per 4 rows
+// of a tile (thread = 4 consecutive columns of one row); the partial list is walked 4 at a time so that 4 loads are in flight.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Ktot, int tiles_k, int ntiles, int nkt,
+                                                        int cpx) {
+  const int tile = blockIdx.x >> 6, row = (blockIdx.x & 63) * 4 + (threadIdx.x >> 6);
+  const int tco = tile / tiles_k, tk = tile - tco * tiles_k;
+  const int grid = 8 * cpx, full = ntiles / cpx, r = ntiles - full * cpx;
+  const bool whole = tile < full * cpx;
+  const int idx = whole ? tile / cpx : full;
+  const int j0 = whole ? tile % cpx : tile - full * cpx;
+  const int nsub = whole ? 1 : cpx / r, jstep = whole ? 0 : r;
+  const int c4 = (threadIdx.x & 63) * 4;
+  const float* __restrict__ base = slab + (size_t)idx * grid * 65536 + row * 256 + c4;
+  const int n = 8 * nsub;  // candidate partials, order: x-major, then sub
+  f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int q0 = 0; q0 < n; q0 += 4) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = q0 + u, x = q / nsub, sub = q - x * nsub;
+      const int b = (j0 + sub * jstep) * 8 + x;
+      int t, kb, ke;
+      const bool ok = q < n && tn_item(b, idx, ntiles, nkt, cpx, t, kb, ke);
+      v[u] = ok ? *reinterpret_cast<const f32x4*>(base + (size_t)b * 65536) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a += v[u];
+  }
+  *reinterpret_cast<f32x4*>(dw + (size_t)(tco * 256 + row) * Ktot + tk * 256 + c4) = a;
+}
+
+}  // namespace
+
+static int p8_grid(int ntiles) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return ntiles < 256 ? ntiles : 256;
+    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return ntiles < cus ? ntiles : cus;
+}
+
+int coin_p8_debug = 0;  // lab hook, see TnArgs::dbg
+
+bool coin_p8_nt_ok(int M, int N, int K, int mode, int Cin) {
+  if (M <= 0 || N % PN || K % PK || K < 2 * PK) return false;
+  if (mode == 1 && (Cin % PK || K != 9 * Cin)) return false;
+  return true;
+}
+
+int coin_p8_nt_launch(const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb, void* C, int ldc, const void* R, int ldr,
+                      int M, int N, int K, float* stats, long long stats_rows, int grid_override, hipStream_t st) {
+  P8Args a;
+  a.A = (const bf16_t*)A; a.lda = lda;
+  a.B = (const bf16_t*)B; a.ldb = ldb;
+  a.C = (bf16_t*)C; a.ldc = ldc;
+  a.R = (const bf16_t*)R; a.ldr = ldr;
+  a.M = M; a.N = N; a.K = K; a.H = H; a.W = W; a.Cin = Cin;
+  a.stats = stats; a.stats_rows = stats_rows;
+  a.tiles_m = (M + PM - 1) / PM; a.tiles_n = N / PN;
+  a.dbg = coin_p8_debug;
+  const int ntiles = a.tiles_m * a.tiles_n;
+  const int grid = grid_override > 0 ? (grid_override < ntiles ? grid_override : ntiles) : p8_grid(ntiles);
+#define P8_LAUNCH(G3, ST)                                                                                                          \
+  do {                                                                                                                             \
+    static bool attr_set = false;                                                                                                  \
+    if (!attr_set) {                                                                                                               \
+      (void)hipFuncSetAttribute((const void*)conv_gemm_p8_kernel<G3, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);      \
+      attr_set = true;                                                                                                             \
+    }                                                                                                                              \
+    conv_gemm_p8_kernel<G3, ST><<<grid, 512, P_LDS, st>>>(a);                                                                      \
+  } while (0)
+  if (mode == 1) {
+    if (stats) P8_LAUNCH(true, true); else P8_LAUNCH(true, false);
+  } else {
+    if (stats) P8_LAUNCH(false, true); else P8_LAUNCH(false, false);
+  }
+#undef P8_LAUNCH
+  return coin_launch_status();
+}
+
+static void tn_plan(int M, int Cout, int Ktot, TnArgs& a, int& grid) {
+  a.ntiles = (Cout / 256) * (Ktot / 256);
+  a.tiles_k = Ktot / 256;
+  a.nkt = (M + 63) / 64;  // pixels beyond M read a zero page
+  a.cpx = p8_grid(1 << 30) / 8;
+  if (a.cpx < 1) a.cpx = 1;
+  grid = 8 * a.cpx;
+}
+
+bool coin_p8_tn_ok(int M, int Cout, int Cin, int Ktot, int mode) {
+  if (M <= 0 || Cout % 256 || Cin % 256) return false;
+  if (((size_t)M + 64 + 256) * (size_t)(Cout > Cin ? Cout : Cin) * 2 >= 0x7f000000ull) return false;  // 32-bit buffer offsets, TN_OOB beyond them
+  return mode == 0 ? Ktot == Cin : Ktot == 9 * Cin;
+}
+
+size_t coin_p8_tn_workspace_bytes(int M, int Cout, int Ktot) {
+  TnArgs a;
+  int grid;
+  tn_plan(M, Cout, Ktot, a, grid);
+  return (size_t)grid * (a.ntiles / a.cpx + 1) * 65536 * sizeof(float);
+}
+
+int coin_p8_tn_launch(const void* GY, const void* X, int mode, int H, int W, int Cin, int M, int Cout, int Ktot, float* dW, void* workspace,
+                      hipStream_t st) {
+  TnArgs a;
+  int grid;
+  tn_plan(M, Cout, Ktot, a, grid);
+  a.GY = (const bf16_t*)GY; a.X = (const bf16_t*)X; a.slab = (float*)workspace;
+  a.M = M; a.Cout = Cout; a.Cin = Cin; a.Ktot = Ktot; a.H = mode ? H : 1; a.W = mode ? W : 1;
+  a.magic_w = (unsigned)((0x100000000ull + (unsigned)a.W - 1) / (unsigned)a.W);
+  a.hw = a.H * a.W; a.r64 = 64 % a.hw; a.r32 = 32 % a.hw;
+  a.x_bias = mode ? (unsigned)(W + 1) * Cin * 2 : 0;
+  a.g_bytes = (unsigned)((size_t)M * Cout * 2);
+  a.x_bytes = (unsigned)((size_t)M * Cin * 2 + a.x_bias);
+  a.dbg = coin_p8_debug;
+  if (mode == 1) {
+    static bool set3 = false;
+    if (!set3) { (void)hipFuncSetAttribute((const void*)conv_wgrad_p8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_IMG); set3 = true; }
+    conv_wgrad_p8_kernel<true><<<grid, 512, P_IMG, st>>>(a);
+  } else {
+    static bool set1 = false;
+    if (!set1) { (void)hipFuncSetAttribute((const void*)conv_wgrad_p8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, P_IMG); set1 = true; }
+    conv_wgrad_p8_kernel<false><<<grid, 512, P_IMG, st>>>(a);
+  }
+  tn_reduce_kernel<<<a.ntiles * 64, 256, 0, st>>>(a.slab, dW, Ktot, a.tiles_k, a.ntiles, a.nkt, a.cpx);
+  return coin_launch_status();
+}

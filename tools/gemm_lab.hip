@@ -1,0 +1,399 @@
+// Development harness (not part of the product): coin_conv_gemm_bf16 / coin_conv_wgrad_bf16 variants side by side on the res5 shapes.
+// No torch: build with tools/build_lab.sh, run on the GPU box as  tools/gemm_lab [check|bench|all] [iters].
+//   check: the persistent 8-phase core (p8) against the round-2 kernels (parity-tested by tests/test_kernels_gpu.py) on every
+//          shape class incl. row tails, residual, statistics over a row prefix, few tiles; and against an fp64 host reference on
+//          sampled outputs.
+//   bench: interleaved rounds in ONE process (guide rule 24), random operands (rule 25), HIP events; JSON lines on stdout.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "../include/coin_hip.h"
+#include "../coin_amd/csrc/conv_gemm_p8.h"
+
+#define CK(x)                                                                                   \
+  do {                                                                                          \
+    hipError_t e_ = (x);                                                                        \
+    if (e_ != hipSuccess) {                                                                     \
+      fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__);   \
+      exit(2);                                                                                  \
+    }                                                                                           \
+  } while (0)
+
+typedef uint16_t bf16raw;
+
+static inline float bf2f(bf16raw v) {
+  uint32_t u = (uint32_t)v << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+__global__ void fill_kernel(bf16raw* p, size_t n, uint32_t seed, float scale) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    uint32_t x = (uint32_t)(i * 2654435761u) ^ seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    const float f = ((float)(x & 0xffffff) / 8388608.0f - 1.0f) * scale;  // uniform [-scale, scale)
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u = (u + 0x7fff + ((u >> 16) & 1)) >> 16;
+    p[i] = (bf16raw)u;
+  }
+}
+
+static void fill(void* p, size_t n, uint32_t seed, float scale) {
+  fill_kernel<<<2048, 256>>>((bf16raw*)p, n, seed, scale);
+  CK(hipGetLastError());
+}
+
+struct Shape {
+  const char* name;
+  int nb, h, w, ci, co, ks;
+};
+
+static const Shape kShapes[] = {{"l4.0.conv1", 2048, 14, 14, 1024, 512, 1}, {"l4.0.conv2", 2048, 14, 14, 512, 512, 3}, {"l4.0.conv3", 2048, 7, 7, 512, 2048, 1},
+                                {"l4.0.down", 2048, 7, 7, 1024, 2048, 1},   {"l4.1.conv1", 2048, 7, 7, 2048, 512, 1},  {"l4.1.conv2", 2048, 7, 7, 512, 512, 3}};
+
+static int run_gemm(int impl, const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb, void* C, int ldc, const void* R, int ldr,
+                    int M, int N, int K, float* stats, int64_t stats_rows) {
+  coin_conv_gemm_force_impl = impl;
+  const int rc = coin_conv_gemm_bf16(A, lda, mode, H, W, Cin, B, ldb, C, ldc, R, ldr, M, N, K, stats, stats_rows, nullptr);
+  coin_conv_gemm_force_impl = 0;
+  return rc;
+}
+
+// fp64 host reference of one output element (implicit 3x3 or plain row dot)
+static double ref_elem(const std::vector<bf16raw>& A, const std::vector<bf16raw>& B, int m, int n, int K, int mode, int H, int W, int Cin, int lda,
+                       int ldb) {
+  double s = 0;
+  if (mode == 0) {
+    for (int k = 0; k < K; ++k) s += (double)bf2f(A[(size_t)m * lda + k]) * bf2f(B[(size_t)n * ldb + k]);
+    return s;
+  }
+  const int hw = H * W, nb = m / hw, rem = m % hw, oy = rem / W, ox = rem % W;
+  for (int t = 0; t < 9; ++t) {
+    const int yy = oy + t / 3 - 1, xx = ox + t % 3 - 1;
+    if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+    const size_t row = (size_t)nb * hw + yy * W + xx;
+    for (int c = 0; c < Cin; ++c) s += (double)bf2f(A[row * Cin + c]) * bf2f(B[(size_t)n * ldb + t * Cin + c]);
+  }
+  return s;
+}
+
+static int check_case(const char* name, int M, int N, int K, int mode, int H, int W, int Cin, bool with_r, int64_t stats_rows, int grid_note) {
+  const int lda = mode == 0 ? K : Cin;
+  const size_t an = (size_t)M * lda, bn = (size_t)N * K, cn = (size_t)M * N;
+  void *A, *B, *C0, *C1, *R = nullptr;
+  CK(hipMalloc(&A, an * 2)); CK(hipMalloc(&B, bn * 2)); CK(hipMalloc(&C0, cn * 2)); CK(hipMalloc(&C1, cn * 2));
+  fill(A, an, 0x1234u, 1.0f);
+  fill(B, bn, 0x9876u, 0.05f);
+  if (with_r) { CK(hipMalloc(&R, cn * 2)); fill(R, cn, 0x5555u, 1.0f); }
+  CK(hipMemset(C0, 0xff, cn * 2)); CK(hipMemset(C1, 0xff, cn * 2));
+  float *S0 = nullptr, *S1 = nullptr;
+  const size_t sb = coin_conv_gemm_stats_bytes(M, N);
+  if (stats_rows > 0) { CK(hipMalloc(&S0, sb)); CK(hipMalloc(&S1, sb)); CK(hipMemset(S0, 0, sb)); CK(hipMemset(S1, 0, sb)); }
+  int rc0 = run_gemm(2, A, lda, mode, H, W, Cin, B, K, C0, N, R, N, M, N, K, S0, stats_rows);
+  int rc1 = run_gemm(1, A, lda, mode, H, W, Cin, B, K, C1, N, R, N, M, N, K, S1, stats_rows);
+  CK(hipDeviceSynchronize());
+  if (rc0 || rc1) { printf("CHECK %s: launch rc %d %d\n", name, rc0, rc1); return 1; }
+  std::vector<bf16raw> h0(cn), h1(cn);
+  CK(hipMemcpy(h0.data(), C0, cn * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), C1, cn * 2, hipMemcpyDeviceToHost));
+  size_t ndiff = 0, nbad = 0;
+  double maxrel = 0;
+  for (size_t i = 0; i < cn; ++i) {
+    if (h0[i] == h1[i]) continue;
+    ++ndiff;
+    const float a = bf2f(h0[i]), b = bf2f(h1[i]);
+    const double rel = fabs((double)a - b) / (fabs((double)a) + 0.05);
+    if (rel > maxrel) maxrel = rel;
+    if (!(rel < 0.02) && !(with_r && fabs((double)a - b) < 0.04)) ++nbad;  // more than ~2 bf16 ulps apart (different fp32 summation orders may differ by one ulp)
+  }
+  // fp64 reference on sampled elements
+  std::vector<bf16raw> hA(an), hB(bn), hR;
+  CK(hipMemcpy(hA.data(), A, an * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(hB.data(), B, bn * 2, hipMemcpyDeviceToHost));
+  if (with_r) { hR.resize(cn); CK(hipMemcpy(hR.data(), R, cn * 2, hipMemcpyDeviceToHost)); }
+  double maxerr = 0;
+  uint32_t rs = 12345;
+  for (int s = 0; s < 400; ++s) {
+    rs = rs * 1664525u + 1013904223u;
+    int m = (int)((rs >> 8) % (uint32_t)M);
+    rs = rs * 1664525u + 1013904223u;
+    int n = (int)((rs >> 8) % (uint32_t)N);
+    if (s < 8) m = s < 4 ? s : M - 1 - (s - 4);  // first / last rows
+    double r = ref_elem(hA, hB, m, n, K, mode, H, W, Cin, lda, K);
+    if (with_r) r += bf2f(hR[(size_t)m * N + n]);
+    const double got = bf2f(h1[(size_t)m * N + n]);
+    const double err = fabs(got - r) / (fabs(r) + 0.25);
+    if (err > maxerr) maxerr = err;
+  }
+  // statistics partials -> compare the finalized mean / rstd
+  double stat_err = 0;
+  if (stats_rows > 0) {
+    float *m0, *r0, *m1, *r1;
+    CK(hipMalloc(&m0, N * 4)); CK(hipMalloc(&r0, N * 4)); CK(hipMalloc(&m1, N * 4)); CK(hipMalloc(&r1, N * 4));
+    coin_conv_gemm_stats_finalize(S0, M, N, stats_rows, 1e-5f, 0.1f, m0, r0, nullptr, nullptr, nullptr);
+    coin_conv_gemm_stats_finalize(S1, M, N, stats_rows, 1e-5f, 0.1f, m1, r1, nullptr, nullptr, nullptr);
+    CK(hipDeviceSynchronize());
+    std::vector<float> a(N), b(N), c(N), d(N);
+    CK(hipMemcpy(a.data(), m0, N * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), m1, N * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(c.data(), r0, N * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(d.data(), r1, N * 4, hipMemcpyDeviceToHost));
+    // the two kernels may store outputs that differ by one bf16 ulp in a few places, so the statistics agree to ~1e-4, not exactly;
+    // the exact check (fp64 over the STORED values of p8) follows
+    std::vector<double> s1(N, 0.0), s2(N, 0.0);
+    for (int64_t m = 0; m < stats_rows; ++m)
+      for (int n = 0; n < N; ++n) {
+        const double v = bf2f(h1[(size_t)m * N + n]);
+        s1[n] += v; s2[n] += v * v;
+      }
+    for (int n = 0; n < N; ++n) {
+      const double mu = s1[n] / stats_rows, var = s2[n] / stats_rows - mu * mu;
+      const double rstd = 1.0 / sqrt(var + 1e-5);
+      stat_err = std::max(stat_err, fabs(b[n] - mu) / (fabs(mu) + 1e-2));
+      stat_err = std::max(stat_err, fabs(d[n] - rstd) / rstd);
+    }
+    (void)a; (void)c;
+    hipFree(m0); hipFree(r0); hipFree(m1); hipFree(r1);
+  }
+  const bool ok = nbad == 0 && maxerr < 0.02 && stat_err < 2e-5;
+  printf("CHECK %-28s M=%d N=%d K=%d mode=%d R=%d stats_rows=%lld : differing=%zu (%.4f%%) bad=%zu maxrel=%.4g fp64_err=%.4g stat_err=%.3g %s\n", name, M, N, K, mode,
+         (int)with_r, (long long)stats_rows, ndiff, 100.0 * ndiff / cn, nbad, maxrel, maxerr, stat_err, ok ? "OK" : "FAIL");
+  fflush(stdout);
+  hipFree(A); hipFree(B); hipFree(C0); hipFree(C1);
+  if (R) hipFree(R);
+  if (S0) { hipFree(S0); hipFree(S1); }
+  (void)grid_note;
+  return ok ? 0 : 1;
+}
+
+static float time_ms(hipEvent_t s, hipEvent_t e) {
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, s, e));
+  return ms;
+}
+
+static void bench_shape(const Shape& sh, int iters, int rounds) {
+  const int M = sh.nb * sh.h * sh.w, mode = sh.ks == 3 ? 1 : 0;
+  // forward: A = x [M, ci], B = w [co, ks*ks*ci];  dgrad: A = gy [M, co], B = wd [ci, ks*ks*co]
+  for (int dir = 0; dir < 2; ++dir) {
+    const int Cin = dir == 0 ? sh.ci : sh.co, N = dir == 0 ? sh.co : sh.ci, K = sh.ks * sh.ks * Cin;
+    const size_t an = (size_t)M * Cin, bn = (size_t)N * K, cn = (size_t)M * N;
+    void *A, *B, *C;
+    float* S;
+    CK(hipMalloc(&A, an * 2)); CK(hipMalloc(&B, bn * 2)); CK(hipMalloc(&C, cn * 2));
+    CK(hipMalloc(&S, coin_conv_gemm_stats_bytes(M, N)));
+    fill(A, an, 0x1234u + dir, 1.0f);
+    fill(B, bn, 0x9876u + dir, 0.05f);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int impls[3] = {1, 2, 1};
+    const bool stats[3] = {false, false, true};
+    const char* names[3] = {"p8", "sq", "p8+stats"};
+    std::vector<float> best(3, 1e30f), med[3];
+    for (int r = 0; r < rounds; ++r)
+      for (int v = 0; v < 3; ++v) {
+        if (dir == 1 && stats[v]) continue;
+        run_gemm(impls[v], A, Cin, mode, sh.h, sh.w, Cin, B, K, C, N, nullptr, 0, M, N, K, stats[v] ? S : nullptr, M);  // warm
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < iters; ++i) run_gemm(impls[v], A, Cin, mode, sh.h, sh.w, Cin, B, K, C, N, nullptr, 0, M, N, K, stats[v] ? S : nullptr, M);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        const float ms = time_ms(e0, e1) / iters;
+        med[v].push_back(ms);
+        best[v] = std::min(best[v], ms);
+      }
+    const double flop = 2.0 * M * (double)N * K;
+    printf("{\"shape\": \"%s\", \"dir\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d", sh.name, dir == 0 ? "fwd" : "dgrad", M, N, K);
+    for (int v = 0; v < 3; ++v) {
+      if (med[v].empty()) continue;
+      std::sort(med[v].begin(), med[v].end());
+      const float m = med[v][med[v].size() / 2];
+      printf(", \"%s_ms\": %.4f, \"%s_TF\": %.1f, \"%s_best_TF\": %.1f", names[v], m, names[v], flop / m / 1e9, names[v], flop / best[v] / 1e9);
+    }
+    printf("}\n");
+    fflush(stdout);
+    hipFree(A); hipFree(B); hipFree(C); hipFree(S);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- weight gradient
+static int run_wgrad(int impl, const void* GY, const void* X, int mode, int H, int W, int Cin, int M, int Cout, int Ktot, float* dW, void* ws) {
+  coin_conv_gemm_force_impl = impl;
+  const int rc = coin_conv_wgrad_bf16(GY, X, mode, H, W, Cin, M, Cout, Ktot, dW, ws, nullptr);
+  coin_conv_gemm_force_impl = 0;
+  return rc;
+}
+
+static int check_wgrad(const char* name, int M, int Cout, int Cin, int mode, int H, int W) {
+  const int Ktot = mode ? 9 * Cin : Cin;
+  const size_t gn = (size_t)M * Cout, xn = (size_t)M * Cin, wn = (size_t)Cout * Ktot;
+  void *GY, *X, *ws;
+  float *W0, *W1;
+  CK(hipMalloc(&GY, gn * 2)); CK(hipMalloc(&X, xn * 2)); CK(hipMalloc(&W0, wn * 4)); CK(hipMalloc(&W1, wn * 4));
+  CK(hipMalloc(&ws, coin_conv_wgrad_workspace_bytes(M, Cout, Ktot)));
+  fill(GY, gn, 0x4242u, 0.05f);
+  fill(X, xn, 0x1717u, 1.0f);
+  CK(hipMemset(W0, 0xff, wn * 4)); CK(hipMemset(W1, 0xff, wn * 4));
+  const int rc0 = run_wgrad(2, GY, X, mode, H, W, Cin, M, Cout, Ktot, W0, ws);
+  CK(hipDeviceSynchronize());
+  const int rc1 = run_wgrad(1, GY, X, mode, H, W, Cin, M, Cout, Ktot, W1, ws);
+  CK(hipDeviceSynchronize());
+  if (rc0 || rc1) { printf("WCHECK %s: launch rc %d %d\n", name, rc0, rc1); return 1; }
+  std::vector<float> h0(wn), h1(wn);
+  CK(hipMemcpy(h0.data(), W0, wn * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), W1, wn * 4, hipMemcpyDeviceToHost));
+  double maxabs = 0, maxdiff = 0;
+  for (size_t i = 0; i < wn; ++i) {
+    maxabs = std::max(maxabs, (double)fabs(h0[i]));
+    const double d = fabs((double)h0[i] - h1[i]);
+    if (!(d <= maxdiff)) maxdiff = d;  // also catches NaN
+  }
+  // fp64 reference on sampled entries
+  std::vector<bf16raw> hG(gn), hX(xn);
+  CK(hipMemcpy(hG.data(), GY, gn * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(hX.data(), X, xn * 2, hipMemcpyDeviceToHost));
+  double maxerr = 0;
+  uint32_t rs = 777;
+  const int hw = mode ? H * W : 1;
+  for (int s = 0; s < 48; ++s) {
+    rs = rs * 1664525u + 1013904223u;
+    const int co = (int)((rs >> 8) % (uint32_t)Cout);
+    rs = rs * 1664525u + 1013904223u;
+    const int k = (int)((rs >> 8) % (uint32_t)Ktot);
+    const int tap = mode ? k / Cin : 0, ci = mode ? k % Cin : k, dy = mode ? tap / 3 - 1 : 0, dx = mode ? tap % 3 - 1 : 0;
+    double acc = 0;
+    for (int m = 0; m < M; ++m) {
+      if (mode) {
+        const int rem = m % hw, oy = rem / W, ox = rem % W;
+        if (oy + dy < 0 || oy + dy >= H || ox + dx < 0 || ox + dx >= W) continue;
+      }
+      acc += (double)bf2f(hG[(size_t)m * Cout + co]) * bf2f(hX[(size_t)(m + dy * W + dx) * Cin + ci]);
+    }
+    const double err = fabs(acc - h1[(size_t)co * Ktot + k]);
+    if (!(err <= maxerr)) maxerr = err;
+  }
+  const bool ok = maxdiff < 2e-4 * (maxabs + 1e-3) + 1e-3 && maxerr < 2e-4 * (maxabs + 1e-3) + 1e-3;
+  printf("WCHECK %-24s M=%d Cout=%d Cin=%d mode=%d : max|dW|=%.4g  p8 vs sliced max diff=%.4g  p8 vs fp64 (48 samples)=%.4g %s\n", name, M, Cout, Cin, mode, maxabs,
+         maxdiff, maxerr, ok ? "OK" : "FAIL");
+  fflush(stdout);
+  hipFree(GY); hipFree(X); hipFree(W0); hipFree(W1); hipFree(ws);
+  return ok ? 0 : 1;
+}
+
+static void bench_wgrad(const Shape& sh, int iters, int rounds) {
+  const int M = sh.nb * sh.h * sh.w, mode = sh.ks == 3 ? 1 : 0, Ktot = sh.ks * sh.ks * sh.ci;
+  const size_t gn = (size_t)M * sh.co, xn = (size_t)M * sh.ci, wn = (size_t)sh.co * Ktot;
+  void *GY, *X, *ws;
+  float* dW;
+  CK(hipMalloc(&GY, gn * 2)); CK(hipMalloc(&X, xn * 2)); CK(hipMalloc(&dW, wn * 4));
+  CK(hipMalloc(&ws, coin_conv_wgrad_workspace_bytes(M, sh.co, Ktot)));
+  fill(GY, gn, 0x4242u, 0.05f);
+  fill(X, xn, 0x1717u, 1.0f);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int impls[2] = {1, 2};
+  const char* names[2] = {"p8", "sliced"};
+  std::vector<float> med[2];
+  for (int r = 0; r < rounds; ++r)
+    for (int v = 0; v < 2; ++v) {
+      run_wgrad(impls[v], GY, X, mode, sh.h, sh.w, sh.ci, M, sh.co, Ktot, dW, ws);
+      CK(hipEventRecord(e0));
+      for (int i = 0; i < iters; ++i) run_wgrad(impls[v], GY, X, mode, sh.h, sh.w, sh.ci, M, sh.co, Ktot, dW, ws);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      med[v].push_back(time_ms(e0, e1) / iters);
+    }
+  const double flop = 2.0 * M * (double)sh.co * Ktot;
+  printf("{\"shape\": \"%s\", \"dir\": \"wgrad\", \"M\": %d, \"Cout\": %d, \"Ktot\": %d", sh.name, M, sh.co, Ktot);
+  for (int v = 0; v < 2; ++v) {
+    std::sort(med[v].begin(), med[v].end());
+    const float m = med[v][med[v].size() / 2];
+    printf(", \"%s_ms\": %.4f, \"%s_TF\": %.1f", names[v], m, names[v], flop / m / 1e9);
+  }
+  printf("}\n");
+  fflush(stdout);
+  hipFree(GY); hipFree(X); hipFree(dW); hipFree(ws);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+}
+
+static void bench_debug(int iters) {
+  // what bounds the p8 main loops: (a) as shipped, (b) every DMA from the L2-resident zero page (no memory system), (c) TN without stores
+  for (int si : {0, 1, 5}) {
+    const Shape& sh = kShapes[si];
+    const int M = sh.nb * sh.h * sh.w, mode = sh.ks == 3 ? 1 : 0, Ktot = sh.ks * sh.ks * sh.ci;
+    void *GY, *X, *ws, *B, *C;
+    float* dW;
+    CK(hipMalloc(&GY, (size_t)M * sh.co * 2)); CK(hipMalloc(&X, (size_t)M * sh.ci * 2)); CK(hipMalloc(&dW, (size_t)sh.co * Ktot * 4));
+    CK(hipMalloc(&B, (size_t)sh.co * Ktot * 2)); CK(hipMalloc(&C, (size_t)M * sh.co * 2));
+    CK(hipMalloc(&ws, coin_conv_wgrad_workspace_bytes(M, sh.co, Ktot)));
+    fill(GY, (size_t)M * sh.co, 1, 0.05f); fill(X, (size_t)M * sh.ci, 2, 1.0f); fill(B, (size_t)sh.co * Ktot, 3, 0.05f);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const double flop = 2.0 * M * (double)sh.co * Ktot;
+    for (int dbg : {0, 1, 2, 3}) {
+      float best_w = 1e30f, best_f = 1e30f;
+      for (int r = 0; r < 3; ++r) {
+        coin_p8_debug = dbg;
+        run_wgrad(1, GY, X, mode, sh.h, sh.w, sh.ci, M, sh.co, Ktot, dW, ws);
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < iters; ++i) run_wgrad(1, GY, X, mode, sh.h, sh.w, sh.ci, M, sh.co, Ktot, dW, ws);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        best_w = std::min(best_w, time_ms(e0, e1) / iters);
+        if (dbg < 2) {
+          run_gemm(1, X, sh.ci, mode, sh.h, sh.w, sh.ci, B, Ktot, C, sh.co, nullptr, 0, M, sh.co, Ktot, nullptr, 0);
+          CK(hipEventRecord(e0));
+          for (int i = 0; i < iters; ++i) run_gemm(1, X, sh.ci, mode, sh.h, sh.w, sh.ci, B, Ktot, C, sh.co, nullptr, 0, M, sh.co, Ktot, nullptr, 0);
+          CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+          best_f = std::min(best_f, time_ms(e0, e1) / iters);
+        }
+        coin_p8_debug = 0;
+      }
+      printf("{\"shape\": \"%s\", \"dbg\": %d, \"wgrad_ms\": %.4f, \"wgrad_TF\": %.1f, \"fwd_ms\": %.4f, \"fwd_TF\": %.1f}\n", sh.name, dbg, best_w, flop / best_w / 1e9,
+             best_f, best_f < 1e29f ? flop / best_f / 1e9 : 0.0);
+      fflush(stdout);
+    }
+    hipFree(GY); hipFree(X); hipFree(dW); hipFree(B); hipFree(C); hipFree(ws);
+  }
+}
+
+int main(int argc, char** argv) {
+  const char* what = argc > 1 ? argv[1] : "all";
+  const int iters = argc > 2 ? atoi(argv[2]) : 10;
+  int fails = 0;
+  if (!strcmp(what, "check") || !strcmp(what, "all")) {
+    // 1x1 classes
+    fails += check_case("1x1 K=512 N=2048", 256 * 37, 2048, 512, 0, 0, 0, 0, false, 256 * 37, 0);
+    fails += check_case("1x1 tail rows", 256 * 300 + 77, 512, 1024, 0, 0, 0, 0, false, 256 * 300 + 77, 0);
+    fails += check_case("1x1 stats prefix + R", 49 * 1000, 512, 2048, 0, 0, 0, 0, true, 49 * 900, 0);
+    fails += check_case("1x1 few tiles", 256 * 3, 256, 128, 0, 0, 0, 0, false, 0, 0);
+    fails += check_case("1x1 one tile", 100, 256, 512, 0, 0, 0, 0, true, 100, 0);
+    // 3x3 classes
+    fails += check_case("3x3 14x14", 196 * 320, 512, 9 * 512, 1, 14, 14, 512, false, 196 * 320, 0);
+    fails += check_case("3x3 7x7 tail + R", 49 * 777, 512, 9 * 512, 1, 7, 7, 512, true, 49 * 700, 0);
+    fails += check_case("3x3 Cin=64", 196 * 40, 256, 9 * 64, 1, 14, 14, 64, false, 196 * 40, 0);
+    // benchmark shapes, full size (bit comparison with the round-2 kernel)
+    fails += check_case("l4.0.conv1 full", 401408, 512, 1024, 0, 0, 0, 0, false, 401408, 0);
+    fails += check_case("l4.1.conv2 full", 100352, 512, 4608, 1, 7, 7, 512, false, 100352, 0);
+    printf("CHECK total failures: %d\n", fails);
+  }
+  if (!strcmp(what, "wcheck") || !strcmp(what, "all")) {
+    fails += check_wgrad("1x1 small", 64 * 50 + 17, 256, 256, 0, 0, 0);
+    fails += check_wgrad("1x1 512x1024", 49 * 600, 512, 1024, 0, 0, 0);
+    fails += check_wgrad("3x3 7x7", 49 * 300 + 0, 256, 256, 1, 7, 7);
+    fails += check_wgrad("3x3 14x14 512", 196 * 128, 512, 512, 1, 14, 14);
+    fails += check_wgrad("3x3 tiny", 49 * 2, 256, 256, 1, 7, 7);
+    printf("WCHECK total failures: %d\n", fails);
+  }
+  if (!strcmp(what, "bench") || !strcmp(what, "all")) {
+    for (const Shape& s : kShapes) bench_shape(s, iters, 5);
+  }
+  if (!strcmp(what, "dbg")) bench_debug(iters);
+  if (!strcmp(what, "wbench") || !strcmp(what, "all")) {
+    for (const Shape& s : kShapes) bench_wgrad(s, iters, 5);
+  }
+  return fails ? 1 : 0;
+}
