@@ -2,8 +2,9 @@
 """Benchmark of COIN's adaptation-training hot path on MI355X (contract: see the task prompt / DESIGN.md §4).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          # starts its own N ranks (one process per GPU, RCCL over 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             # ... or runs as one rank of an outer launcher (RANK / WORLD_SIZE set)
 
 One "step" = one ``PRETrainer.run_step`` of the CLIPDET pre-training config (BASELINE.json configs[1]):
 per GPU 2 synthetic 800x1333 VOC-shaped images x (strong + weak view) = 4 views, each forward + backward
@@ -41,18 +42,18 @@ ENTRY_KERNELS = {
     "coin_roi_align_fwd": ["roi_align_fwd_nhwc_kernel"], "coin_roi_align_bwd": ["roi_align_bwd_gather_kernel"],
     "coin_bn_stats": ["bn_stats_kernel", "bn_finalize_kernel"], "coin_bn_apply_fwd": ["bn_apply_kernel | bn_apply_mean_kernel"],
     "coin_bn_bwd": ["bn_bwd_reduce_kernel", "bn_bwd_finalize_kernel", "bn_bwd_dx_kernel"], "coin_gemm_nt": ["gemm_nt_bf16_kernel"],
-    "coin_conv_gemm_bf16": ["conv_gemm256_bf16_kernel | conv_gemm_bf16_kernel  (<GATHER3, STATS> instantiations)"],
-    "coin_conv_wgrad_bf16": ["conv_wgrad_bf16_kernel", "wgrad_reduce_kernel"],
+    "coin_conv_gemm_bf16": ["conv_gemm_p8_kernel | conv_gemm256_bf16_kernel | conv_gemm_bf16_kernel  (<GATHER3, STATS> instantiations)"],
+    "coin_conv_wgrad_bf16": ["conv_wgrad_p8_kernel", "tn_reduce_kernel"],
     "coin_conv_gemm_stats_finalize": ["conv_stats_finalize_kernel"],
 }
 MFMA_ENTRIES = ("coin_gemm_nt", "coin_conv_gemm_bf16", "coin_conv_wgrad_bf16")   # their `units` slot carries FLOPs, not bytes
 
 
 def pmc_traffic(entry: str, alg_bytes: float):
-    """HBM bytes per launch from the committed PMC passes (profiles/r2_pmc_traffic.json, else r1's: FETCH_SIZE x2 on gfx950 +
+    """HBM bytes per launch from the committed PMC passes (profiles/r3_pmc_traffic.json, else older rounds': FETCH_SIZE x2 on gfx950 +
     WRITE_SIZE, KB units, MI355X_MICROARCH.md) -- only when that pass measured this entry point at this launch size (for the MFMA
     entry points: at this mean FLOP count per launch), else None."""
-    for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    for name in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 table = json.load(f)
@@ -186,6 +187,34 @@ def run_cpu_baseline(timeout_s: int):
         return {"value": None, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port", "sample": f"not measured: {type(e).__name__}: {e}"[:300]}
 
 
+def child_env(rank: int, world: int, port: int, base=None) -> dict:
+    """Environment of rank `rank` of a self-launched run (what torch.distributed.run would set, rendezvous on 127.0.0.1)."""
+    env = dict(os.environ if base is None else base)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    return env
+
+
+def child_argv(argv) -> list:
+    return [sys.executable, os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv) -> int:
+    """`python bench.py --gpus N` without an outer launcher: this process starts N fresh rank processes and waits for them.  It never
+    imports torch.cuda or touches a GPU itself (the ranks are children, not exec replacements: train_net.py:132-139 of the reference
+    plays the same role with detectron2's launch())."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [subprocess.Popen(child_argv(argv), env=child_env(r, args.gpus, port), cwd=ROOT) for r in range(args.gpus)]
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,6 +230,8 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_only:
         return cpu_baseline_main(args)
+    if args.gpus > 1 and "RANK" not in os.environ:   # no outer launcher: become the launcher (before anything touches the GPU)
+        raise SystemExit(self_launch(args, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist

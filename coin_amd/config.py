@@ -370,8 +370,7 @@ def add_config(cfg: CfgNode) -> None:
     _C.AMD.FIXED_ROI_SAMPLER = False   # benchmark mode of SURVEY §8d: exactly 128 fg + 384 bg per view
     _C.AMD.CONV_GEMM = True            # bf16 mode: res5 convolutions forward / dgrad on coin_conv_gemm_bf16 (BN statistics in its epilogue)
     _C.AMD.GRAD_ARENA = False          # one GPU: also pack the gradients into the flat arena of coin_amd.parallel.GradReducer (measured 0.8 ms/step slower than handing autograd's tensors to the optimizer; the arena is always used when world_size > 1)
-    _C.AMD.WGRAD_STREAM = False        # res5 weight gradients on their own HIP stream, off the dgrad / BatchNorm-backward chain
-    _C.AMD.CONV_GEMM_WGRAD = False     # ... and their weight gradients on coin_conv_wgrad_bf16
+    _C.AMD.CONV_GEMM_WGRAD = True      # ... and their weight gradients on coin_conv_wgrad_bf16 (round 3: 1.3-1.7x the library's wrw kernels)
 
 
 def get_cfg() -> CfgNode:

@@ -5,7 +5,6 @@ Reference call sites are cited per class (paths under /root/reference).
 """
 from __future__ import annotations
 
-import contextlib
 import weakref
 from typing import Optional, Sequence, Tuple
 
@@ -107,23 +106,11 @@ def conv2d(x: torch.Tensor, conv: torch.nn.Conv2d) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- convolutions on the hand-written GEMM
-# res5 runs on the RoI tiles ([R*196, 1024] ... [R*49, 2048] rows): its 1x1 convolutions are NHWC GEMMs that sit on the HBM
-# roofline and its 3x3 convolutions implicit GEMMs; forward and data-gradient go through coin_conv_gemm_bf16 (with the BatchNorm
-# statistics of the output taken in the epilogue), the weight gradient stays a library contraction.  bf16 compute mode only: the
-# fp32 parity mode keeps the library's fp32 convolutions.
-CONV_GEMM = {"enabled": False, "min_rows": 32768, "wgrad": False}
-
-# Weight gradients of these convolutions on their own HIP stream: nothing in backward consumes them (only the optimizer does), so
-# they need not sit on the chain dgrad -> BatchNorm backward -> dgrad ...; issued on a second stream they fill the low-occupancy
-# stretches of that chain.  `join_wgrad_stream()` (optimizer step, gradient reducer) makes the consumer's stream wait for them.
-WGRAD_STREAM = {"enabled": False, "stream": None, "dirty": False}
-
-
-def join_wgrad_stream() -> None:
-    st = WGRAD_STREAM["stream"]
-    if st is not None and WGRAD_STREAM["dirty"]:
-        torch.cuda.current_stream().wait_stream(st)
-        WGRAD_STREAM["dirty"] = False
+# res5 runs on the RoI tiles ([R*196, 1024] ... [R*49, 2048] rows): its 1x1 convolutions are NHWC GEMMs and its 3x3 convolutions
+# implicit GEMMs; forward and data-gradient go through coin_conv_gemm_bf16 (with the BatchNorm statistics of the output taken in
+# the epilogue), the weight gradient through coin_conv_wgrad_bf16 (channel counts that are multiples of 256; the library's
+# contraction otherwise).  bf16 compute mode only: the fp32 parity mode keeps the library's fp32 convolutions.
+CONV_GEMM = {"enabled": False, "min_rows": 32768, "wgrad": True}
 
 
 def _conv_gemm_ok(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
@@ -170,14 +157,6 @@ class _ConvGemm(Function):
         n, h, w, co = gyn.shape
         ci = wq.shape[1]
         dx = dw = None
-        side = None
-        if ctx.needs_input_grad[1] and WGRAD_STREAM["enabled"] and gyn.is_cuda:
-            if WGRAD_STREAM["stream"] is None:
-                WGRAD_STREAM["stream"] = torch.cuda.Stream(device=gyn.device)
-            side = WGRAD_STREAM["stream"]
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream())   # gy and x are complete here; the dgrad below is NOT waited for
-            side.wait_event(ready)
         if ctx.needs_input_grad[0]:
             # dgrad = the same contraction over (flipped tap, Cout): weight re-laid [Cin][ky'][kx'][Cout] (a few MB, once per call)
             wd = wq.flip(2, 3).permute(1, 2, 3, 0).contiguous().reshape(ci, ks * ks * co)
@@ -188,18 +167,13 @@ class _ConvGemm(Function):
             gx, _ = K.conv_gemm(gyn.reshape(n * h * w, co), wd, spatial=(h, w, co) if ks == 3 else None, residual=res)
             dx = gx.view(n, h, w, ci).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-                if CONV_GEMM["wgrad"] and K.conv_wgrad_ok(co, ci):
-                    xn = _as_nhwc(x)
-                    dw2 = K.conv_wgrad(gyn.reshape(n * h * w, co), xn.reshape(n * h * w, ci), spatial=(h, w, ci) if ks == 3 else None)
-                    dw = dw2.view(co, ks, ks, ci).permute(0, 3, 1, 2)  # fp32, already in the parameter's channels-last layout
-                else:
-                    dw = torch.ops.aten.convolution_backward(gyn.permute(0, 3, 1, 2), x, wq, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
-                                                             [False, True, False])[1].float()
-            if side is not None:
-                for t in (gyn, x, wq):
-                    t.record_stream(side)
-                WGRAD_STREAM["dirty"] = True
+            if CONV_GEMM["wgrad"] and K.conv_wgrad_ok(co, ci):
+                xn = _as_nhwc(x)
+                dw2 = K.conv_wgrad(gyn.reshape(n * h * w, co), xn.reshape(n * h * w, ci), spatial=(h, w, ci) if ks == 3 else None)
+                dw = dw2.view(co, ks, ks, ci).permute(0, 3, 1, 2)  # fp32, already in the parameter's channels-last layout
+            else:
+                dw = torch.ops.aten.convolution_backward(gyn.permute(0, 3, 1, 2), x, wq, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
+                                                         [False, True, False])[1].float()
         return dx, dw, None, None, None
 
 

@@ -62,7 +62,6 @@ class OpenVocabularyRCNN(nn.Module):
         L.CONV_GEMM["wgrad"] = (bool(cfg.AMD.CONV_GEMM_WGRAD) or os.environ.get("COIN_CONV_WGRAD") == "1") and os.environ.get("COIN_CONV_WGRAD") != "0"
         if os.environ.get("COIN_CONV_GEMM_MIN_ROWS"):   # measurements only
             L.CONV_GEMM["min_rows"] = int(os.environ["COIN_CONV_GEMM_MIN_ROWS"])
-        L.WGRAD_STREAM["enabled"] = (bool(cfg.AMD.WGRAD_STREAM) or os.environ.get("COIN_WGRAD_STREAM") == "1") and os.environ.get("COIN_WGRAD_STREAM") != "0"
         backbone = build_backbone(cfg)
         if cfg.MODEL.ROI_HEADS.POOLING_TYPE != "attnpool":
             backbone.del_attnpool()

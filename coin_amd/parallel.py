@@ -15,7 +15,11 @@ needs and nothing else:
     multi-tensor copy and the slice is all-reduced asynchronously (RCCL: on the communicator's own stream, overlapping the rest
     of backward); slices are always launched in index order, so every rank issues the same sequence of collectives whatever
     its autograd graph looks like, and ``finalize()`` flushes slices whose parameters received no gradient with zeros;
-  * ``p.grad`` is then a view of the arena: stable addresses, so the optimizer's device table is uploaded once;
+  * after the pack ``p.grad`` is a view of the arena (the optimizer reads the averaged gradient there); the trainers drop the
+    gradients every step (``set_to_none``), so autograd hands over fresh tensors and the pack copy is paid every step
+    (0.8 ms of 40, measured with ``cfg.AMD.GRAD_ARENA``);
+  * ONE backward per step: a parameter must not receive a second gradient between two ``finalize()`` calls (gradient
+    accumulation over several backward calls would launch its slice with a partial sum) -- a second arrival raises;
   * the division by the world size is folded into the SGD launch (``inv_scale``), not a kernel of its own.
 BatchNorm statistics, prototypes and the sampler RNG stay per rank, exactly as with ``broadcast_buffers=False`` in the reference.
 """
@@ -28,7 +32,7 @@ import torch.distributed as dist
 
 
 class _Slice:
-    __slots__ = ("params", "views", "flat", "arrived", "launched", "work", "events")
+    __slots__ = ("params", "views", "flat", "arrived", "launched", "work", "events", "seen")
 
 
 class GradReducer:
@@ -66,7 +70,7 @@ class GradReducer:
             # optimizer sees the layout it expects
             s.views.append(s.flat[off:off + p.numel()].as_strided(p.shape, p.stride()) if _dense(p) else s.flat[off:off + p.numel()].view(p.shape))
             off += p.numel()
-        s.arrived, s.launched, s.work, s.events = 0, False, None, []
+        s.arrived, s.launched, s.work, s.events, s.seen = 0, False, None, [], set()
         idx = len(self.slices)
         self.slices.append(s)
         for p in params:
@@ -80,6 +84,10 @@ class GradReducer:
     # happened to serialise and the missing dependency did not show; with 8 the packed gradients were read too early -> NaN.)
     def _on_grad(self, p: torch.nn.Parameter):
         s = self.slices[self._slice_of[id(p)]]
+        if id(p) in s.seen or s.launched:
+            raise RuntimeError("GradReducer: a parameter received a second gradient before finalize() (one backward per step; "
+                               "restrict extra backward calls to other parameters with backward(inputs=...))")
+        s.seen.add(id(p))
         s.arrived += 1
         if p.grad is not None and p.grad.is_cuda:
             ev = torch.cuda.Event()
@@ -96,9 +104,6 @@ class GradReducer:
 
     @torch.no_grad()
     def _launch(self, s: _Slice):
-        from . import layers as L
-
-        L.join_wgrad_stream()   # weight gradients produced on the side stream (layers.WGRAD_STREAM) must be complete before the pack
         if s.events:
             cur = torch.cuda.current_stream(s.flat.device)
             for ev in s.events:
@@ -139,6 +144,7 @@ class GradReducer:
                 s.work.wait()
                 s.work = None
             s.arrived, s.launched, s.events = 0, False, []
+            s.seen.clear()
         self._next = 0
         return 1.0 / self.world_size
 

@@ -80,9 +80,6 @@ class FusedSGD:
 
     @torch.no_grad()
     def step(self, inv_loss_scale: float = 1.0):
-        from .. import layers as L
-
-        L.join_wgrad_stream()   # weight gradients computed on the side stream (layers.WGRAD_STREAM)
         params = self.params
         if self._table is None:
             self._table = K.SgdTable(params, [g["lr"] for g in self.param_groups], [g["weight_decay"] for g in self.param_groups])
