@@ -65,9 +65,13 @@ class BASE_Trainer:
         was_training = model.training
         model.eval()
         evaluator.reset()
-        items = list(items)
-        for i in range(0, len(items), batch_size):
-            batch = items[i:i + batch_size]
+        batch = []
+        for item in items:   # `items` may be lazy (coin_amd.data.LazyTestSet): an image is mapped when its batch is due and dropped afterwards
+            batch.append(item)
+            if len(batch) == batch_size:
+                evaluator.process(batch, model(batch, branch="test"))
+                batch = []
+        if batch:
             evaluator.process(batch, model(batch, branch="test"))
         model.train(was_training)
         return evaluator.evaluate()
@@ -76,11 +80,14 @@ class BASE_Trainer:
     _eval_items = _eval_factory = None
 
     def set_evaluation(self, items, evaluator_factory, batch_size: int = 1):
-        """`items`: the test set as dataset-mapper outputs (image / height / width / image_id ...); `evaluator_factory()` builds a fresh
+        """`items`: the test set as dataset-mapper outputs (image / height / width / image_id ...), or a lazy re-iterable that maps an image
+        when it is reached (`coin_amd.data.LazyTestSet`, this rank's shard); `evaluator_factory()` builds a fresh
         evaluator (reset / process / evaluate, e.g. coin_amd.evaluation.PascalVOCEvaluator).  With `TEST.EVAL_PERIOD > 0` `train()` then
         evaluates after every EVAL_PERIOD-th iteration (BEFORE that iteration's checkpoint, so the file carries the new AP50) and
         after the last one, exactly like the reference's hook order."""
-        self._eval_items, self._eval_factory, self._eval_batch = list(items), evaluator_factory, batch_size
+        # a re-iterable (list, LazyTestSet) is kept as it is; a one-shot generator is materialised
+        self._eval_items = items if hasattr(items, "__len__") else list(items)
+        self._eval_factory, self._eval_batch = evaluator_factory, batch_size
 
     def _eval_due(self, start: int = -1) -> bool:
         """detectron2 EvalHook.after_step / after_train with MyEvalHook's start iteration; `self.iter` = index of the step just done."""

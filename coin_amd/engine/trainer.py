@@ -112,19 +112,27 @@ class CoinTrainer(BASE_Trainer):
         return rcnn, rpn
 
     # ------------------------------------------------------------------ one step (trainer.py:160-218)
-    def _teacher_targets(self, weak):
-        """Steps 1-3 of the iteration `self.iter`: EMA of the teacher when due, teacher inference on the weak views, matching.
+    def _fetch(self):
+        """The next batch and its targets: `next(loader)`, then steps 1-3 of the iteration `self.iter` (EMA of the teacher when due,
+        teacher inference on the weak views, matching) -> (strong views, (A, B, C) targets).
 
-        On the GPU (cfg.AMD.TEACHER_STREAM) the three run on the teacher's own HIP stream.  The read-back of the detections then
-        waits for the teacher's kernels only -- not for the student's backward that `prepare_next` left queued on the main stream --
-        so the host walks through the matcher while the device is still busy with the student, and the teacher's (small,
-        low-occupancy) inference kernels share the GPU with that backward.  The only cross-stream dependency is the EMA, which reads
-        the weights the optimizer has just written: the teacher stream waits for the main stream when an EMA is due.  The targets
-        stay on the host until `run_step` uploads them on the main stream (no tensor crosses streams)."""
+        On the GPU (cfg.AMD.TEACHER_STREAM) ALL of it runs on the teacher's own HIP stream -- the loader included: with real
+        files the loader uploads the decoded image and queues the coin_aug_* kernels that WRITE the two views
+        (DatasetMapperUnsupervised); drawn on the main stream those kernels would sit behind the student's backward while the
+        teacher stream read the still-empty buffers (round-2 ADVICE: garbage detections -> silently wrong pseudo-labels; the
+        synthetic loader, whose images are resident, hid it).  The batch is produced on the stream that consumes it first; the main
+        stream takes the strong views after its `wait_stream(teacher)` in `run_step` (the tensors are marked with
+        `record_stream`, as they were allocated from the teacher stream's pool).
+        The read-back of the detections waits for the teacher's kernels only -- not for the student's backward that `prepare_next`
+        left queued on the main stream -- so the host walks through the matcher while the device is still busy with the student,
+        and the teacher's (small, low-occupancy) inference kernels share the GPU with that backward.  The only cross-stream
+        dependency is the EMA, which reads the weights the optimizer has just written: the teacher stream waits for the main
+        stream when an EMA is due.  The targets stay on the host until `run_step` uploads them on the main stream."""
         cfg, burn = self.cfg, self.cfg.CLOUD.BURN_UP_STEP
         ema_due = self.iter >= burn and (self.iter - burn) % cfg.CLOUD.OFFLINE_TEACHER_UPDATE_ITER == 0
         side = None
         if self.device.type == "cuda" and getattr(getattr(cfg, "AMD", None), "TEACHER_STREAM", True):
+            main = torch.cuda.current_stream(self.device)
             if self._teacher_stream is None:
                 self._teacher_stream = torch.cuda.Stream(device=self.device)
                 ema_due_or_first = True
@@ -132,15 +140,21 @@ class CoinTrainer(BASE_Trainer):
                 ema_due_or_first = ema_due
             side = self._teacher_stream
             if ema_due_or_first:
-                side.wait_stream(torch.cuda.current_stream(self.device))
+                side.wait_stream(main)
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            strong, weak = next(self._data_loader_iter)
             if ema_due:
                 self.update_teacher(cfg.CLOUD.EMA_KEEP_RATE_OFFLINE)
             with torch.no_grad():
                 self.offline_teacher.eval()
                 offline_results = self.offline_teacher(weak, branch="test")
                 self.offline_teacher.train()
-                return self.match_boxes(weak, offline_results, to_device=side is None)
+                targets = self.match_boxes(weak, offline_results, to_device=side is None)
+        if side is not None:
+            for d in strong:  # consumed by the main stream (after its wait_stream in run_step)
+                if torch.is_tensor(d.get("image")) and d["image"].is_cuda:
+                    d["image"].record_stream(main)
+        return strong, targets
 
     def _targets_to_device(self, targets):
         """(A, B, C) tuples of `match_boxes(to_device=False)` -> device, on the current (consumer's) stream."""
@@ -157,8 +171,7 @@ class CoinTrainer(BASE_Trainer):
         assert self.model.training, "[PTrainer] model was changed to eval mode!"
         burn = cfg.CLOUD.BURN_UP_STEP
         if self._pending is None:
-            strong, weak = next(self._data_loader_iter)
-            dual_teacher_instances = self._teacher_targets(weak)
+            strong, dual_teacher_instances = self._fetch()
         else:
             strong, dual_teacher_instances = self._pending
             self._pending = None
@@ -211,8 +224,7 @@ class CoinTrainer(BASE_Trainer):
         `train()` AFTER `after_step()`, so a checkpoint written for iteration i holds the teacher as iteration i left it
         (the reference saves in after_step, before the next iteration's EMA: trainer.py:149-172)."""
         if self._pending is None and self.iter < self.max_iter:
-            strong, weak = next(self._data_loader_iter)
-            self._pending = (strong, self._teacher_targets(weak))
+            self._pending = self._fetch()
 
     def resume_or_load(self, resume: bool = False):
         """trainer.py:220-262: ``MODEL.WEIGHTS`` = "offline_teacher.pth+cloud_results.pth" (start of adaptation) or one CoinTrainer

@@ -144,7 +144,23 @@ class PascalVOCEvaluator:
             out[thr] = voc_ap(rec, prec, self._is_2007) * 100
         return out
 
+    def _gather(self):
+        """The test loader shards the images over the ranks (InferenceSampler): every rank evaluates on the union of the
+        predictions (the reference gathers them on rank 0, pascal_voc_evaluation.py `comm.gather`)."""
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        parts = [None] * dist.get_world_size()
+        dist.all_gather_object(parts, dict(self._lines))
+        merged = defaultdict(list)
+        for part in parts:            # rank order: the same rows in the same order on every rank
+            for cls, rows in part.items():
+                merged[cls].extend(rows)
+        self._lines = merged
+
     def evaluate(self) -> "OrderedDict[str, Dict[str, float]]":
+        self._gather()
         per_class = [self._class_ap(c) for c in range(len(self._class_names))]
         mean = {thr: float(np.mean([pc[thr] for pc in per_class])) for thr in self.THRESHOLDS}
         res = OrderedDict()

@@ -73,3 +73,41 @@ def test_grad_reducer_rejects_a_second_gradient_for_one_parameter_in_a_step():
     with pytest.raises(RuntimeError, match="second gradient"):
         (w * 3).sum().backward()
     red.remove()
+
+
+def test_lazy_test_set_is_sharded_and_mapped_on_demand():
+    """Round-2 ADVICE: the evaluation set is mapped image by image when it is reached (not kept on the device), sharded over the ranks."""
+    from coin_amd.data import LazyTestSet
+    from coin_amd.engine.base import BASE_Trainer
+
+    dicts = [{"image_id": f"{i:03d}"} for i in range(7)]
+    mapped = []
+
+    def mapper(d):
+        mapped.append(d["image_id"])
+        return {"image_id": d["image_id"], "image": torch.zeros(3, 4, 4)}
+
+    shards = [LazyTestSet(None, dicts, mapper=mapper, rank=r, world_size=2) for r in range(2)]
+    assert [len(s) for s in shards] == [4, 3] and mapped == []          # nothing mapped at construction
+    assert [d["image_id"] for d in shards[0]] + [d["image_id"] for d in shards[1]] == [d["image_id"] for d in dicts]
+
+    class Model(torch.nn.Module):
+        def forward(self, batch, branch="test"):
+            return [{"n": len(batch)} for _ in batch]
+
+    class Ev:
+        def reset(self):
+            self.seen = []
+
+        def process(self, inputs, outputs):
+            self.seen.append(([i["image_id"] for i in inputs], len(mapped)))
+
+        def evaluate(self):
+            return self.seen
+
+    mapped.clear()
+    seen = BASE_Trainer.test(Model(), shards[0], Ev(), batch_size=3)
+    # batches of 3 + the remainder; when the first batch is processed only its 3 images have been mapped
+    assert [ids for ids, _ in seen] == [["000", "001", "002"], ["003"]] and seen[0][1] == 3
+    mapped.clear()
+    assert len(BASE_Trainer.test(Model(), shards[0], Ev(), batch_size=1)) == 4   # re-iterable: a second evaluation maps again

@@ -147,3 +147,68 @@ def test_pretrainer_trains_from_image_files_through_the_gpu_mapper(tmp_path):
     recs = [{k: float(v) for k, v in tr.run_step().items()} for _ in range(3)]
     assert all(np.isfinite(v) for r in recs for v in r.values()), recs
     assert recs[0] != recs[2]
+
+
+def test_cointrainer_teacher_stream_sees_the_views_the_loader_wrote(tmp_path):
+    """Round-2 ADVICE (high): with real files the loader's upload + coin_aug_* kernels WRITE the weak / strong views; drawn on the main
+    stream (behind the student's backward) while the teacher ran on its own stream, the teacher read unwritten buffers.  `_fetch`
+    now draws the batch on the teacher stream.  Here the main stream is kept busy before every fetch; the checksums of the weak views
+    the teacher receives (taken on ITS stream) and the strong views the student receives must equal those of a synchronous run."""
+    from PIL import Image
+
+    from coin_amd.config import get_cfg
+    from coin_amd.data import build_detection_unsupervised_train_loader
+    from coin_amd.data.synthetic import SyntheticTeacherCache, synthetic_teacher_result
+    from coin_amd.engine import CoinTrainer
+    import os
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "coin", "GDINO", "foggy_synthetic.yaml")
+    g = torch.Generator().manual_seed(0)
+    files = []
+    for i, (h, w) in enumerate([(300, 500), (320, 480), (375, 500), (333, 500)]):
+        fn = str(tmp_path / f"{i:06d}.png")
+        Image.fromarray(_img(60 + i, h, w), "RGB").save(fn)
+        files.append((fn, f"{i:06d}", h, w))
+
+    def run(teacher_stream: bool):
+        cfg = get_cfg()
+        cfg.merge_from_file(root)
+        cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", 2, "AMD.SYNTHETIC.ENABLED", False, "AMD.TEXT_TEMPLATES", 2, "MODEL.DEVICE", "cuda:0",
+                             "INPUT.MIN_SIZE_TRAIN", (256,), "INPUT.MAX_SIZE_TRAIN", 448, "INPUT.FORMAT", "RGB", "DATALOADER.NUM_WORKERS", 2, "SEED", 3,
+                             "AMD.TEACHER_STREAM", teacher_stream])
+        gg = torch.Generator().manual_seed(0)
+        cache, dicts = SyntheticTeacherCache(), []
+        for fn, iid, h, w in files:
+            dicts.append({"file_name": fn, "image_id": iid, "height": h, "width": w})
+            cache.add(synthetic_teacher_result(fn, iid, h, w, 12, len(cfg.AMD.CLASS_NAMES), gg))
+        torch.manual_seed(3)
+        np.random.seed(3)
+        random.seed(3)
+        loader = build_detection_unsupervised_train_loader(cfg, dicts)
+        tr = CoinTrainer(cfg, data_loader=loader, cloud_results=cache)
+        seen = []
+        real = tr.offline_teacher.forward
+
+        def spy(batch, *a, **k):
+            seen.append(torch.stack([d["image"].double().sum() for d in batch]))  # on the stream the teacher runs on
+            return real(batch, *a, **k)
+
+        tr.offline_teacher.forward = spy
+        busy = torch.randn(4096, 4096, device="cuda")
+        sums = []
+        for _ in range(3):
+            for _ in range(40):   # the "student's backward" still queued on the main stream when the next batch is drawn
+                busy = (busy @ busy).clamp_(-1, 1)
+            strong, _targets = tr._fetch()
+            if tr._teacher_stream is not None:
+                torch.cuda.current_stream().wait_stream(tr._teacher_stream)
+            sums.append(torch.stack([d["image"].double().sum() for d in strong]))
+        torch.cuda.synchronize()
+        assert (tr._teacher_stream is not None) == teacher_stream
+        return torch.stack(seen).cpu(), torch.stack(sums).cpu()
+
+    weak_a, strong_a = run(True)
+    weak_b, strong_b = run(False)
+    assert torch.equal(weak_a, weak_b), (weak_a, weak_b)
+    assert torch.equal(strong_a, strong_b)
+    assert float(weak_a.min()) > 0

@@ -52,6 +52,13 @@ static void fill(void* p, size_t n, uint32_t seed, float scale) {
   CK(hipGetLastError());
 }
 
+static bool g_cold = false;       // "cold": a 640 MB fill between launches evicts L2 / Infinity Cache (what a training step sees)
+static void* g_flush = nullptr;
+static void flush_caches() {
+  if (!g_flush) CK(hipMalloc(&g_flush, (size_t)640 << 20));
+  fill(g_flush, (size_t)320 << 20, 0xabcdu, 1.0f);
+}
+
 struct Shape {
   const char* name;
   int nb, h, w, ci, co, ks;
@@ -199,11 +206,23 @@ static void bench_shape(const Shape& sh, int iters, int rounds) {
       for (int v = 0; v < 3; ++v) {
         if (dir == 1 && stats[v]) continue;
         run_gemm(impls[v], A, Cin, mode, sh.h, sh.w, Cin, B, K, C, N, nullptr, 0, M, N, K, stats[v] ? S : nullptr, M);  // warm
-        CK(hipEventRecord(e0));
-        for (int i = 0; i < iters; ++i) run_gemm(impls[v], A, Cin, mode, sh.h, sh.w, Cin, B, K, C, N, nullptr, 0, M, N, K, stats[v] ? S : nullptr, M);
-        CK(hipEventRecord(e1));
-        CK(hipEventSynchronize(e1));
-        const float ms = time_ms(e0, e1) / iters;
+        float ms = 0;
+        if (g_cold) {
+          for (int i = 0; i < iters; ++i) {
+            flush_caches();
+            CK(hipEventRecord(e0));
+            run_gemm(impls[v], A, Cin, mode, sh.h, sh.w, Cin, B, K, C, N, nullptr, 0, M, N, K, stats[v] ? S : nullptr, M);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            ms += time_ms(e0, e1) / iters;
+          }
+        } else {
+          CK(hipEventRecord(e0));
+          for (int i = 0; i < iters; ++i) run_gemm(impls[v], A, Cin, mode, sh.h, sh.w, Cin, B, K, C, N, nullptr, 0, M, N, K, stats[v] ? S : nullptr, M);
+          CK(hipEventRecord(e1));
+          CK(hipEventSynchronize(e1));
+          ms = time_ms(e0, e1) / iters;
+        }
         med[v].push_back(ms);
         best[v] = std::min(best[v], ms);
       }
@@ -301,11 +320,24 @@ static void bench_wgrad(const Shape& sh, int iters, int rounds) {
   for (int r = 0; r < rounds; ++r)
     for (int v = 0; v < 2; ++v) {
       run_wgrad(impls[v], GY, X, mode, sh.h, sh.w, sh.ci, M, sh.co, Ktot, dW, ws);
-      CK(hipEventRecord(e0));
-      for (int i = 0; i < iters; ++i) run_wgrad(impls[v], GY, X, mode, sh.h, sh.w, sh.ci, M, sh.co, Ktot, dW, ws);
-      CK(hipEventRecord(e1));
-      CK(hipEventSynchronize(e1));
-      med[v].push_back(time_ms(e0, e1) / iters);
+      float ms = 0;
+      if (g_cold) {
+        for (int i = 0; i < iters; ++i) {
+          flush_caches();
+          CK(hipEventRecord(e0));
+          run_wgrad(impls[v], GY, X, mode, sh.h, sh.w, sh.ci, M, sh.co, Ktot, dW, ws);
+          CK(hipEventRecord(e1));
+          CK(hipEventSynchronize(e1));
+          ms += time_ms(e0, e1) / iters;
+        }
+      } else {
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < iters; ++i) run_wgrad(impls[v], GY, X, mode, sh.h, sh.w, sh.ci, M, sh.co, Ktot, dW, ws);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        ms = time_ms(e0, e1) / iters;
+      }
+      med[v].push_back(ms);
     }
   const double flop = 2.0 * M * (double)sh.co * Ktot;
   printf("{\"shape\": \"%s\", \"dir\": \"wgrad\", \"M\": %d, \"Cout\": %d, \"Ktot\": %d", sh.name, M, sh.co, Ktot);
@@ -363,6 +395,7 @@ static void bench_debug(int iters) {
 int main(int argc, char** argv) {
   const char* what = argc > 1 ? argv[1] : "all";
   const int iters = argc > 2 ? atoi(argv[2]) : 10;
+  g_cold = argc > 3 && !strcmp(argv[3], "cold");
   int fails = 0;
   if (!strcmp(what, "check") || !strcmp(what, "all")) {
     // 1x1 classes
@@ -389,11 +422,11 @@ int main(int argc, char** argv) {
     printf("WCHECK total failures: %d\n", fails);
   }
   if (!strcmp(what, "bench") || !strcmp(what, "all")) {
-    for (const Shape& s : kShapes) bench_shape(s, iters, 5);
+    for (const Shape& s : kShapes) bench_shape(s, iters, g_cold ? 2 : 5);
   }
   if (!strcmp(what, "dbg")) bench_debug(iters);
   if (!strcmp(what, "wbench") || !strcmp(what, "all")) {
-    for (const Shape& s : kShapes) bench_wgrad(s, iters, 5);
+    for (const Shape& s : kShapes) bench_wgrad(s, iters, g_cold ? 2 : 5);
   }
   return fails ? 1 : 0;
 }

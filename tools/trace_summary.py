@@ -14,6 +14,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("trace")
 ap.add_argument("out")
 ap.add_argument("--window-ms", type=float, default=300.0)
+ap.add_argument("--list", default=None, help="also list every dispatch whose name contains this string inside the last --list-ms of the trace")
+ap.add_argument("--list-ms", type=float, default=45.0)
 a = ap.parse_args()
 rows = []
 with open(a.trace) as f:
@@ -38,3 +40,14 @@ with open(a.out, "w") as f:
 print(f"window {a.window_ms} ms: busy {busy/1e6:.1f} ms over {len(items)} kernels")
 for n, (c, t) in items[:40]:
     print(f"{t/1e6:8.2f} ms {100.0*t/busy:5.1f}% n={c:5d} avg={t/c/1e3:9.1f}us {n[:100]}")
+
+if a.list:
+    # each matching dispatch of the last `list-ms`: start offset, duration, and how much OTHER kernel time overlaps it (side streams)
+    lo2 = end - int(a.list_ms * 1e6)
+    sel = [(s, e, n) for s, e, n in rows if s >= lo2]
+    print(f"-- dispatches containing '{a.list}' in the last {a.list_ms} ms (offset ms, duration us, overlapped-by-others us, name)")
+    for s0, e0, n in sorted(sel):
+        if a.list not in n:
+            continue
+        ov = sum(max(0, min(e0, e1) - max(s0, s1)) for s1, e1, n1 in sel if (s1, e1, n1) != (s0, e0, n))
+        print(f"{(s0 - lo2) / 1e6:8.3f} {(e0 - s0) / 1e3:9.1f} {ov / 1e3:9.1f}  {n[:90]}")

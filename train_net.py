@@ -76,7 +76,7 @@ def main(args):
         # -> strong / weak views on the GPU -> two-crop batches; the cached teacher results arrive with MODEL.WEIGHTS (resume_or_load)
         import os.path as osp
 
-        from coin_amd.data import build_detection_test_loader, build_detection_unsupervised_train_loader
+        from coin_amd.data import LazyTestSet, build_detection_unsupervised_train_loader
         from coin_amd.data.catalog import SPLITS, dataset_root, get_detection_dataset_dicts, thing_classes
         from coin_amd.evaluation import PascalVOCEvaluator
 
@@ -87,8 +87,9 @@ def main(args):
         if cfg.DATASETS.TEST and cfg.TEST.EVAL_PERIOD >= 0:
             name = cfg.DATASETS.TEST[0]
             dirname, split = osp.join(dataset_root(), SPLITS[name][0]), SPLITS[name][1]
-            items = [b[0] for b in build_detection_test_loader(cfg, get_detection_dataset_dicts([name]))]
-            trainer.set_evaluation(items, lambda: PascalVOCEvaluator(dirname, split, thing_classes(name), year=2012))
+            # lazily mapped, sharded over the ranks; the evaluator gathers the predictions (coin/data/build.py:28-53 + inference_on_dataset)
+            trainer.set_evaluation(LazyTestSet(cfg, get_detection_dataset_dicts([name]), rank=rank, world_size=world),
+                                   lambda: PascalVOCEvaluator(dirname, split, thing_classes(name), year=2012))
     if hasattr(trainer, "resume_or_load"):
         trainer.resume_or_load(resume=args.resume)
     trainer.train()
