@@ -91,6 +91,9 @@ class CoinTrainer(BASE_Trainer):
                          [(t_sd[k], s_sd[k]) for k, v in t_sd.items() if v.dtype != torch.float32])
         table, others = self._ema
         table.update(keep_rate)
+        for m in self.offline_teacher.modules():   # the kernel writes through raw pointers: drop results cached on the old prompt vectors
+            if hasattr(m, "invalidate_text_cache"):
+                m.invalidate_text_cache()
         for t, s in others:  # integer buffers (num_batches_tracked): float arithmetic, then truncation on the copy
             t.copy_(s * (1 - keep_rate) + t * keep_rate)
 

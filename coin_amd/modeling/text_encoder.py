@@ -131,15 +131,23 @@ class TEXT_ENCODER(nn.Module):
         self.text_projection.requires_grad = False
         self.logit_scale.requires_grad = False
 
-    def forward(self, text, add: bool):
-        if add:
-            n = self.embedding_class.size(0)
-            ex = lambda p: p.unsqueeze(0).expand(n, -1, -1)
-            x = torch.cat([ex(self.sos), ex(self.embedding_tmp), ex(self.add_in_embedding), self.embedding_class, ex(self.eos)], dim=1)
-            eot = self.tokenized_prompts.argmax(dim=-1)
-        else:
-            x = self.token_embedding(text.long())
-            eot = text.argmax(dim=-1)
+    # ---- the prompt-conditioned pass (clip_text.py:165-205 with `add=True`) ------------------------------------------------------
+    # Shapes are static (classes x 77 x width) and the transformer is frozen: the ~300 forward and ~300 backward launches of the
+    # 12 blocks are captured ONCE as two HIP graphs (torch.cuda.make_graphed_callables; the prompt vectors are the graph's inputs
+    # and receive its gradients) and replayed with two launches per step; without a gradient (the EMA teacher's inference) the result
+    # is cached until the prompt vectors change (`invalidate_text_cache`, called after an EMA; in-place loads bump `_version`).
+    use_graph = True           # cfg.AMD.TEXT_GRAPH
+    _graphs = None             # (autocast dtype or None) -> graphed callable
+    _nograd_cache = None       # (key, tensor)
+    _graph_failed = False
+
+    def _prompted(self, embedding_tmp, add_in_embedding):
+        n = self.embedding_class.size(0)
+        ex = lambda p: p.unsqueeze(0).expand(n, -1, -1)
+        x = torch.cat([ex(self.sos), ex(embedding_tmp), ex(add_in_embedding), self.embedding_class, ex(self.eos)], dim=1)
+        return self._encode(x, self.tokenized_prompts.argmax(dim=-1))
+
+    def _encode(self, x, eot):
         x = x.float() + self.positional_embedding
         if x.is_cuda and torch.is_autocast_enabled("cuda"):
             # bf16 throughput mode: keep the residual stream in the compute dtype, as the reference's fp16 encoder does
@@ -150,17 +158,70 @@ class TEXT_ENCODER(nn.Module):
         x = x @ L.compute_weight(self.text_projection, L.compute_dtype_of(x))
         return x / torch.norm(x, dim=-1, keepdim=True)
 
+    def invalidate_text_cache(self):
+        self._nograd_cache = None
+
+    def _prompt_key(self):
+        a, b = self.embedding_tmp, self.add_in_embedding
+        ac = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None
+        return (a.data_ptr(), a._version, b.data_ptr(), b._version, ac)
+
+    def _graphed(self):
+        """-> graphed callable for the current autocast mode (built on first use), or None if capture is not possible here."""
+        ac = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None
+        if self._graphs is None:
+            self._graphs = {}
+        if ac not in self._graphs:
+            def fn(tmp, add):
+                with torch.autocast("cuda", dtype=ac or torch.bfloat16, enabled=ac is not None, cache_enabled=False):
+                    return self._prompted(tmp, add)
+            sample = tuple(t.detach().clone().requires_grad_(True) for t in (self.embedding_tmp, self.add_in_embedding))
+            try:
+                with torch.autocast("cuda", enabled=False):
+                    self._graphs[ac] = torch.cuda.make_graphed_callables(fn, sample)
+            except Exception as e:  # same device path either way: eager launches of the same kernels
+                import warnings
+
+                warnings.warn(f"text encoder: HIP graph capture failed ({type(e).__name__}: {e}); running it eagerly")
+                self._graph_failed = True
+                return None
+        return self._graphs[ac]
+
+    def forward(self, text, add: bool):
+        if not add:
+            return self._encode(self.token_embedding(text.long()), text.argmax(dim=-1))
+        tmp, addv = self.embedding_tmp, self.add_in_embedding
+        needs_grad = torch.is_grad_enabled() and (tmp.requires_grad or addv.requires_grad)
+        if not tmp.is_cuda:
+            return self._prompted(tmp, addv)
+        if not needs_grad:
+            if tmp.requires_grad or addv.requires_grad:
+                # a trainable copy evaluated without a gradient (student in eval mode): the fused SGD kernel rewrites the prompt
+                # vectors through raw pointers without a version bump, so nothing may be cached here
+                return self._prompted(tmp, addv)
+            key = self._prompt_key()   # frozen copy (the EMA teacher): changes only through update_teacher / load_state_dict
+            if self._nograd_cache is None or self._nograd_cache[0] != key:
+                with torch.no_grad():
+                    self._nograd_cache = (key, self._prompted(tmp, addv))
+            return self._nograd_cache[1]
+        if self.use_graph and not self._graph_failed and not torch.cuda.is_current_stream_capturing():
+            g = self._graphed()
+            if g is not None:
+                return g(tmp, addv)
+        return self._prompted(tmp, addv)
+
 
 @TEXT_ENCODER_REGISTRY.register()
 class CLIP_TEXT(nn.Module):
     def __init__(self, type: str, classes: List[str], add_prompt_num: int = 4, dataset_style: str = "", embed_dim=None,
                  context_length=77, vocab_size=49408, width=512, heads=8, layers=12, tokenized_prompts=None,
-                 n_templates: int = N_TEMPLATES):
+                 n_templates: int = N_TEMPLATES, graph: bool = True):
         super().__init__()
         self.type, self.classes, self.dataset_style, self.add_prompt_num = type, list(classes), dataset_style, add_prompt_num
         embed_dim = embed_dim or TEXT_DIMS[type]
         toks = tokenized_prompts if tokenized_prompts is not None else prompt_tokens(len(classes), context_length, add_prompt_num, vocab_size=vocab_size)
         self.encoder = TEXT_ENCODER(embed_dim, context_length, vocab_size, width, heads, layers, (toks, len(TEMPLATE_IDS), add_prompt_num))
+        self.encoder.use_graph = bool(graph)
         self.n_templates = n_templates
         self.load_embedding()
 
@@ -173,7 +234,7 @@ class CLIP_TEXT(nn.Module):
         return cls(type=cfg.MODEL.TEACHER_OFFLINE.TYPE or "RN50", classes=classes, add_prompt_num=cfg.CLOUD.ADD_PROMPT_NUM,
                    dataset_style=cfg.DATASETS.STYLE_NAME, n_templates=cfg.AMD.TEXT_TEMPLATES, embed_dim=a.TEXT_DIM or None,
                    context_length=a.CONTEXT_LENGTH, vocab_size=a.VOCAB_SIZE, width=a.TEXT_WIDTH or 512, heads=a.TEXT_HEADS or 8,
-                   layers=a.TEXT_LAYERS or 12)
+                   layers=a.TEXT_LAYERS or 12, graph=bool(getattr(cfg.AMD, "TEXT_GRAPH", True)))
 
     @torch.no_grad()
     def load_embedding(self):
