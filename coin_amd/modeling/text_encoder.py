@@ -12,6 +12,8 @@ CLIP-initialised at random (clip_text.py:65-79) and prompts use CLIP's token ids
 from __future__ import annotations
 
 import math
+import os
+import weakref
 from collections import OrderedDict
 from typing import List, Sequence
 
@@ -204,11 +206,28 @@ class TEXT_ENCODER(nn.Module):
                 with torch.no_grad():
                     self._nograd_cache = (key, self._prompted(tmp, addv))
             return self._nograd_cache[1]
-        if self.use_graph and not self._graph_failed and not torch.cuda.is_current_stream_capturing():
+        # only on the default stream: replayed from the pre-train step's side stream (beside the backbone) the two graphs cost 30 ms per
+        # step on this runtime (bench.py 37.1 -> 67.9 ms, round-3 A/B), on the main stream of the targetDET step they save 0-4 ms
+        if (self.use_graph and not self._graph_failed and not torch.cuda.is_current_stream_capturing() and not self._graph_busy()
+                and torch.cuda.current_stream(tmp.device) == torch.cuda.default_stream(tmp.device)):
             g = self._graphed()
             if g is not None:
-                return g(tmp, addv)
+                out = g(tmp, addv)
+                # the graphs own ONE set of activation buffers: until this output has been back-propagated (or dropped) a second
+                # pass must not replay them (the step branches classify twice per forward when `shared_text` is off)
+                self._inflight = weakref.ref(out)
+                out.register_hook(self._graph_done)
+                return out
         return self._prompted(tmp, addv)
+
+    _inflight = None
+
+    def _graph_done(self, grad):
+        self._inflight = None
+        return grad
+
+    def _graph_busy(self) -> bool:
+        return self._inflight is not None and self._inflight() is not None
 
 
 @TEXT_ENCODER_REGISTRY.register()
@@ -234,7 +253,8 @@ class CLIP_TEXT(nn.Module):
         return cls(type=cfg.MODEL.TEACHER_OFFLINE.TYPE or "RN50", classes=classes, add_prompt_num=cfg.CLOUD.ADD_PROMPT_NUM,
                    dataset_style=cfg.DATASETS.STYLE_NAME, n_templates=cfg.AMD.TEXT_TEMPLATES, embed_dim=a.TEXT_DIM or None,
                    context_length=a.CONTEXT_LENGTH, vocab_size=a.VOCAB_SIZE, width=a.TEXT_WIDTH or 512, heads=a.TEXT_HEADS or 8,
-                   layers=a.TEXT_LAYERS or 12, graph=bool(getattr(cfg.AMD, "TEXT_GRAPH", True)))
+                   layers=a.TEXT_LAYERS or 12,
+                   graph=bool(getattr(cfg.AMD, "TEXT_GRAPH", True)) and os.environ.get("COIN_TEXT_GRAPH", "1") != "0")
 
     @torch.no_grad()
     def load_embedding(self):
