@@ -10,10 +10,11 @@
 // All row-blocks of one RoI are placed on one XCD (blocks b and b+8 share an XCD) so that the
 // RoI's footprint is fetched into a single L2.
 //
-// Backward is a separable gather per RoI (see the kernel): the RoI's gradient tile is staged in LDS once,
-// every footprint pixel of the map contracts the few bins that touch it and receives ONE 256-byte-contiguous
-// float atomic: ~(samples*4)/(footprint) fewer global atomics than the per-tap scheme, which is what bounds a
-// naive backward on this chip (~1.3 TB/s of atomic bytes, MI355X_MICROARCH.md "Global float atomics").
+// Backward (NHWC, bins up to 16 x 16: every shape the detector uses) is an atomic-free gather per 4 x 8 map tile x channel slab
+// (roi_align_bwd_gather_kernel): the RoIs that touch the tile are walked in index order, the per-(RoI, tile) bilinear weight
+// tables are built once per workgroup in LDS, every map element is stored exactly once in a fixed summation order
+// (bit-reproducible).  Larger bins fall back to a separable per-RoI gather with one float atomic per footprint pixel
+// (roi_align_bwd_nhwc_kernel; float atomics are bounded at ~1.3 TB/s of added bytes, MI355X_MICROARCH.md).
 //
 // The NCHW kernels are the layout-compatible (reference layout) path: one thread per element.
 #include <stdlib.h>
@@ -154,139 +155,8 @@ __device__ __forceinline__ float bin_weight(float start, float binsz, int grid, 
 
 
 // ------------------------------------------------------------------------------------------
-// forward, NHWC, separable gather (the shipped NHWC path for pw <= 16):
-//   out[py][px][c] = 1/count * sum_y Wy[py][y] * sum_x Wx[px][x] * feat[y][x][c]
-// Wy[py][y] / Wx[px][x] = summed bilinear weight that the samples of bin row py / bin column px put on map row y / column x
-// (exactly the per-sample arithmetic of torchvision's bilinear_interpolate, `axis_taps`).  A block owns one RoI x one channel
-// part (lane = one 16-byte channel vector, a wave spans 64 of them); it builds the RoI's column table Wx once in LDS.  A work
-// item = (bin row py, 8 consecutive bin columns): its wave keeps the 8 output vectors in registers, walks the (few) map rows
-// with non-zero Wy[py][.] and, on each, the footprint columns of its 8 bins ONCE -- every loaded 16-byte vector is converted
-// once and fanned out to the bins that touch it.  Against the per-sample loop (4 taps x gh x gw samples per output vector)
-// this moves 2.5-5x fewer bytes through the vector L1, which is what bounded that kernel (0.26 of the HBM peak).
-// ------------------------------------------------------------------------------------------
-constexpr int FWD_NB = 8;   // bins per work item = accumulator vectors per lane
-constexpr int FWD_NX = 8;   // map columns requested together
-
-template <typename T>
-__global__ __launch_bounds__(256) void roi_align_fwd_sep_kernel(
-    const T* __restrict__ feat, const float* __restrict__ rois, T* __restrict__ out, int C, int H, int W, int R, int ph, int pw,
-    float scale, int sampling_ratio, int aligned, int nparts) {
-  constexpr int VEC = Vec16<T>::N;
-  typedef typename Vec16<T>::type vec_t;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* wx = reinterpret_cast<float*>(smem);                  // [W][16]
-  unsigned* xmask = reinterpret_cast<unsigned*>(wx + (size_t)W * 16);  // [W] bit px: bin column px has weight on column x
-  int* xr = reinterpret_cast<int*>(xmask + W);                  // [2 halves][lo, hi]
-  const int roi = blockIdx.x / nparts, part = blockIdx.x - roi * nparts;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c0 = (part * 64 + lane) * VEC;
-  const bool c_ok = c0 < C;
-  const RoiGeom g = roi_geom(rois + (size_t)roi * 5, ph, pw, scale, sampling_ratio, aligned);
-
-  for (int i = threadIdx.x; i < W * 16; i += 256) wx[i] = 0.f;
-  if (threadIdx.x < 4) xr[threadIdx.x] = (threadIdx.x & 1) ? -1 : W;
-  __syncthreads();
-  if ((int)threadIdx.x < pw) {  // one thread per bin column: only it writes wx[.][px]
-    const int px = threadIdx.x;
-    for (int ix = 0; ix < g.gw; ++ix) {
-      const float x = g.x0 + (float)px * g.bw + ((float)ix + 0.5f) * g.bw / (float)g.gw;
-      int lo, hi;
-      float wl, wh;
-      if (!axis_taps(x, W, lo, hi, wl, wh)) continue;
-      wx[lo * 16 + px] += wl;
-      wx[hi * 16 + px] += wh;
-    }
-  }
-  __syncthreads();
-  for (int x = threadIdx.x; x < W; x += 256) {
-    unsigned m = 0;
-    for (int px = 0; px < pw; ++px) m |= (wx[x * 16 + px] != 0.f ? 1u : 0u) << px;
-    xmask[x] = m;
-    if (m & 0xffu) { atomicMin(&xr[0], x); atomicMax(&xr[1], x); }
-    if (m >> 8) { atomicMin(&xr[2], x); atomicMax(&xr[3], x); }
-  }
-  __syncthreads();
-
-  const int nh = (pw + FWD_NB - 1) / FWD_NB;
-  const T* __restrict__ fmap = feat + (size_t)g.n * H * W * C + (c_ok ? c0 : 0);  // lanes beyond C read channel 0 (never stored)
-  for (int item = wave; item < ph * nh; item += 4) {
-    const int py = item / nh, hx = item - py * nh;
-    const int pb = hx * FWD_NB;
-    const int xlo = xr[2 * hx], xhi = xr[2 * hx + 1];
-    float acc[FWD_NB][VEC];
-#pragma unroll
-    for (int t = 0; t < FWD_NB; ++t)
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[t][i] = 0.f;
-    if (g.gh > 0 && xhi >= xlo) {
-      // map rows that the samples of bin row py can touch
-      const float ysa = g.y0 + (float)py * g.bh + 0.5f * g.bh / (float)g.gh;
-      const float ysb = g.y0 + (float)py * g.bh + ((float)g.gh - 0.5f) * g.bh / (float)g.gh;
-      const float ymin = fminf(ysa, ysb), ymax = fmaxf(ysa, ysb);
-      int ylo = (int)floorf(fmaxf(ymin, 0.f)), yhi = (int)floorf(fminf(fmaxf(ymax, 0.f), (float)(H - 1))) + 1;
-      ylo = ylo > H - 1 ? H - 1 : ylo;
-      yhi = yhi > H - 1 ? H - 1 : yhi;
-      if (!(ymax < -1.0f || ymin > (float)H)) {
-        for (int ybase = ylo; ybase <= yhi; ybase += 64) {
-          const int yl = ybase + lane;
-          const float wr = yl <= yhi ? bin_weight(g.y0, g.bh, g.gh, py, yl, H) * g.inv_count : 0.f;
-          unsigned long long rows = __ballot(wr != 0.f);
-          while (rows) {
-            const int r = __builtin_ctzll(rows);
-            rows &= rows - 1;
-            const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wr), r));
-            const T* __restrict__ rowp = fmap + (size_t)(ybase + r) * W * C;
-            for (int x = xlo; x <= xhi; x += FWD_NX) {
-              // every column of the segment is requested before the first is used: the loop is bound by load latency, not by
-              // bytes (FWD_NX x 1 KiB in flight per wave)
-              vec_t v[FWD_NX];
-#pragma unroll
-              for (int j = 0; j < FWD_NX; ++j) {
-                const int xx = x + j <= xhi ? x + j : xhi;  // clamped: the tail re-reads a valid column, its mask is skipped
-                v[j] = *reinterpret_cast<const vec_t*>(rowp + (size_t)xx * C);
-              }
-#pragma unroll
-              for (int j = 0; j < FWD_NX; ++j) {
-                if (x + j > xhi) break;
-                const unsigned mk = ((unsigned)__builtin_amdgcn_readfirstlane((int)xmask[x + j]) >> pb) & 0xffu;
-                if (mk == 0) continue;
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(&wx[(x + j) * 16 + pb]);
-                const f32x4 w1 = *reinterpret_cast<const f32x4*>(&wx[(x + j) * 16 + pb + 4]);
-                float vf[VEC];
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) vf[i] = (float)v[j][i];
-#pragma unroll
-                for (int t = 0; t < FWD_NB; ++t) {
-                  if (mk & (1u << t)) {
-                    asm volatile("; bin taken");  // keeps this a (wave-uniform) branch: hipcc otherwise if-converts it into 8 FMAs + 8 selects per bin
-                    const float wt = a * (t < 4 ? w0[t & 3] : w1[t & 3]);
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) acc[t][i] += wt * vf[i];
-                  }
-                }
-              }
-            }
-          }
-        }
-      }
-    }
-    if (c_ok) {
-      T* __restrict__ orow = out + (((size_t)roi * ph + py) * pw + pb) * C + c0;
-#pragma unroll
-      for (int t = 0; t < FWD_NB; ++t) {
-        if (pb + t < pw) {
-          vec_t o;
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) o[i] = (T)acc[t][i];
-          __builtin_nontemporal_store(o, reinterpret_cast<vec_t*>(orow + (size_t)t * C));
-        }
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// backward, NHWC: separable gather.
+// backward, NHWC, bins larger than 16 x 16 only (the tile-gather kernel below serves the detector's 14 x 14 / 7 x 7 bins): separable gather
+// with float atomics.
 //   d feat[y][x][c] = sum_py sum_px Wy[py][y] * Wx[px][x] * gout[py][px][c] / count
 // Wy[py][y] (resp. Wx) is the summed bilinear weight of all samples of bin row py that touch map row y.
 // A block owns one RoI x 64 channels (lane = channel): it builds the two small weight tables in LDS,
@@ -692,24 +562,9 @@ extern "C" int coin_roi_align_fwd(const void* feat, int N, int C, int H, int W, 
   if (rc) return rc;
   if (R == 0) return COIN_OK;
   hipStream_t st = (hipStream_t)stream;
-  // Forward variants (both exact to rounding): 0 = one thread per output vector, 4 taps per sample (wins on the detector's
-  // proposal mix, where half of the RoIs are smaller than 64 px: measured 0.39 ms against 0.50 ms at the benchmark shape);
-  // 1 = separable gather with register-resident output rows (wins on large RoIs: 0.46 ms against 0.51 ms on a uniform
-  // 32..400 px mix).  The shipped choice is 0; COIN_ROI_ALIGN_FWD=1 selects the other one for measurements.
-  static const int variant = [] { const char* e = getenv("COIN_ROI_ALIGN_FWD"); return e && e[0] == '1' ? 1 : 0; }();
-  const size_t sep_lds = sizeof(float) * (size_t)W * 16 + sizeof(unsigned) * (size_t)W + 4 * sizeof(int);
-  if (layout == COIN_NHWC && pw <= 2 * FWD_NB && sep_lds <= 64 * 1024 && variant == 1) {
-    // separable gather with register-resident output rows (see the kernel)
-    if (dtype == COIN_F32) {
-      const int nparts = (C + 64 * 4 - 1) / (64 * 4);
-      roi_align_fwd_sep_kernel<float><<<R * nparts, 256, sep_lds, st>>>((const float*)feat, rois, (float*)out, C, H, W, R, ph, pw,
-                                                                        spatial_scale, sampling_ratio, aligned, nparts);
-    } else {
-      const int nparts = (C + 64 * 8 - 1) / (64 * 8);
-      roi_align_fwd_sep_kernel<bf16_t><<<R * nparts, 256, sep_lds, st>>>((const bf16_t*)feat, rois, (bf16_t*)out, C, H, W, R, ph, pw,
-                                                                         spatial_scale, sampling_ratio, aligned, nparts);
-    }
-  } else if (layout == COIN_NHWC) {
+  // (A separable forward -- row pass into LDS, then a column pass -- was built and measured in round 2: 0.46 ms against 0.40 ms of this
+  // kernel at the benchmark shape; each output needs 4-16 taps out of L2 and the kernel is bound by those gathers, so it was removed.)
+  if (layout == COIN_NHWC) {
     const int grid = ((R + 7) / 8) * 8 * ph;
     if (dtype == COIN_F32)
       roi_align_fwd_nhwc_kernel<float><<<grid, 256, 0, st>>>((const float*)feat, rois, (float*)out, C, H, W, R, ph,
