@@ -232,3 +232,59 @@ def test_inference_fp32_vs_reference_golden():
         assert (ours[:, 0] == ref[:, 0]).all()
         np.testing.assert_allclose(ours[:, 1], ref[:, 1], atol=1e-4)
         np.testing.assert_allclose(ours[:, 2:], ref[:, 2:], atol=2e-2)
+
+
+def test_cointrainer_constructor_teacher_stream_equals_the_synchronous_run_over_ema_iterations():
+    """The real `CoinTrainer(cfg)` constructor, three consecutive `run_step` + `prepare_next` iterations in step_two with an EMA due
+    at EVERY iteration: with `AMD.TEACHER_STREAM` on (the next iteration's EMA / teacher inference / matching are issued on the
+    teacher's stream right after the optimizer step, `prepare_next`) against the same trainer run synchronously (teacher on the
+    main stream, no `prepare_next`).  What must hold for the ordering to be right (trainer.py:149-218, ts_ensemble.py:39-69): the
+    EMA of iteration i+1 reads the weights the optimizer of iteration i wrote, and the optimizer of iteration i+1 does not
+    overtake it -- then the teacher's parameters after every iteration and the number of (A, B, C) targets agree between the two
+    runs (parameters to the run-to-run spread of the library convolutions)."""
+    import os
+    import random
+
+    from coin_amd.config import get_cfg
+    from coin_amd.engine import CoinTrainer
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "coin", "GDINO", "foggy_synthetic.yaml")
+
+    def run(stream: bool):
+        cfg = get_cfg()
+        cfg.merge_from_file(root)
+        cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", 2, "AMD.SYNTHETIC.NUM_IMAGES", 2, "AMD.SYNTHETIC.HEIGHT", 256, "AMD.SYNTHETIC.WIDTH", 384,
+                             "AMD.TEXT_TEMPLATES", 2, "MODEL.DEVICE", "cuda:0", "AMD.COMPUTE_DTYPE", "fp32", "CLOUD.BURN_UP_STEP", 0,
+                             "CLOUD.OFFLINE_TEACHER_UPDATE_ITER", 1, "CLOUD.EMA_KEEP_RATE_OFFLINE", 0.5, "CLOUD.PROTOTYPE_UPDATE_START", 0,
+                             "AMD.TEACHER_STREAM", stream, "SEED", 5])
+        torch.manual_seed(5)
+        np.random.seed(5)
+        random.seed(5)
+        tr = CoinTrainer(cfg)
+        tr.max_iter = 10
+        seen, match = [], tr.match_boxes
+        cnt = lambda x: 0 if x is None else len(x)
+        tr.match_boxes = lambda b, o, **kw: (lambda t: (seen.append([[cnt(x[0]), cnt(x[1]), cnt(x[2])] for x in t[0]]), t)[1])(match(b, o, **kw))
+        teacher_sums, losses = [], []
+        for _ in range(3):
+            rec = tr.run_step()
+            if stream:
+                tr.prepare_next()          # EMA + teacher pass of the NEXT iteration, on the teacher stream, beside this backward
+            torch.cuda.synchronize()
+            losses.append({k: float(v) for k, v in rec.items()})
+            teacher_sums.append(torch.stack([p.detach().double().abs().sum() for p in tr.offline_teacher.parameters()]).cpu())
+        assert (tr._teacher_stream is not None) == stream
+        return seen, teacher_sums, losses
+
+    seen_a, teach_a, loss_a = run(True)
+    seen_b, teach_b, loss_b = run(False)
+    # stream run: the teacher has already taken the EMA of the iteration to come (prepare_next), i.e. it is one EMA AHEAD of the
+    # synchronous run after every step: its state after step i equals the synchronous teacher's state after step i+1's EMA, which the
+    # synchronous run exposes at the end of step i+1 (the EMA is the first thing a step does)
+    for i in range(2):
+        torch.testing.assert_close(teach_a[i], teach_b[i + 1], rtol=2e-4, atol=0)
+    assert seen_a[:3] == seen_b[:3], (seen_a, seen_b)     # the same targets reach the student in both runs
+    for la, lb in zip(loss_a, loss_b):
+        assert set(la) == set(lb)
+        for k in la:
+            assert abs(la[k] - lb[k]) <= 5e-3 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
