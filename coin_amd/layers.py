@@ -454,10 +454,15 @@ class _LinearAct(Function):
                 dzp = dz
             dx = K.gemm_nt(dzp, wt)
         if ctx.needs_input_grad[1]:
-            # dW[N,K] = dZ^T[N,M] . X[M,K]  ==  gemm_nt(dZ^T, X^T); contraction M zero-padded
-            dzt = K.transpose2d(_pad_rows(dz, kmult))   # [N, Mp]
-            xt = K.transpose2d(_pad_rows(x, kmult))     # [K, Mp]
-            dw = K.gemm_nt(dzt, xt, out_dtype=torch.float32)
+            if x.dtype == torch.bfloat16 and K.conv_wgrad_ok(n, x.shape[1]) and x.shape[0] >= 128:
+                # dW[N,K] = dZ^T . X: both operands row-major over the contraction index M -- the transposed-read kernel of the res5
+                # weight gradients takes them as they are (no transposes, no zero padding of M)
+                dw = K.conv_wgrad(dz, x)
+            else:
+                # dW[N,K] = dZ^T[N,M] . X[M,K]  ==  gemm_nt(dZ^T, X^T); contraction M zero-padded
+                dzt = K.transpose2d(_pad_rows(dz, kmult))   # [N, Mp]
+                xt = K.transpose2d(_pad_rows(x, kmult))     # [K, Mp]
+                dw = K.gemm_nt(dzt, xt, out_dtype=torch.float32)
         return dx, dw, (dbias if ctx.has_bias else None), None, None, None, None
 
 
