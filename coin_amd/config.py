@@ -196,6 +196,9 @@ def _d2_defaults() -> CfgNode:
     C.DATALOADER.FILTER_EMPTY_ANNOTATIONS = True
     C.MODEL.BACKBONE = CN({"NAME": "build_resnet_backbone", "FREEZE_AT": 2})
     C.MODEL.PROPOSAL_GENERATOR = CN({"NAME": "RPN", "MIN_SIZE": 0})
+    # FPN extension (coin_amd/modeling/fpn.py, swin.py; no counterpart in the reference's config tree)
+    C.MODEL.FPN = CN({"OUT_CHANNELS": 256})
+    C.MODEL.SWIN = CN({"EMBED_DIM": 96, "DEPTHS": [2, 2, 6, 2], "NUM_HEADS": [3, 6, 12, 24], "WINDOW_SIZE": 7})
     C.MODEL.ANCHOR_GENERATOR = CN()
     C.MODEL.ANCHOR_GENERATOR.NAME = "DefaultAnchorGenerator"
     C.MODEL.ANCHOR_GENERATOR.SIZES = [[32, 64, 128, 256, 512]]
@@ -237,6 +240,7 @@ def _d2_defaults() -> CfgNode:
     C.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_WEIGHT = 1.0
     C.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS = (10.0, 10.0, 5.0, 5.0)
     C.MODEL.ROI_BOX_HEAD.SMOOTH_L1_BETA = 0.0
+    C.MODEL.ROI_BOX_HEAD.FC_DIM = 1024  # 2-FC head of the FPN extension
     C.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION = 14
     C.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO = 0
     C.MODEL.ROI_BOX_HEAD.POOLER_TYPE = "ROIAlignV2"

@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, COIN_BF16, COIN_F32, COIN_NCHW, COIN_NHWC, CoinHipError, check
 
 __all__ = [
-    "roi_align_fwd", "roi_align_bwd", "gemm_nt", "conv_gemm", "conv_wgrad", "conv_stats_finalize", "transpose2d", "bias_act_bwd", "cosine_logits_fwd",
+    "roi_align_fwd", "roi_align_bwd", "gemm_nt", "conv_gemm", "conv_wgrad", "window_attn_fwd", "conv_stats_finalize", "transpose2d", "bias_act_bwd", "cosine_logits_fwd",
     "cosine_logits_bwd", "bn_stats", "bn_apply_fwd", "bn_bwd", "avgpool2_fwd", "avgpool2_bwd", "nms_batched", "mil_ce", "mil_focal", "kl_div", "box_reg_l1", "l1_mean", "rpn_losses", "normalize_pad",
     "SgdTable", "EmaTable",
 ]
@@ -237,6 +237,24 @@ def conv_wgrad(gy: torch.Tensor, x: torch.Tensor, spatial: Optional[Tuple[int, i
     with _timed("coin_conv_wgrad_bf16", 2 * m * cout * ktot):
         check(_lib.lib().coin_conv_wgrad_bf16(_p(gy), _p(x), mode, h, w, cin, m, cout, ktot, _p(dw), _p(ws), _stream()), "coin_conv_wgrad_bf16")
     return dw
+
+
+def window_attn_fwd(qkv: torch.Tensor, bias64: torch.Tensor, mask64: Optional[torch.Tensor], heads: int, scale: float) -> torch.Tensor:
+    """Window attention (coin_window_attn_fwd).  qkv bf16 [B, T, 3*heads*32] (layout [3][heads][32] along the last axis); bias64 fp32
+    [heads, 64, 64] and mask64 fp32 [nW, 64, 64] padded as the header says -> bf16 [B, T, heads*32]."""
+    _dev(qkv, bias64, mask64)
+    b, t, c3 = qkv.shape
+    if qkv.dtype != torch.bfloat16 or not qkv.is_contiguous() or c3 != 3 * heads * 32:
+        raise CoinHipError("window_attn_fwd needs a contiguous bf16 [B, T, 3*heads*32] tensor")
+    _f32c(bias64, "bias64")
+    if bias64.shape != (heads, 64, 64) or (mask64 is not None and (mask64.dim() != 3 or mask64.shape[1:] != (64, 64) or b % mask64.shape[0])):
+        raise CoinHipError("window_attn_fwd: bias must be [heads, 64, 64], mask [nW, 64, 64] with B % nW == 0")
+    if mask64 is not None:
+        _f32c(mask64, "mask64")
+    out = torch.empty((b, t, heads * 32), dtype=torch.bfloat16, device=qkv.device)
+    check(_lib.lib().coin_window_attn_fwd(_p(qkv), _p(bias64), _p(mask64), _p(out), b, mask64.shape[0] if mask64 is not None else 1, heads, t, 32,
+                                          float(scale), _stream()), "coin_window_attn_fwd")
+    return out
 
 
 def conv_stats_finalize(part: torch.Tensor, m: int, n: int, rows: int, eps: float, momentum: float,

@@ -162,8 +162,8 @@ class ModifiedResNet(nn.Module):
         self.layer3 = self._make_layer(width * 4, layers[2], stride=2)
         self.layer4 = self._make_layer(width * 8, layers[3], stride=2)  # used by the RoI head (C4)
         self._out_features = list(out_features)
-        self._out_feature_channels = {"stem": width, "res2": width * 4, "res3": width * 8, "res4": width * 16}
-        self._out_feature_strides = {"stem": 4, "res2": 4, "res3": 8, "res4": 16}
+        self._out_feature_channels = {"stem": width, "res2": width * 4, "res3": width * 8, "res4": width * 16, "res5": width * 32}
+        self._out_feature_strides = {"stem": 4, "res2": 4, "res3": 8, "res4": 16, "res5": 32}
         self.freeze_at = freeze_at
         self.freeze(freeze_at)
 
@@ -209,6 +209,21 @@ class ModifiedResNet(nn.Module):
             else:
                 x = stage(x)
         return {"res4": x}
+
+    def forward_pyramid(self, x) -> Dict[str, torch.Tensor]:
+        """res2 .. res5 (strides 4, 8, 16, 32): the bottom-up pathway of the FPN extension (coin_amd/modeling/fpn.py); layer4 runs on
+        the whole map here instead of on RoI tiles."""
+        frozen_prefix = min(self.freeze_at, 5)
+        out = {}
+        stages = [("stem", self._stem), ("res2", self.layer1), ("res3", self.layer2), ("res4", self.layer3), ("res5", self.layer4)]
+        for i, (name, stage) in enumerate(stages, start=1):
+            if i <= frozen_prefix and not x.requires_grad:
+                with torch.no_grad():
+                    x = stage(x)
+            else:
+                x = stage(x)
+            out[name] = x
+        return out
 
     @torch.no_grad()
     def frozen_forward(self, x) -> torch.Tensor:

@@ -180,12 +180,19 @@ int coin_conv_gemm_stats_finalize(const float* partials, int M, int N, int64_t r
 
 /* Weight gradient of the same convolutions: dW[Cout][Ktot] (fp32, OVERWRITTEN) = gy[M,Cout]^T . Acol[M,Ktot] with Acol as in
  * coin_conv_gemm_bf16 (mode 0: Ktot = Cin; mode 1: Ktot = 9*Cin, (ky, kx, ci) = the channels-last weight layout).  gy and x are the
- * NHWC tensors of the forward pass (bf16, row strides Cout / Cin); Cout % 256 == 0 and Cin % 256 == 0.  The contraction over the M
- * pixels is cut into slices whose fp32 partial results go to `workspace` (coin_conv_wgrad_workspace_bytes) and are summed in slice
- * order (no atomics: bit-reproducible). */
+ * NHWC tensors of the forward pass (bf16, row strides Cout / Cin); Cout % 256 == 0 and Cin % 256 == 0.  Also the weight gradient of a
+ * linear layer (mode 0: dW[N,K] = dZ[M,N]^T . X[M,K]).  The contraction over the M pixels is cut into per-XCD segments whose fp32
+ * partial tiles go to `workspace` (coin_conv_wgrad_workspace_bytes) and are summed in a fixed order (no atomics: bit-reproducible). */
 size_t coin_conv_wgrad_workspace_bytes(int M, int Cout, int Ktot);
 int coin_conv_wgrad_bf16(const void* gy, const void* x, int mode, int H, int W, int Cin, int M, int Cout, int Ktot,
                          float* dW, void* workspace, void* stream);
+
+/* Window attention forward of the Swin-T student (FPN extension, coin_amd/modeling/swin.py; no counterpart in the reference):
+ *   out[b][i][h*32 + d] = sum_j softmax_j(scale * q[b][i][h].k[b][j][h] + bias[h][i][j] + mask[b % windows_per_image][i][j]) * v[b][j][h][d]
+ * qkv bf16 [num_windows][tokens][3][heads][32]; bias float32 [heads][64][64] with columns >= tokens <= -1e30 (rows / columns padded to
+ * 64); mask float32 [windows_per_image][64][64] or NULL; out bf16 [num_windows][tokens][heads*32].  tokens <= 64, head_dim == 32. */
+int coin_window_attn_fwd(const void* qkv, const float* bias, const float* mask, void* out, int num_windows, int windows_per_image,
+                         int heads, int tokens, int head_dim, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused losses: each computes the scalar loss AND the gradient w.r.t. its differentiable

@@ -22,7 +22,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--images", type=int, default=2)
     ap.add_argument("--step-two", action="store_true")
-    ap.add_argument("--config", default="foggy", choices=["foggy", "bdd100k_rn101"])
+    ap.add_argument("--config", default="foggy", choices=["foggy", "bdd100k_rn101", "swint_fpn", "rn101_fpn"],
+                    help="swint_fpn / rn101_fpn: the FPN extension (configs/coin/FPN, no counterpart in the reference)")
     ap.add_argument("--sync-free-step", action="store_true", help="(default since round 2) cfg.AMD.SYNC_FREE_STEP: fixed-shape samplers + packed losses")
     ap.add_argument("--reference-samplers", action="store_true", help="cfg.AMD.SYNC_FREE_STEP off: the reference-shaped nonzero / randperm samplers")
     ap.add_argument("--no-teacher-stream", action="store_true", help="cfg.AMD.TEACHER_STREAM off: teacher pass on the main stream (A/B measurement)")
@@ -35,7 +36,9 @@ def main():
 
     torch.backends.cudnn.benchmark = True
     cfg = get_cfg()
-    cfg.merge_from_file(os.path.join(ROOT, "configs", "coin", "GDINO", "foggy_synthetic.yaml" if args.config == "foggy" else "bdd100k_rn101_synthetic.yaml"))
+    files = {"foggy": ("GDINO", "foggy_synthetic.yaml"), "bdd100k_rn101": ("GDINO", "bdd100k_rn101_synthetic.yaml"),
+             "swint_fpn": ("FPN", "targetdet_swint_fpn_synthetic.yaml"), "rn101_fpn": ("FPN", "targetdet_rn101_fpn_synthetic.yaml")}
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "coin", *files[args.config]))
     cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", args.images, "AMD.SYNTHETIC.NUM_IMAGES", args.images, "AMD.TEXT_TEMPLATES", 4,
                          "MODEL.DEVICE", "cuda:0", "CLOUD.BURN_UP_STEP", 0 if args.step_two else 10 ** 9, "CLOUD.PROTOTYPE_UPDATE_START", 0,
                          "AMD.SYNC_FREE_STEP", not args.reference_samplers, "AMD.TEACHER_STREAM", not args.no_teacher_stream])
