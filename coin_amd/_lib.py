@@ -39,7 +39,7 @@ class EmaTensor(ctypes.Structure):
     _fields_ = [("teacher", c_void_p), ("student", c_void_p), ("numel", c_int64)]
 
 
-_P, _I, _F, _L = c_void_p, c_int, c_float, c_int64
+_P, _I, _F, _L, _Z = c_void_p, c_int, c_float, c_int64, ctypes.c_size_t
 # name -> argtypes ; every entry point returns int.  Mirrors include/coin_hip.h one to one
 # (tests/test_abi.py parses the header and checks this table against it).
 SIGNATURES = {
@@ -47,6 +47,7 @@ SIGNATURES = {
     "coin_roi_align_bwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _F, _I, _I, _P, _I, _P],
     "coin_gemm_nt": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _F, _I, _I, _P],
     "coin_conv_gemm_bf16": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P],
+    "coin_conv_gemm_bf16_ws": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P, _Z, _P],
     "coin_conv_gemm_stats_finalize": [_P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P],
     "coin_conv_wgrad_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "coin_window_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
@@ -120,6 +121,8 @@ def lib() -> ctypes.CDLL:
     l.coin_conv_gemm_stats_bytes.restype = ctypes.c_size_t
     l.coin_conv_wgrad_workspace_bytes.argtypes = [c_int, c_int, c_int]
     l.coin_conv_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    l.coin_conv_gemm_workspace_bytes.argtypes = [c_int, c_int, c_int]
+    l.coin_conv_gemm_workspace_bytes.restype = ctypes.c_size_t
     l.coin_abi_version.restype = c_int
     l.coin_build_arch.restype = c_char_p
     _lib = l

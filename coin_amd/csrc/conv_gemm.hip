@@ -669,8 +669,16 @@ extern "C" size_t coin_conv_gemm_stats_bytes(int M, int N) {
   return (size_t)((M + GM - 1) / GM) * 3 * (size_t)N * sizeof(float);
 }
 
+extern "C" size_t coin_conv_gemm_workspace_bytes(int M, int N, int K) { return coin_p8_nt_workspace_bytes(M, N, K); }
+
 extern "C" int coin_conv_gemm_bf16(const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb, void* C, int ldc,
                                    const void* R, int ldr, int M, int N, int K, float* stats, int64_t stats_rows, void* stream) {
+  return coin_conv_gemm_bf16_ws(A, lda, mode, H, W, Cin, B, ldb, C, ldc, R, ldr, M, N, K, stats, stats_rows, nullptr, 0, stream);
+}
+
+extern "C" int coin_conv_gemm_bf16_ws(const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb, void* C, int ldc,
+                                      const void* R, int ldr, int M, int N, int K, float* stats, int64_t stats_rows, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
   if (!A || !B || !C) return COIN_EINVAL;
   if (M < 0 || N < 0 || K <= 0 || ldb < K || ldc < N || (mode != 0 && mode != 1) || (R && ldr < N)) return COIN_EINVAL;
   if (M == 0 || N == 0) return COIN_OK;
@@ -695,8 +703,9 @@ extern "C" int coin_conv_gemm_bf16(const void* A, int lda, int mode, int H, int 
     return !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 'r' ? 2 : 0));
   }();
   const int impl = coin_conv_gemm_force_impl ? coin_conv_gemm_force_impl - 1 : env_impl;
-  if (impl == 0 && coin_p8_nt_ok(M, N, K, mode, Cin))
-    return coin_p8_nt_launch(A, lda, mode, H, W, Cin, B, ldb, C, ldc, R, ldr, M, N, K, stats, (long long)stats_rows, 0, st);
+  if (impl == 0 && coin_p8_nt_ok(M, N, K, mode, Cin, lda, ldb))
+    return coin_p8_nt_launch(A, lda, mode, H, W, Cin, B, ldb, C, ldc, R, ldr, M, N, K, stats, (long long)stats_rows,
+                             ((uintptr_t)workspace & 15) ? nullptr : workspace, workspace_bytes, st);
   const int force_rect = impl == 2;
   if (N % QN == 0 && !force_rect) {
     const int tm = (M + QM - 1) / QM, tn = N / QN;

@@ -41,6 +41,14 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Range-checked buffer LDS-DMA of 16 bytes per lane: address = base + voff (per lane) + soff (wave-uniform); an offset at or beyond
+// `bytes` writes zeros.  (A plain function on purpose: called with these builtins directly, the function TEMPLATES below are rejected
+// by the host pass of hipcc 7.2 with a bare "substitution failure".)
+__device__ __forceinline__ void blds16(const void* base, unsigned bytes, unsigned voff, unsigned soff, void* lds_wave_base) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
 #define P8_SCHED() __builtin_amdgcn_sched_barrier(0)
 // raw barrier (no counter is waited for: LDS-DMA stays in flight across it) + a compiler-level memory fence
 #define P8_BAR()                      \
@@ -75,18 +83,46 @@ struct P8Args {
   int M, N, K, H, W, Cin;
   float* stats; long long stats_rows;
   int tiles_m, tiles_n;
+  // Split-K tail: tiles [0, whole_tiles) are computed whole (whole_tiles is a multiple of the grid when split > 1); each of the
+  // remaining `rem` tiles is cut along K into `split` pieces so that the last, partly filled round occupies every CU for 1/split of a
+  // tile's time (3136 tiles on 256 CUs are 12.25 rounds: 13 are paid without this).  A piece stores its fp32 accumulators to
+  // slab[(tile - whole_tiles) * split + piece] and conv_gemm_p8_tail_kernel sums a tile's pieces in piece order and runs the epilogue.
+  float* slab; int whole_tiles, rem, split;
+  unsigned a_bytes, b_bytes;  // operand sizes for the range-checked DMA
   int dbg;  // lab only: bit 0 = every A / B DMA reads the zero page
 };
+
+// Work items of workgroup b (grid G): its whole tiles b, b + G, ... (n_whole of them) first, then at most one split-K piece.
+// Everything here is wave-uniform scalar arithmetic.
+struct P8Items {
+  int b, G, nk, n_whole, n_items, piece, whole_tiles, rem, split;
+  __device__ __forceinline__ int tile(int idx) const { return idx < n_whole ? p8_remap(b + idx * G, G, whole_tiles) : whole_tiles + b % rem; }
+  __device__ __forceinline__ int kb(int idx) const { return idx < n_whole ? 0 : piece * nk / split; }
+  __device__ __forceinline__ int ke(int idx) const { return idx < n_whole ? nk : (piece + 1) * nk / split; }
+  __device__ __forceinline__ bool whole(int idx) const { return idx < n_whole; }
+};
+
+__device__ __forceinline__ P8Items p8_items(const P8Args& p, int b, int G, int nk) {
+  P8Items w;
+  w.b = b; w.G = G; w.nk = nk; w.whole_tiles = p.whole_tiles; w.rem = p.rem > 0 ? p.rem : 1; w.split = p.split > 0 ? p.split : 1;
+  w.n_whole = b < p.whole_tiles ? (p.whole_tiles - 1 - b) / G + 1 : 0;
+  const bool has_piece = p.split > 1 && b < p.rem * p.split;
+  w.piece = has_piece ? b / w.rem : 0;
+  w.n_items = w.n_whole + (has_piece ? 1 : 0);
+  return w;
+}
 
 // ---------------------------------------------------------------------------------------------------------------- NT kernel
 // LDS image of a half-tile: 128 rows x 128 B; one DMA instruction writes 8 rows; 16-byte chunk c of row r sits at chunk c ^ (r & 7)
 // (applied on the SOURCE address; the fragment reads apply the same XOR): conflict-free ds_read_b128 for the 16x16x32 operands.
+constexpr unsigned P8_OOB = 0x80000000u;  // a buffer offset beyond every operand (host: sizes < 2^31): the range-checked DMA writes zeros
+
 template <bool GATHER3>
 struct NtCursor {
-  const bf16_t* a[4];  // [A-lo e0, A-lo e1, A-hi e0, A-hi e1]: this lane's source rows (+ swizzled chunk); 3x3: the centre pixel
-  const bf16_t* b[4];
+  unsigned a[4];  // [A-lo e0, A-lo e1, A-hi e0, A-hi e1]: byte offset of this lane's source row (+ swizzled chunk); 3x3: the centre pixel
+  unsigned b[4];
   unsigned taps[4];
-  int kt, it, buf;
+  int kt, ke, idx, buf;
 };
 
 template <bool GATHER3>
@@ -111,35 +147,36 @@ __device__ __forceinline__ void nt_set_tile(NtCursor<GATHER3>& c, const P8Args& 
           m |= (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W ? 1u : 0u) << t;
         }
         c.taps[h * 2 + e] = m;
-        c.a[h * 2 + e] = p.A + (size_t)row * p.Cin + sc;
+        c.a[h * 2 + e] = (unsigned)(((size_t)row * p.Cin + sc) * 2);
       } else {
         c.taps[h * 2 + e] = 0;
-        c.a[h * 2 + e] = p.A + (size_t)row * p.lda + sc;
+        c.a[h * 2 + e] = (unsigned)(((size_t)row * p.lda + sc) * 2);
       }
-      c.b[h * 2 + e] = p.B + (size_t)(tn * PN + rloc) * p.ldb + sc;  // N % 256 == 0: always inside
+      c.b[h * 2 + e] = (unsigned)(((size_t)(tn * PN + rloc) * p.ldb + sc) * 2);  // N % 256 == 0: always inside
     }
 }
 
-// which: 0 = B-lo, 1 = A-lo, 2 = B-hi, 3 = A-hi of the cursor's K-tile
+// which: 0 = B-lo, 1 = A-lo, 2 = B-hi, 3 = A-hi of the cursor's K-tile.  Range-checked buffer LDS-DMA: 32-bit per-lane offsets, the
+// K offset of the 1x1 case and of B rides in the scalar offset; 3x3 taps outside the image get an out-of-range offset -> zeros.
 template <bool GATHER3, int WHICH>
-__device__ __forceinline__ void nt_stage(const NtCursor<GATHER3>& c, const P8Args& p, char* lds, int wave, int lane) {
+__device__ __forceinline__ void nt_stage(const NtCursor<GATHER3>& c, const P8Args& p, char* lds, int wave) {
   constexpr bool IS_A = (WHICH & 1) != 0;
   constexpr int H = WHICH >> 1;
   char* dst = lds + c.buf * P_KT + (IS_A ? 0 : 2 * P_HALF) + H * P_HALF + wave * 2048;
   if (IS_A) {
     if (GATHER3) {
       const int chunk = c.kt / 9, tap = c.kt - chunk * 9;
-      const long long shift = ((long long)(tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.Cin + chunk * PK;
-      const bf16_t* zp = reinterpret_cast<const bf16_t*>(p8_zero_page) + (((lane & 7) ^ (lane >> 3)) * 8);
+      const int shift = (((tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.Cin + chunk * PK) * 2;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const bf16_t* src = ((c.taps[H * 2 + e] >> tap) & 1u) ? c.a[H * 2 + e] + shift : zp;
-        glds16(src, dst + e * 1024);
+        unsigned off = ((c.taps[H * 2 + e] >> tap) & 1u) ? c.a[H * 2 + e] + (unsigned)shift : P8_OOB;
+        if (p.dbg & 1) off = P8_OOB;
+        blds16(p.A, p.a_bytes, off, 0, dst + e * 1024);
       }
     } else {
-      const bf16_t* zp = reinterpret_cast<const bf16_t*>(p8_zero_page) + (((lane & 7) ^ (lane >> 3)) * 8);
 #pragma unroll
-      for (int e = 0; e < 2; ++e) glds16((p.dbg & 1) ? zp : c.a[H * 2 + e] + c.kt * PK, dst + e * 1024);
+      for (int e = 0; e < 2; ++e)
+        blds16(p.A, p.a_bytes, (p.dbg & 1) ? P8_OOB : c.a[H * 2 + e], c.kt * (PK * 2), dst + e * 1024);
     }
   } else {
     int koff = c.kt * PK;
@@ -147,9 +184,107 @@ __device__ __forceinline__ void nt_stage(const NtCursor<GATHER3>& c, const P8Arg
       const int chunk = c.kt / 9, tap = c.kt - chunk * 9;
       koff = tap * p.Cin + chunk * PK;
     }
-    const bf16_t* zpb = reinterpret_cast<const bf16_t*>(p8_zero_page) + (((lane & 7) ^ (lane >> 3)) * 8);
 #pragma unroll
-    for (int e = 0; e < 2; ++e) glds16((p.dbg & 1) ? zpb : c.b[H * 2 + e] + koff, dst + e * 1024);
+    for (int e = 0; e < 2; ++e)
+      blds16(p.B, p.b_bytes, (p.dbg & 1) ? P8_OOB : c.b[H * 2 + e], koff * 2, dst + e * 1024);
+  }
+}
+
+// Epilogue of one output tile: four 128 x 128 quadrants through the 32 KiB image -> whole 256-byte rows (+ residual, + statistics of
+// the stored values).  Workgroup-wide (all 512 threads, aligned); `img` = 32 KiB of LDS.
+template <bool STATS>
+__device__ __forceinline__ void p8_epilogue(const P8Args& p, f32x4 (&acc)[2][2][4][2], int tile, char* img, int lane, int wave) {
+  const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, fq = lane >> 4;
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int m0 = tm * PM, n0 = tn * PN;
+  const int chunk = threadIdx.x & 15, rsub = threadIdx.x >> 4;
+#pragma unroll
+  for (int bh = 0; bh < 2; ++bh) {
+    float s1[8], s2[8], piv[8];
+#pragma unroll
+    for (int ah = 0; ah < 2; ++ah) {
+      // (the previous pass's readers are past their barrier below)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wr * 64 + i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int ch = wc * 4 + j * 2 + (fq >> 1);
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[ah][bh][i][j][r];
+          *reinterpret_cast<bf16x4*>(img + row * 256 + ((ch ^ (row & 15)) << 4) + (fq & 1) * 8) = o;
+        }
+      }
+      P8_LDS_SYNC();
+      const int gcol = n0 + bh * 128 + chunk * 8;
+      if (STATS && ah == 0) {
+        const bf16x8 pv = *reinterpret_cast<const bf16x8*>(img + (chunk << 4));  // row 0 of the tile: every thread's pivot
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          piv[i] = (float)pv[i];
+          s1[i] = s2[i] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = q * 32 + rsub;
+        const int grow = m0 + ah * 128 + row;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(img + row * 256 + ((chunk ^ (row & 15)) << 4));
+        if (p.R != nullptr && grow < p.M) {  // C = bf16(bf16(A.B^T) + R): what two separate launches would store
+          const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.R + (size_t)grow * p.ldr + gcol);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = (bf16_t)((float)v[i] + (float)r[i]);
+        }
+        if (grow < p.M) *reinterpret_cast<bf16x8*>(p.C + (size_t)grow * p.ldc + gcol) = v;
+        if (STATS && (long long)grow < p.stats_rows) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float d = (float)v[i] - piv[i];
+            s1[i] += d;
+            s2[i] += d * d;
+          }
+        }
+      }
+      P8_LDS_SYNC();
+    }
+    if (STATS) {
+      // threads with equal `chunk`: lanes l, l ^ 16, l ^ 32 of a wave, then the 8 waves through the (free) image, fixed order
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        s1[i] += __shfl_xor(s1[i], 16, 64);
+        s2[i] += __shfl_xor(s2[i], 16, 64);
+        s1[i] += __shfl_xor(s1[i], 32, 64);
+        s2[i] += __shfl_xor(s2[i], 32, 64);
+      }
+      float* red = reinterpret_cast<float*>(img);  // [8 waves][16 chunks][16]
+      if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          red[(wave * 16 + lane) * 16 + i] = s1[i];
+          red[(wave * 16 + lane) * 16 + 8 + i] = s2[i];
+        }
+        if (wave == 0) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) red[8 * 16 * 16 + lane * 8 + i] = piv[i];
+        }
+      }
+      P8_LDS_SYNC();
+      if (threadIdx.x < 128) {
+        const int c = threadIdx.x, ch = c >> 3, ci = c & 7;
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          a1 += red[(w * 16 + ch) * 16 + ci];
+          a2 += red[(w * 16 + ch) * 16 + 8 + ci];
+        }
+        float* __restrict__ part = p.stats + (size_t)tm * 3 * p.N + n0 + bh * 128 + c;
+        part[0] = red[8 * 16 * 16 + c];
+        part[p.N] = a1;
+        part[2 * (size_t)p.N] = a2;
+      }
+      P8_LDS_SYNC();
+    }
   }
 }
 
@@ -159,35 +294,39 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(const P8Args p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  const int G = gridDim.x, ntiles = p.tiles_m * p.tiles_n, nk = p.K / PK;
-  int it_c = blockIdx.x;
-  if (it_c >= ntiles) return;
-  const int my_tiles = (ntiles - 1 - it_c) / G + 1;
-  const int total_kt = my_tiles * nk;
+  const int G = gridDim.x, nk = p.K / PK;
+  const P8Items items = p8_items(p, blockIdx.x, G, nk);
+  if (items.n_items == 0) return;
+  int total_kt = items.n_whole * nk;
+  if (items.n_items > items.n_whole) total_kt += items.ke(items.n_whole) - items.kb(items.n_whole);   // (>= 2: every item holds at least two K-tiles)
+  int item_idx = 0;
 
   NtCursor<GATHER3> cur;
-  cur.kt = 0;
-  cur.it = it_c;
+  cur.idx = 0;
+  cur.kt = items.kb(0);
+  cur.ke = items.ke(0);
   cur.buf = 0;
-  nt_set_tile<GATHER3>(cur, p, p8_remap(cur.it, G, ntiles), wave, lane);
+  nt_set_tile<GATHER3>(cur, p, items.tile(0), wave, lane);
   auto advance = [&]() {
     cur.buf ^= 1;
-    if (++cur.kt == nk) {
-      cur.kt = 0;
-      cur.it += G;
-      if (cur.it < ntiles) nt_set_tile<GATHER3>(cur, p, p8_remap(cur.it, G, ntiles), wave, lane);
+    if (++cur.kt == cur.ke) {
+      if (++cur.idx < items.n_items) {
+        cur.kt = items.kb(cur.idx);
+        cur.ke = items.ke(cur.idx);
+        nt_set_tile<GATHER3>(cur, p, items.tile(cur.idx), wave, lane);
+      }
     }
   };
 
   // ---- prologue: K-tile 0 (four half-tiles) and three half-tiles of K-tile 1
-  nt_stage<GATHER3, 0>(cur, p, lds, wave, lane);
-  nt_stage<GATHER3, 1>(cur, p, lds, wave, lane);
-  nt_stage<GATHER3, 2>(cur, p, lds, wave, lane);
-  nt_stage<GATHER3, 3>(cur, p, lds, wave, lane);
+  nt_stage<GATHER3, 0>(cur, p, lds, wave);
+  nt_stage<GATHER3, 1>(cur, p, lds, wave);
+  nt_stage<GATHER3, 2>(cur, p, lds, wave);
+  nt_stage<GATHER3, 3>(cur, p, lds, wave);
   advance();
-  nt_stage<GATHER3, 0>(cur, p, lds, wave, lane);
-  nt_stage<GATHER3, 1>(cur, p, lds, wave, lane);
-  nt_stage<GATHER3, 2>(cur, p, lds, wave, lane);
+  nt_stage<GATHER3, 0>(cur, p, lds, wave);
+  nt_stage<GATHER3, 1>(cur, p, lds, wave);
+  nt_stage<GATHER3, 2>(cur, p, lds, wave);
   asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // B-lo(0), A-lo(0) have landed; B-hi(0), A-hi(0) are waited for in phases 1, 2
   P8_BAR();
 
@@ -214,7 +353,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(const P8Args p) {
           for (int j = 0; j < 2; ++j) acc[x][y][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     if (wr == 1) P8_BAR();  // G1 runs one barrier behind G0
-    for (int kt = 0; kt < nk; ++kt, ++g) {
+    for (int kt = items.kb(item_idx), kt_end = items.ke(item_idx); kt < kt_end; ++kt, ++g) {
       const char* kb = lds + (g & 1) * P_KT;
       bf16x8 af[4][2], b0[2][2], b1[2][2];
       // ------------------------------------------------ phase 1
@@ -229,7 +368,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(const P8Args p) {
         for (int ks = 0; ks < 2; ++ks) af[i][ks] = *reinterpret_cast<const bf16x8*>(kb + a_off[ks] + i * 2048);
       P8_SCHED();
       if (g + 1 < total_kt) {
-        nt_stage<GATHER3, 3>(cur, p, lds, wave, lane);  // A-hi(g+1)
+        nt_stage<GATHER3, 3>(cur, p, lds, wave);  // A-hi(g+1)
         advance();                                       // cursor -> K-tile g+2
       }
       asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the B-lo reads are back: B-lo may be re-staged in phase 2
@@ -259,7 +398,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(const P8Args p) {
       P8_SCHED();
       const bool more = g + 2 < total_kt;
       if (more) {
-        nt_stage<GATHER3, 0>(cur, p, lds, wave, lane);  // B-lo(g+2)
+        nt_stage<GATHER3, 0>(cur, p, lds, wave);  // B-lo(g+2)
         asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // A-hi(g) has landed (read in phase 3)
       } else if (g + 1 < total_kt) {
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -286,7 +425,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(const P8Args p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) af[i][ks] = *reinterpret_cast<const bf16x8*>(kb + a_off[ks] + P_HALF + i * 2048);
       P8_SCHED();
-      if (more) nt_stage<GATHER3, 1>(cur, p, lds, wave, lane);  // A-lo(g+2)
+      if (more) nt_stage<GATHER3, 1>(cur, p, lds, wave);  // A-lo(g+2)
       P8_SCHED();
       P8_BAR();
       P8_SCHED();
@@ -303,7 +442,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(const P8Args p) {
       P8_SCHED();
       // ------------------------------------------------ phase 4
       if (more) {
-        nt_stage<GATHER3, 2>(cur, p, lds, wave, lane);  // B-hi(g+2)
+        nt_stage<GATHER3, 2>(cur, p, lds, wave);  // B-hi(g+2)
         asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // B-lo(g+1), A-lo(g+1) have landed (this wave's part; the barrier publishes it)
       } else if (g + 1 < total_kt) {
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -327,105 +466,58 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(const P8Args p) {
     }
     if (wr == 0) P8_BAR();  // both groups aligned again
 
-    // ---- epilogue: four 128 x 128 quadrants through the 32 KiB image -> whole 256-byte rows (+ residual, + statistics)
-    const int tile = p8_remap(it_c, G, ntiles);
-    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-    const int m0 = tm * PM, n0 = tn * PN;
-    char* img = lds + P_IMG;
-    const int chunk = threadIdx.x & 15, rsub = threadIdx.x >> 4;
+    if (items.whole(item_idx)) {
+      p8_epilogue<STATS>(p, acc, items.tile(item_idx), lds + P_IMG, lane, wave);
+    } else {
+      // split-K piece: fp32 accumulators in thread-private order (float4 index q * 512 + thread): coalesced 16-byte stores
+      unsigned tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));  // keeps the 32 store addresses from being formed (and spilled) ahead of the K loop
+      f32x4* __restrict__ sl = reinterpret_cast<f32x4*>(p.slab) + ((size_t)(blockIdx.x % items.rem) * p.split + items.piece) * (32 * 512) + tid;
 #pragma unroll
-    for (int bh = 0; bh < 2; ++bh) {
-      float s1[8], s2[8], piv[8];
+      for (int x = 0; x < 2; ++x)
 #pragma unroll
-      for (int ah = 0; ah < 2; ++ah) {
-        // (the previous pass's readers are past their barrier below)
+        for (int y = 0; y < 2; ++y)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = wr * 64 + i * 16 + fr;
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int ch = wc * 4 + j * 2 + (fq >> 1);
-            bf16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[ah][bh][i][j][r];
-            *reinterpret_cast<bf16x4*>(img + row * 256 + ((ch ^ (row & 15)) << 4) + (fq & 1) * 8) = o;
-          }
-        }
-        P8_LDS_SYNC();
-        const int gcol = n0 + bh * 128 + chunk * 8;
-        if (STATS && ah == 0) {
-          const bf16x8 pv = *reinterpret_cast<const bf16x8*>(img + (chunk << 4));  // row 0 of the tile: every thread's pivot
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            piv[i] = (float)pv[i];
-            s1[i] = s2[i] = 0.f;
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int row = q * 32 + rsub;
-          const int grow = m0 + ah * 128 + row;
-          bf16x8 v = *reinterpret_cast<const bf16x8*>(img + row * 256 + ((chunk ^ (row & 15)) << 4));
-          if (p.R != nullptr && grow < p.M) {  // C = bf16(bf16(A.B^T) + R): what two separate launches would store
-            const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.R + (size_t)grow * p.ldr + gcol);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = (bf16_t)((float)v[i] + (float)r[i]);
-          }
-          if (grow < p.M) *reinterpret_cast<bf16x8*>(p.C + (size_t)grow * p.ldc + gcol) = v;
-          if (STATS && (long long)grow < p.stats_rows) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              const float d = (float)v[i] - piv[i];
-              s1[i] += d;
-              s2[i] += d * d;
-            }
-          }
-        }
-        P8_LDS_SYNC();
-      }
-      if (STATS) {
-        // threads with equal `chunk`: lanes l, l ^ 16, l ^ 32 of a wave, then the 8 waves through the (free) image, fixed order
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          s1[i] += __shfl_xor(s1[i], 16, 64);
-          s2[i] += __shfl_xor(s2[i], 16, 64);
-          s1[i] += __shfl_xor(s1[i], 32, 64);
-          s2[i] += __shfl_xor(s2[i], 32, 64);
-        }
-        float* red = reinterpret_cast<float*>(img);  // [8 waves][16 chunks][16]
-        if (lane < 16) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            red[(wave * 16 + lane) * 16 + i] = s1[i];
-            red[(wave * 16 + lane) * 16 + 8 + i] = s2[i];
-          }
-          if (wave == 0) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) red[8 * 16 * 16 + lane * 8 + i] = piv[i];
-          }
-        }
-        P8_LDS_SYNC();
-        if (threadIdx.x < 128) {
-          const int c = threadIdx.x, ch = c >> 3, ci = c & 7;
-          float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-          for (int w = 0; w < 8; ++w) {
-            a1 += red[(w * 16 + ch) * 16 + ci];
-            a2 += red[(w * 16 + ch) * 16 + 8 + ci];
-          }
-          float* __restrict__ part = p.stats + (size_t)tm * 3 * p.N + n0 + bh * 128 + c;
-          part[0] = red[8 * 16 * 16 + c];
-          part[p.N] = a1;
-          part[2 * (size_t)p.N] = a2;
-        }
-        P8_LDS_SYNC();
-      }
+            for (int j = 0; j < 2; ++j) sl[(((x * 2 + y) * 4 + i) * 2 + j) * 512] = acc[x][y][i][j];
     }
-    it_c += G;
-    if (it_c >= ntiles) break;
+    if (++item_idx >= items.n_items) break;
   }
 }
 
+// Split-K tail, pass 1: slab[tile][0] += slab[tile][1] + ... (piece order: bit-reproducible), every CU busy: grid = rem * 32 workgroups
+// of 256 threads, two float4 per thread and piece.
+__global__ __launch_bounds__(256) void conv_gemm_p8_slab_sum_kernel(float* __restrict__ slab, int split) {
+  f32x4* __restrict__ sl = reinterpret_cast<f32x4*>(slab) + (size_t)(blockIdx.x >> 5) * split * (32 * 512) + (blockIdx.x & 31) * 512 + threadIdx.x;
+  f32x4 a = sl[0], b = sl[256];
+  for (int s = 1; s < split; ++s) {
+    a += sl[(size_t)s * (32 * 512)];
+    b += sl[(size_t)s * (32 * 512) + 256];
+  }
+  sl[0] = a;
+  sl[256] = b;
+}
+
+// Split-K tail, pass 2: the summed accumulators of one tail tile (thread-private order, as the pieces stored them) -> the epilogue.
+// grid = rem tiles, 512 threads.
+template <bool STATS>
+__global__ __launch_bounds__(512) void conv_gemm_p8_tail_kernel(const P8Args p) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const f32x4* __restrict__ sl = reinterpret_cast<const f32x4*>(p.slab) + (size_t)blockIdx.x * p.split * (32 * 512) + threadIdx.x;
+  f32x4 acc[2][2][4][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[x][y][i][j] = sl[(((x * 2 + y) * 4 + i) * 2 + j) * 512];
+  p8_epilogue<STATS>(p, acc, p.whole_tiles + blockIdx.x, lds, lane, wave);
+}
 
 // ---------------------------------------------------------------------------------------------------------------- TN kernel
 // Weight gradient: dW[co][k] = sum over pixels m of gy[m][co] * xcol[m][k], k = tap * Cin + ci.  Output tile = 256 co x 256 k (one
@@ -804,15 +896,38 @@ static int p8_grid(int ntiles) {
 }
 
 int coin_p8_debug = 0;  // lab hook, see TnArgs::dbg
+int coin_p8_splitk = -1;  // lab hook: -1 = default policy, 0 = never split the tail round, 1 = split whenever it is possible
 
-bool coin_p8_nt_ok(int M, int N, int K, int mode, int Cin) {
+bool coin_p8_nt_ok(int M, int N, int K, int mode, int Cin, int lda, int ldb) {
   if (M <= 0 || N % PN || K % PK || K < 2 * PK) return false;
+  if ((size_t)M * (mode == 1 ? Cin : lda) * 2 >= 0x7f000000ull || (size_t)N * ldb * 2 >= 0x7f000000ull) return false;  // 32-bit buffer offsets
   if (mode == 1 && (Cin % PK || K != 9 * Cin)) return false;
   return true;
 }
 
+// Split-K plan of the tail round (see P8Args): only where a tile is long enough for the combine pass (two passes over `rem * split`
+// fp32 tiles of 256 KiB) to cost less than the idle CUs it removes -- K >= 2048 -- and the tail fills at most half of the CUs.
+static void p8_nt_plan(int ntiles, int nk, int G, bool have_ws, int force, int& whole, int& rem, int& split) {
+  whole = ntiles; rem = 0; split = 1;
+  const int r = ntiles % G;
+  if (!have_ws || force == 0 || r == 0 || 2 * r > G || (nk < 32 && force != 1)) return;   // default policy: K >= 2048
+  int s = G / r;
+  if (s > 8) s = 8;
+  while (s > 1 && nk / s < 2) --s;
+  if (s < 2) return;
+  whole = ntiles - r; rem = r; split = s;
+}
+
+size_t coin_p8_nt_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N % PN || K % PK) return 0;
+  const int ntiles = ((M + PM - 1) / PM) * (N / PN), G = p8_grid(1 << 30);
+  int whole, rem, split;
+  p8_nt_plan(ntiles, K / PK, G < ntiles ? G : ntiles, true, 1, whole, rem, split);   // upper bound: as if forced on
+  return (size_t)rem * split * 65536 * sizeof(float);
+}
+
 int coin_p8_nt_launch(const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb, void* C, int ldc, const void* R, int ldr,
-                      int M, int N, int K, float* stats, long long stats_rows, int grid_override, hipStream_t st) {
+                      int M, int N, int K, float* stats, long long stats_rows, void* workspace, size_t workspace_bytes, hipStream_t st) {
   P8Args a;
   a.A = (const bf16_t*)A; a.lda = lda;
   a.B = (const bf16_t*)B; a.ldb = ldb;
@@ -822,8 +937,15 @@ int coin_p8_nt_launch(const void* A, int lda, int mode, int H, int W, int Cin, c
   a.stats = stats; a.stats_rows = stats_rows;
   a.tiles_m = (M + PM - 1) / PM; a.tiles_n = N / PN;
   a.dbg = coin_p8_debug;
+  a.a_bytes = (unsigned)((size_t)M * (mode == 1 ? Cin : lda) * 2);
+  a.b_bytes = (unsigned)((size_t)N * ldb * 2);
   const int ntiles = a.tiles_m * a.tiles_n;
-  const int grid = grid_override > 0 ? (grid_override < ntiles ? grid_override : ntiles) : p8_grid(ntiles);
+  const int grid = p8_grid(ntiles);
+  static const int env_split = [] { const char* e = getenv("COIN_CONV_GEMM_SPLITK"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();  // measurements only
+  const int force = coin_p8_splitk >= 0 ? coin_p8_splitk : env_split;
+  p8_nt_plan(ntiles, K / PK, grid, workspace != nullptr, force, a.whole_tiles, a.rem, a.split);
+  if ((size_t)a.rem * a.split * 65536 * sizeof(float) > workspace_bytes) { a.whole_tiles = ntiles; a.rem = 0; a.split = 1; }
+  a.slab = (float*)workspace;
 #define P8_LAUNCH(G3, ST)                                                                                                          \
   do {                                                                                                                             \
     static bool attr_set = false;                                                                                                  \
@@ -839,6 +961,11 @@ int coin_p8_nt_launch(const void* A, int lda, int mode, int H, int W, int Cin, c
     if (stats) P8_LAUNCH(false, true); else P8_LAUNCH(false, false);
   }
 #undef P8_LAUNCH
+  if (a.split > 1) {
+    conv_gemm_p8_slab_sum_kernel<<<a.rem * 32, 256, 0, st>>>(a.slab, a.split);
+    if (stats) conv_gemm_p8_tail_kernel<true><<<a.rem, 512, 128 * 256, st>>>(a);
+    else conv_gemm_p8_tail_kernel<false><<<a.rem, 512, 128 * 256, st>>>(a);
+  }
   return coin_launch_status();
 }
 

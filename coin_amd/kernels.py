@@ -203,11 +203,20 @@ def conv_gemm(a: torch.Tensor, w: torch.Tensor, spatial: Optional[Tuple[int, int
     part = None
     if stats_rows is not None:
         part = torch.empty(_lib.lib().coin_conv_gemm_stats_bytes(m, n) // 4, dtype=torch.float32, device=a.device)
+    wsb = _lib.lib().coin_conv_gemm_workspace_bytes(m, n, k)   # fp32 partial tiles of the split-K tail round (0: not needed for this shape)
+    ws = None
+    if wsb:
+        ws = _GEMM_WS.get(a.device)
+        if ws is None or ws.numel() < wsb:   # one buffer per device, grown to the largest request (calls on one stream are ordered)
+            ws = _GEMM_WS[a.device] = torch.empty(wsb, dtype=torch.uint8, device=a.device)
     with _timed("coin_conv_gemm_bf16", 2 * m * n * k):  # "bytes" slot carries FLOPs for the MFMA entry point
-        check(_lib.lib().coin_conv_gemm_bf16(_p(a), a.stride(0), mode, h, wd, cin, _p(w), w.stride(0), _p(out), out.stride(0),
-                                             _p(residual), residual.stride(0) if residual is not None else 0, m, n, k,
-                                             _p(part), int(stats_rows or 0), _stream()), "coin_conv_gemm_bf16")
+        check(_lib.lib().coin_conv_gemm_bf16_ws(_p(a), a.stride(0), mode, h, wd, cin, _p(w), w.stride(0), _p(out), out.stride(0),
+                                                _p(residual), residual.stride(0) if residual is not None else 0, m, n, k,
+                                                _p(part), int(stats_rows or 0), _p(ws), wsb if ws is not None else 0, _stream()), "coin_conv_gemm_bf16_ws")
     return out, part
+
+
+_GEMM_WS: dict = {}
 
 
 _WGRAD_WS: dict = {}

@@ -175,6 +175,13 @@ size_t coin_conv_gemm_stats_bytes(int M, int N);
 int coin_conv_gemm_bf16(const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb,
                         void* C, int ldc, const void* R, int ldr, int M, int N, int K, float* stats, int64_t stats_rows,
                         void* stream);
+/* The same with a caller-owned workspace (coin_conv_gemm_workspace_bytes; may be NULL / 0): when the output tiles do not fill the last
+ * round of the persistent grid, the leftover tiles are cut along K, their fp32 partial tiles go through the workspace and are summed in
+ * a fixed order (bit-reproducible).  Results equal coin_conv_gemm_bf16's up to the fp32 summation order of those tiles. */
+size_t coin_conv_gemm_workspace_bytes(int M, int N, int K);
+int coin_conv_gemm_bf16_ws(const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb,
+                           void* C, int ldc, const void* R, int ldr, int M, int N, int K, float* stats, int64_t stats_rows,
+                           void* workspace, size_t workspace_bytes, void* stream);
 int coin_conv_gemm_stats_finalize(const float* partials, int M, int N, int64_t rows, float eps, float momentum,
                                   float* mean, float* rstd, float* running_mean, float* running_var, void* stream);
 

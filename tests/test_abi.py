@@ -45,9 +45,9 @@ def test_binding_table_matches_header(lib):
             is_ptr = "*" in d or "[" in d
             assert is_ptr == (ct in (ctypes.c_void_p,) or hasattr(ct, "contents") or ct is ctypes.POINTER(ctypes.c_float)), (name, d, ct)
             if not is_ptr:
-                want = {"int": ctypes.c_int, "float": ctypes.c_float, "int64_t": ctypes.c_int64}[d.split()[-2] if len(d.split()) > 1 else d]
+                want = {"int": ctypes.c_int, "float": ctypes.c_float, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t}[d.split()[-2] if len(d.split()) > 1 else d]
                 assert ct is want, (name, d, ct)
-    unbound = set(decl) - set(_lib.SIGNATURES) - {"coin_abi_version", "coin_build_arch", "coin_nms_workspace_bytes", "coin_conv_gemm_stats_bytes", "coin_conv_wgrad_workspace_bytes"}
+    unbound = set(decl) - set(_lib.SIGNATURES) - {"coin_abi_version", "coin_build_arch", "coin_nms_workspace_bytes", "coin_conv_gemm_stats_bytes", "coin_conv_wgrad_workspace_bytes", "coin_conv_gemm_workspace_bytes"}
     assert not unbound, unbound
 
 

@@ -39,7 +39,8 @@ __global__ void fill_kernel(bf16raw* p, size_t n, uint32_t seed, float scale) {
   for (; i < n; i += stride) {
     uint32_t x = (uint32_t)(i * 2654435761u) ^ seed;
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-    const float f = ((float)(x & 0xffffff) / 8388608.0f - 1.0f) * scale;  // uniform [-scale, scale)
+    float f = ((float)(x & 0xffffff) / 8388608.0f - 1.0f) * scale;  // uniform [-scale, scale)
+    if (seed & 0x80000000u) f = f > 0.f ? f : 0.f;                   // "post-ReLU" operand: half of the elements exactly zero
     uint32_t u;
     memcpy(&u, &f, 4);
     u = (u + 0x7fff + ((u >> 16) & 1)) >> 16;
@@ -67,11 +68,23 @@ struct Shape {
 static const Shape kShapes[] = {{"l4.0.conv1", 2048, 14, 14, 1024, 512, 1}, {"l4.0.conv2", 2048, 14, 14, 512, 512, 3}, {"l4.0.conv3", 2048, 7, 7, 512, 2048, 1},
                                 {"l4.0.down", 2048, 7, 7, 1024, 2048, 1},   {"l4.1.conv1", 2048, 7, 7, 2048, 512, 1},  {"l4.1.conv2", 2048, 7, 7, 512, 512, 3}};
 
+static void* g_ws = nullptr;
+static size_t g_ws_bytes = 0;
+static int g_split = -1;   // coin_p8_splitk for the next p8 launches
+
 static int run_gemm(int impl, const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb, void* C, int ldc, const void* R, int ldr,
                     int M, int N, int K, float* stats, int64_t stats_rows) {
+  const size_t need = coin_conv_gemm_workspace_bytes(M, N, K);
+  if (need > g_ws_bytes) {
+    if (g_ws) CK(hipFree(g_ws));
+    CK(hipMalloc(&g_ws, need));
+    g_ws_bytes = need;
+  }
   coin_conv_gemm_force_impl = impl;
-  const int rc = coin_conv_gemm_bf16(A, lda, mode, H, W, Cin, B, ldb, C, ldc, R, ldr, M, N, K, stats, stats_rows, nullptr);
+  coin_p8_splitk = g_split;
+  const int rc = coin_conv_gemm_bf16_ws(A, lda, mode, H, W, Cin, B, ldb, C, ldc, R, ldr, M, N, K, stats, stats_rows, g_ws, g_ws_bytes, nullptr);
   coin_conv_gemm_force_impl = 0;
+  coin_p8_splitk = -1;
   return rc;
 }
 
@@ -106,7 +119,9 @@ static int check_case(const char* name, int M, int N, int K, int mode, int H, in
   const size_t sb = coin_conv_gemm_stats_bytes(M, N);
   if (stats_rows > 0) { CK(hipMalloc(&S0, sb)); CK(hipMalloc(&S1, sb)); CK(hipMemset(S0, 0, sb)); CK(hipMemset(S1, 0, sb)); }
   int rc0 = run_gemm(2, A, lda, mode, H, W, Cin, B, K, C0, N, R, N, M, N, K, S0, stats_rows);
+  g_split = grid_note;   // 1: split-K tail forced on wherever it is possible
   int rc1 = run_gemm(1, A, lda, mode, H, W, Cin, B, K, C1, N, R, N, M, N, K, S1, stats_rows);
+  g_split = -1;
   CK(hipDeviceSynchronize());
   if (rc0 || rc1) { printf("CHECK %s: launch rc %d %d\n", name, rc0, rc1); return 1; }
   std::vector<bf16raw> h0(cn), h1(cn);
@@ -174,7 +189,6 @@ static int check_case(const char* name, int M, int N, int K, int mode, int H, in
   hipFree(A); hipFree(B); hipFree(C0); hipFree(C1);
   if (R) hipFree(R);
   if (S0) { hipFree(S0); hipFree(S1); }
-  (void)grid_note;
   return ok ? 0 : 1;
 }
 
@@ -194,16 +208,18 @@ static void bench_shape(const Shape& sh, int iters, int rounds) {
     float* S;
     CK(hipMalloc(&A, an * 2)); CK(hipMalloc(&B, bn * 2)); CK(hipMalloc(&C, cn * 2));
     CK(hipMalloc(&S, coin_conv_gemm_stats_bytes(M, N)));
-    fill(A, an, 0x1234u + dir, 1.0f);
+    fill(A, an, (0x1234u + dir) | (getenv("LAB_RELU") && dir == 0 ? 0x80000000u : 0u), 1.0f);
     fill(B, bn, 0x9876u + dir, 0.05f);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const int impls[3] = {1, 2, 1};
-    const bool stats[3] = {false, false, true};
-    const char* names[3] = {"p8", "sq", "p8+stats"};
-    std::vector<float> best(3, 1e30f), med[3];
+    const int impls[4] = {1, 2, 1, 1};
+    const bool stats[4] = {false, false, true, false};
+    const int splits[4] = {-1, -1, -1, 0};
+    const char* names[4] = {"p8", "sq", "p8+stats", "p8nosplit"};
+    std::vector<float> best(4, 1e30f), med[4];
     for (int r = 0; r < rounds; ++r)
-      for (int v = 0; v < 3; ++v) {
+      for (int v = 0; v < 4; ++v) {
+        g_split = splits[v];
         if (dir == 1 && stats[v]) continue;
         run_gemm(impls[v], A, Cin, mode, sh.h, sh.w, Cin, B, K, C, N, nullptr, 0, M, N, K, stats[v] ? S : nullptr, M);  // warm
         float ms = 0;
@@ -228,7 +244,8 @@ static void bench_shape(const Shape& sh, int iters, int rounds) {
       }
     const double flop = 2.0 * M * (double)N * K;
     printf("{\"shape\": \"%s\", \"dir\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d", sh.name, dir == 0 ? "fwd" : "dgrad", M, N, K);
-    for (int v = 0; v < 3; ++v) {
+    g_split = -1;
+    for (int v = 0; v < 4; ++v) {
       if (med[v].empty()) continue;
       std::sort(med[v].begin(), med[v].end());
       const float m = med[v][med[v].size() / 2];
@@ -411,6 +428,12 @@ int main(int argc, char** argv) {
     // benchmark shapes, full size (bit comparison with the round-2 kernel)
     fails += check_case("l4.0.conv1 full", 401408, 512, 1024, 0, 0, 0, 0, false, 401408, 0);
     fails += check_case("l4.1.conv2 full", 100352, 512, 4608, 1, 7, 7, 512, false, 100352, 0);
+    // the split-K tail round forced on: leftover tiles cut along K, combined by conv_gemm_p8_tail_kernel
+    fails += check_case("splitK 1x1 tail+R+stats", 256 * 300 + 77, 512, 1024, 0, 0, 0, 0, true, 256 * 290, 1);
+    fails += check_case("splitK 1x1 K=2048", 49 * 2048, 512, 2048, 0, 0, 0, 0, false, 49 * 2048, 1);
+    fails += check_case("splitK 1x1 few tiles", 256 * 3, 256, 512, 0, 0, 0, 0, false, 700, 1);
+    fails += check_case("splitK 3x3 7x7", 100352, 512, 4608, 1, 7, 7, 512, true, 100352, 1);
+    fails += check_case("splitK 3x3 14x14", 196 * 700, 512, 4608, 1, 14, 14, 512, false, 196 * 700, 1);
     printf("CHECK total failures: %d\n", fails);
   }
   if (!strcmp(what, "wcheck") || !strcmp(what, "all")) {
