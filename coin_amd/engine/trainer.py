@@ -79,23 +79,41 @@ class CoinTrainer(BASE_Trainer):
         self._ema = None
 
     # ------------------------------------------------------------------ teacher EMA (ts_ensemble.py:39-69)
+    def _build_ema(self, loose):
+        """fp32 state-dict entries -> one table for `coin_ema_update` (raw pointers), except the keys in `loose`; integer buffers and the
+        loose keys are updated with torch ops on the tensors the modules hold at that moment."""
+        t_sd, s_sd = self.offline_teacher.state_dict(), self.model.state_dict()
+        missing = [k for k in t_sd if k not in s_sd]
+        if missing:
+            raise Exception("{} is not found in student model".format(missing[0]))
+        fl = [k for k, v in t_sd.items() if v.dtype == torch.float32 and k not in loose]
+        owners = {}
+        for side, model in (("t", self.offline_teacher), ("s", self.model)):
+            for prefix, mod in model.named_modules():
+                for name in mod._buffers:
+                    owners[(side, (prefix + "." if prefix else "") + name)] = (mod, name)
+        # student buffers inside the table: their storage must still be the one the table points at when the kernel runs
+        watch = [(k, *owners[("s", k)], s_sd[k].data_ptr()) for k in fl if ("s", k) in owners]
+        slow = [k for k, v in t_sd.items() if v.dtype != torch.float32 or k in loose]
+        self._ema = (K.EmaTable([t_sd[k] for k in fl], [s_sd[k] for k in fl]), [(owners[("t", k)], owners[("s", k)]) for k in slow], watch, set(loose))
+
     @torch.no_grad()
     def update_teacher(self, keep_rate: float):
         if self._ema is None:
-            t_sd, s_sd = self.offline_teacher.state_dict(), self.model.state_dict()
-            missing = [k for k in t_sd if k not in s_sd]
-            if missing:
-                raise Exception("{} is not found in student model".format(missing[0]))
-            fl = [k for k, v in t_sd.items() if v.dtype == torch.float32]
-            self._ema = (K.EmaTable([t_sd[k] for k in fl], [s_sd[k] for k in fl]),
-                         [(t_sd[k], s_sd[k]) for k, v in t_sd.items() if v.dtype != torch.float32])
-        table, others = self._ema
+            self._build_ema(set())
+        # A module may REBIND a buffer (`buf.data = new`, the reference's prototype updates, fast_rcnn.py:545-556 -- the old storage
+        # stays alive for that step's backward): the table would keep averaging the stale storage.  Such keys leave the table for good.
+        moved = [k for k, mod, name, ptr in self._ema[2] if mod._buffers[name].data_ptr() != ptr]
+        if moved:
+            self._build_ema(self._ema[3] | set(moved))
+        table, slow, _, _ = self._ema
         table.update(keep_rate)
         for m in self.offline_teacher.modules():   # the kernel writes through raw pointers: drop results cached on the old prompt vectors
             if hasattr(m, "invalidate_text_cache"):
                 m.invalidate_text_cache()
-        for t, s in others:  # integer buffers (num_batches_tracked): float arithmetic, then truncation on the copy
-            t.copy_(s * (1 - keep_rate) + t * keep_rate)
+        for (tm, tn), (sm, sn) in slow:  # integer buffers (num_batches_tracked): float arithmetic, then truncation on the copy
+            t, s_ = tm._buffers[tn], sm._buffers[sn]
+            t.copy_(s_ * (1 - keep_rate) + t * keep_rate)
 
     # ------------------------------------------------------------------ targets (trainer.py:463-485)
     @torch.no_grad()

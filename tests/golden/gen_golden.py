@@ -441,10 +441,10 @@ def _step_proposals(g, na, nb, nbg, nc, size=(96, 128)):
     return props, cs
 
 
-def build_ckg(seed=41):
+def build_ckg(seed=41, head_num=4):
     torch.manual_seed(seed)
     ckg = shim.ref("coin.modeling.merge.ckg")
-    return ckg.CKGNet(hidden_size=TEXT_DIM, all_head_size=TEXT_DIM, num_classes=K + 1, logger=None, head_num=4)
+    return ckg.CKGNet(hidden_size=TEXT_DIM, all_head_size=TEXT_DIM, num_classes=K + 1, logger=None, head_num=head_num)
 
 
 def case_box_predictor_step():
@@ -1052,6 +1052,132 @@ def case_e2e_coin_step():
     npz("e2e_coin_step", **out)
 
 
+def case_e2e_coin_two_steps():
+    """TWO consecutive target-detector iterations (coin/engine/trainer.py:149-218) scripted with the reference's own pieces, in the
+    reference's order: [EMA of the offline teacher, ts_ensemble.py:39-69] -> teacher inference on the weak views -> match_boxes ->
+    student step_two + CKG step + student step -> after_step (WEIGHT_FOR_BOX_A 1.0 -> 0.5, trainer.py:150-157).  BURN_UP_STEP = 0 and
+    OFFLINE_TEACHER_UPDATE_ITER = 1: an EMA is due at BOTH iterations, the second one reads the weights the first optimizer step
+    wrote, the second teacher pass reads the EMA'd teacher, and the second matching runs with the fused A boxes.  Pins the
+    product's `prepare_next` pipelining (teacher stream) to the reference's ordering."""
+    import random
+    tr = import_ref_trainer()
+    base = shim.ref("coin.engine.base")
+    Lref = shim.ref("coin.utils.losses")
+    sb = shim.ref("coin.solver.build")
+    ts = shim.ref("coin.modeling.meta_arch.ts_ensemble")
+    keep = 0.9
+    student, teacher, merge = build_detector(seed=161), build_detector(seed=172), build_ckg(163, head_num=8)   # 8 heads: what CKGNet.from_config builds (ckg.py:95-107)
+    with torch.no_grad():
+        teacher.roi_heads.box_predictor.cls_score.weight.normal_(std=0.3)
+        student.roi_heads.box_predictor.cls_score.weight.normal_(std=0.3)
+    teacher.roi_heads.box_predictor.test_score_thresh = 0.05
+    batches = [make_pretrain_batch(164), make_pretrain_batch(165)]
+    for it, batch in enumerate(batches):
+        for i, b in enumerate(batch):
+            b["file_name"] = f"it{it}_img{i}.png"
+            b["image_id"], b["random_flip"] = f"id{it}_{i}", "no"
+            del b["RCNN"], b["RPN"]
+    out = {k: v.clone() for k, v in sd_arrays(student, "s::").items()}
+    out.update({k: v.clone() for k, v in sd_arrays(teacher, "t::").items()})
+    out.update({k: v.clone() for k, v in sd_arrays(merge, "m::").items()})
+    ens = object.__new__(ts.EnsembleTSModel)
+    nn.Module.__init__(ens)
+    ens.offline_teacher, ens.model_student = teacher, student
+    overrides = [{"backbone.encoder.visual": 0.1, "backbone.encoder.visual.layer4": 0.1, "embedding_tmp": 1.0, "add_in_embedding": 1.0, "logit_scale": 0.0}]
+    groups = lambda m, ov: sb.get_default_optimizer_params(m, base_lr=0.01, weight_decay_norm=0.0, bias_lr_factor=1.0, weight_decay_bias=1e-4,
+                                                            overrides=ov, only_text_encoder=None)
+    opt_s = torch.optim.SGD(groups(student, overrides), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    opt_m = torch.optim.SGD(groups(merge, overrides), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    stub = type("Stub", (), {})()
+    stub.cfg = type("Cfg", (), {})()
+    stub.cfg.CLOUD = type("Cloud", (), {})()
+    stub.cfg.CLOUD.MATCHER = type("Matcher", (), {"IOU_THRESHOLDS": 0.5})()
+    stub.WEIGHT_FOR_BOX_A = 1.0                                          # trainer.py:111
+    cloud = {}
+    stub.model_CLOUD = lambda fn: copy.deepcopy(cloud[fn])
+    stub.process = lambda *a, **k: base.BASE_Trainer.process(stub, *a, **k)
+    stub.preprocess_results = lambda *a, **k: base.BASE_Trainer.preprocess_results(stub, *a, **k)
+    stub.merge_boxes = lambda *a: tr.CoinTrainer.merge_boxes(stub, *a)
+    stub.match_dual_teacher = lambda *a: tr.CoinTrainer.match_dual_teacher(stub, *a)
+    rec = _capture_sampling(student)
+    g = torch.Generator().manual_seed(166)
+    names = ["roi_heads.box_predictor.trans.0.weight", "roi_heads.box_predictor.cls_score.weight", "roi_heads.box_predictor.bbox_pred.bias",
+             "backbone.encoder.visual.layer3.0.conv1.weight", "backbone.encoder.visual.layer4.1.bn2.weight",
+             "backbone.encoder.visual.layer4.1.bn2.running_mean", "backbone.encoder.visual.layer3.0.bn1.num_batches_tracked",
+             "proposal_generator.rpn_head.conv.weight", "roi_heads.box_predictor.text_encoder.encoder.embedding_tmp",
+             "roi_heads.box_predictor.text_encoder.per_class_feat", "roi_heads.box_predictor.text_encoder.prototype_b_online",
+             "roi_heads.box_predictor.text_encoder.prototype_b_offline"]
+    for it, batch in enumerate(batches):
+        T_ = f"it{it}::"
+        # trainer.py:170-172: the EMA comes first (BURN_UP_STEP = 0, OFFLINE_TEACHER_UPDATE_ITER = 1)
+        ens.update_params(keep_rate=keep, name="offline")
+        tsd = teacher.state_dict()
+        out.update({T_ + "t_ema::" + k: tsd[k].clone() for k in names})
+        teacher.eval()
+        with torch.no_grad():
+            offline = teacher([{k: v for k, v in b.items() if k in ("image", "height", "width")} for b in batch], branch="test")
+        teacher.train()
+        for b, o in zip(batch, offline):
+            det = o["instances"]
+            n = min(6, len(det))
+            boxes = det.pred_boxes.tensor[:n] + 1.5 * torch.randn(n, 4, generator=g)
+            probs = det.probs[:n].clone()
+            for j in range(n):
+                if j % 3 == 1:  # a different label than the teacher's -> B
+                    probs[j, :K] = probs[j, :K].roll(1)
+            extra = rand_boxes(2, b["height"], b["width"], g)
+            pe = rand_probs(2, g)
+            boxes, probs = torch.cat([boxes, extra]), torch.cat([probs, pe])
+
+            def inst(boxes=boxes, probs=probs, b=b):
+                r = d2.Instances((b["height"], b["width"]))
+                r.pred_boxes = d2.Boxes(boxes.clone())
+                r.scores = probs[:, :-1].max(1).values
+                r.pred_classes = probs[:, :-1].argmax(1)
+                r.probs = probs.clone()
+                return r
+
+            cloud[b["file_name"]] = {"file_name": b["file_name"], "image_id": b["image_id"], "height": b["height"], "width": b["width"],
+                                     "RCNN": {"instances": inst()}, "RPN": {"instances": inst()}}
+        random.seed(77 + it)
+        rcnn, rpn = tr.CoinTrainer.match_boxes(stub, batch, copy.deepcopy(offline))
+        torch.manual_seed(155 + it)
+        record = student(copy.deepcopy(batch), merge, (rcnn, rpn), branch="step_two", update_prototype=True)
+        opt_s.zero_grad()
+        opt_m.zero_grad()
+        LOG.warning("it %d: detections %s  A/B/C %s", it, [len(o["instances"]) for o in offline], [[len(t[0]), len(t[1]), len(t[2])] for t in rcnn])
+        assert "loss_merge_a" in record, sorted(record)
+        record["loss_merge_grad"] = Lref.gradient_discrepancy_loss(student, 1e4 * record["loss_merge_a"], 1e4 * record["loss_merge_b"])
+        (record["loss_merge_grad"] + record["loss_merge_base"]).backward(retain_graph=True)
+        opt_m.step()
+        opt_s.zero_grad()
+        opt_m.zero_grad()
+        skip = ["loss_merge_grad", "loss_merge_a", "loss_merge_b", "loss_merge_base"]
+        sum(v for k, v in record.items() if k not in skip).backward()
+        opt_s.step()
+        stub.WEIGHT_FOR_BOX_A = 0.5                                      # after_step, trainer.py:150-157 (iter >= BURN_UP_STEP)
+        out.update({T_ + "loss::" + k: v.detach().clone() for k, v in record.items()})
+        for i, (b, o) in enumerate(zip(batch, offline)):
+            out[T_ + f"img{i}"] = b["image"]
+            out.update(instances_arrays(T_ + f"det{i}", o["instances"]))
+            out.update(instances_arrays(T_ + f"cloud{i}", cloud[b["file_name"]]["RCNN"]["instances"]))
+            for name, t in (("a", rcnn[i][0]), ("b", rcnn[i][1]), ("c", rcnn[i][2]), ("rpn_a", rpn[i][0]), ("rpn_c", rpn[i][2])):
+                out.update(instances_arrays(T_ + f"{name}{i}", t))
+        for i, (a, b_, bg) in enumerate(rec["sampled"]):
+            out.update(instances_arrays(T_ + f"s{i}.a", a))
+            out.update(instances_arrays(T_ + f"s{i}.b", b_))
+            out.update(instances_arrays(T_ + f"s{i}.bg", bg))
+        lab, mb, idx, dl = rec["anchor_labels"]
+        out.update({T_ + "anchor_labels": torch.stack(lab), T_ + "anchor_matched_boxes": torch.stack(mb), T_ + "anchor_matched_idxs": torch.stack(idx),
+                    T_ + "anchor_dist_labels": torch.stack(dl)})
+        out[T_ + "n_abc"] = np.array([[len(t[0]), len(t[1]), len(t[2])] for t in rcnn])
+        out.update({T_ + "m_after::" + k: v.clone() for k, v in merge.state_dict().items()})
+        sd = student.state_dict()
+        out.update({T_ + "s_after::" + k: sd[k].clone() for k in names})
+    out["keep_rate"] = np.array(keep)
+    npz("e2e_coin_two_steps", **out)
+
+
 # --------------------------------------------------------------------------- #
 # Evaluation: Pascal-VOC AP as the reference computes it (coin/evaluation/cloud_pascal_voc_evaluation.py)
 # --------------------------------------------------------------------------- #
@@ -1386,7 +1512,7 @@ def case_rn101():
 
 CASES = [case_mil_losses, case_bottleneck, case_resnet, case_box_predictor_pretrain, case_box_predictor_step,
          case_text_encoder, case_ckg, case_lr_and_fusion, case_optimizer_groups, case_rpn, case_roi_sampling,
-         case_e2e_pretrain, case_e2e_step_and_inference, case_ema, case_match_dual_teacher, case_e2e_coin_step, case_voc_eval, case_voc_dataset, case_clip_relabel, case_real_width, case_rn101]
+         case_e2e_pretrain, case_e2e_step_and_inference, case_ema, case_match_dual_teacher, case_e2e_coin_step, case_e2e_coin_two_steps, case_voc_eval, case_voc_dataset, case_clip_relabel, case_real_width, case_rn101]
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])

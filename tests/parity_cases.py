@@ -312,6 +312,148 @@ def cointrainer_scripted_iteration(device, tol=1e-5):
     assert tr.iter == 1 and tr.WEIGHT_FOR_BOX_A == 0.5
 
 
+def cointrainer_two_iterations_through_constructor(device, tol=1e-5, teacher_stream=True):
+    """The REAL `CoinTrainer(cfg, data_loader, cloud_results)` constructor (models, optimizers and LR schedulers from the cfg, teacher
+    stream on the GPU), two consecutive `run_step` + `prepare_next` iterations against the two iterations scripted with the
+    reference's own pieces in the reference's order (tests/golden/gen_golden.py:case_e2e_coin_two_steps; trainer.py:149-218,
+    ts_ensemble.py:39-69).  An EMA is due at both iterations, so the fixture is only reproduced when
+      * the EMA of iteration 1 reads the weights the optimizer of iteration 0 wrote (teacher parameters after each EMA),
+      * the teacher pass of iteration 1 runs on the EMA'd teacher (detection count and scores change from 52/43 to 45/40 boxes),
+      * iteration 1's matching already fuses the A boxes (WEIGHT_FOR_BOX_A 1.0 -> 0.5 in after_step),
+      * the second optimizer step does not overtake the EMA (student parameters after both steps).
+    Boundary P as everywhere: the samplers return what the reference's samplers drew, the matcher gets the stored detections after the
+    product's own teacher pass has been compared with them as a set."""
+    import os
+
+    from coin_amd.config import get_cfg
+    from coin_amd.engine import CoinTrainer
+    from coin_amd.structures import Boxes
+    from golden_util import tiny_tokens
+
+    z = load("e2e_coin_two_steps")
+    dev = torch.device(device)
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "coin", "GDINO", "foggy_synthetic.yaml")
+    cfg = get_cfg()
+    cfg.merge_from_file(root)
+    cfg.merge_from_list([
+        "MODEL.DEVICE", str(device), "AMD.COMPUTE_DTYPE", "fp32", "AMD.TEACHER_STREAM", bool(teacher_stream), "AMD.SYNC_FREE", False, "AMD.SYNC_FREE_STEP", False,
+        "AMD.CLASS_NAMES", ["car", "person", "bus"], "AMD.TEXT_TEMPLATES", 2, "DATASETS.TRAIN_UNLABEL", ("foggytrain_0.02",),
+        "AMD.ARCH.LAYERS", [1, 1, 2, 2], "AMD.ARCH.WIDTH", 8, "AMD.ARCH.TEXT_WIDTH", 32, "AMD.ARCH.TEXT_LAYERS", 2, "AMD.ARCH.TEXT_HEADS", 2,
+        "AMD.ARCH.TEXT_DIM", 32, "AMD.ARCH.CONTEXT_LENGTH", 16, "AMD.ARCH.VOCAB_SIZE", 64, "MODEL.MERGE_DIM", 32, "MODEL.BACKBONE.FREEZE_AT", 2,
+        "MODEL.ANCHOR_GENERATOR.SIZES", [[32, 64, 128]], "MODEL.RPN.BATCH_SIZE_PER_IMAGE", 64, "MODEL.RPN.POSITIVE_FRACTION", 0.5,
+        "MODEL.RPN.PRE_NMS_TOPK_TRAIN", 200, "MODEL.RPN.PRE_NMS_TOPK_TEST", 120, "MODEL.RPN.POST_NMS_TOPK_TRAIN", 60, "MODEL.RPN.POST_NMS_TOPK_TEST", 40,
+        "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 32, "MODEL.ROI_HEADS.POSITIVE_FRACTION", 0.25, "MODEL.ROI_HEADS.SCORE_THRESH_TEST", 0.05,
+        "MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG", True, "CLOUD.CLASSES_WEIGHT", [1.0, 1.0, 1.0, 0.9], "CLOUD.CLS_B_THRESH", 0.3,
+        "CLOUD.BURN_UP_STEP", 0, "CLOUD.OFFLINE_TEACHER_UPDATE_ITER", 1, "CLOUD.EMA_KEEP_RATE_OFFLINE", float(z["keep_rate"]), "CLOUD.PROTOTYPE_UPDATE_START", 0,
+        "SOLVER.BASE_LR", 0.01, "SOLVER.MOMENTUM", 0.9, "SOLVER.WEIGHT_DECAY", 1e-4, "SOLVER.WEIGHT_DECAY_NORM", 0.0, "SOLVER.WEIGHT_DECAY_BIAS", 1e-4,
+        "SOLVER.BIAS_LR_FACTOR", 1.0, "SOLVER.LR_SCHEDULER_NAME", "WarmupMultiStepLR", "SOLVER.STEPS", (1000,), "SOLVER.WARMUP_ITERS", 0,
+        "SOLVER.MAX_ITER", 2, "SOLVER.IMG_PER_BATCH_UNLABEL", 2,
+        "SOLVER.PER_MODULE_PARAM_WEIGHT", [{"backbone.encoder.visual": 0.1, "backbone.encoder.visual.layer4": 0.1, "embedding_tmp": 1.0,
+                                            "add_in_embedding": 1.0, "logit_scale": 0.0}]])
+    batches, cloud, sizes, stored = [], {}, [], []
+    for it in range(2):
+        batch, sz = [], []
+        for i in range(2):
+            img = T(z[f"it{it}::img{i}"]).to(dev)
+            s = (img.shape[1], img.shape[2])
+            sz.append(s)
+            name = f"it{it}_img{i}.png"
+            batch.append({"image": img, "height": s[0], "width": s[1], "file_name": name, "image_id": f"id{it}_{i}", "random_flip": "no"})
+            cloud[name] = {"file_name": name, "image_id": f"id{it}_{i}", "height": s[0], "width": s[1],
+                           "RCNN": {"instances": _inst(z, f"it{it}::cloud{i}", s)}, "RPN": {"instances": _inst(z, f"it{it}::cloud{i}", s)}}
+        batches.append(batch)
+        sizes.append(sz)
+        stored.append([{"instances": _inst(z, f"it{it}::det{i}", s).to(dev)} for i, s in enumerate(sz)])
+    loader = [(copy.deepcopy(b), copy.deepcopy(b)) for b in batches]   # (strong, weak): the scripted iterations feed the same views to both
+    with kernels_for(device):
+        torch.manual_seed(0)
+        tr = CoinTrainer(cfg, data_loader=loader, cloud_results=lambda fn: copy.deepcopy(cloud[fn]))
+        student, teacher, merge = tr.model, tr.offline_teacher, tr.merge
+        for m in (student, teacher):
+            m.roi_heads.box_predictor.text_encoder.encoder.tokenized_prompts.copy_(tiny_tokens())
+        load_weights(student, z, "s::")
+        load_weights(teacher, z, "t::")
+        load_weights(merge, z, "m::")
+        assert tr.WEIGHT_FOR_BOX_A == 1.0 and tr.iter == 0                      # trainer.py:111
+        names = [k[len("it0::t_ema::"):] for k in z.files if k.startswith("it0::t_ema::")]
+        state = {"teacher_calls": 0, "match_calls": 0, "student_calls": 0}
+        teacher_forward = teacher.forward
+
+        def teacher_pass(bi, branch=None, **kw):
+            it = state["teacher_calls"]
+            state["teacher_calls"] += 1
+            tsd = teacher.state_dict()
+            for k in names:   # the EMA that precedes this pass has read the right student weights
+                close(tsd[k].float().cpu(), T(z[f"it{it}::t_ema::{k}"]).float(), tol, f"teacher after EMA {it}: {k}")
+            own = teacher_forward(bi, branch=branch, **kw)
+            for o, st in zip(own, stored[it]):
+                assert len(o["instances"]) == len(st["instances"]), (it, len(o["instances"]), len(st["instances"]))
+                close(torch.sort(o["instances"].scores, descending=True).values.cpu(), torch.sort(st["instances"].scores, descending=True).values.cpu(),
+                      max(tol, 1e-5), f"teacher scores, iteration {it}")
+            return copy.deepcopy(stored[it])
+
+        teacher.forward = teacher_pass
+        seen, match = [], tr.match_boxes
+
+        def match_boxes(b, o, **kw):
+            random.seed(77 + state["match_calls"])
+            state["match_calls"] += 1
+            seen.append(match(b, o, **kw))
+            return seen[-1]
+
+        tr.match_boxes = match_boxes
+        # boundary P: per iteration, the samplers return what the reference's samplers drew
+        def sampled(proposals, targets, branch):
+            it = state["student_calls"]
+            return [(_inst(z, f"it{it}::s{i}.a", s).to(dev), _inst(z, f"it{it}::s{i}.b", s).to(dev), _inst(z, f"it{it}::s{i}.bg", s).to(dev))
+                    for i, s in enumerate(sizes[it])]
+
+        def anchors(anc, gt, branch):
+            it = state["student_calls"]
+            g = lambda k: list(T(z[f"it{it}::{k}"]).to(dev))
+            return g("anchor_labels"), g("anchor_matched_boxes"), g("anchor_matched_idxs"), g("anchor_dist_labels")
+
+        student.roi_heads.label_and_sample_proposals = sampled
+        student.proposal_generator.label_and_sample_anchors = anchors
+        records = []
+        for it in range(2):
+            rec = tr.run_step()
+            state["student_calls"] += 1
+            records.append({k: float(v.detach()) for k, v in rec.items()})
+            if os.environ.get("COIN_TEST_DEBUG"):
+                for k in sorted(records[-1]):
+                    print(it, k, records[-1][k], float(z[f"it{it}::loss::{k}"]))
+            assert tr.iter == it + 1 and tr.WEIGHT_FOR_BOX_A == 0.5
+            for k, v in merge.state_dict().items():
+                close(v.cpu(), z[f"it{it}::m_after::" + k], tol, f"merge {k} after iteration {it}")
+            sd = student.state_dict()
+            for k in names:
+                close(sd[k].float().cpu(), T(z[f"it{it}::s_after::" + k]).float(), tol, f"student {k} after iteration {it}")
+            tr.prepare_next()          # iteration it+1's EMA / teacher pass / matching (teacher stream on the GPU); no-op after the last one
+            if it == 0:
+                assert state["teacher_calls"] == 2 and state["match_calls"] == 2, state   # iteration 1 was prepared BEFORE its run_step
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+            assert (tr._teacher_stream is not None) == bool(teacher_stream)
+    assert state["teacher_calls"] == 2
+    for it in range(2):
+        rcnn, rpn = seen[it]
+        assert [[len(t[0]), 0 if t[1] is None else len(t[1]), len(t[2])] for t in rcnn] == z[f"it{it}::n_abc"].tolist(), it
+        for i in range(2):
+            for name, inst in (("a", rcnn[i][0]), ("b", rcnn[i][1]), ("c", rcnn[i][2]), ("rpn_a", rpn[i][0]), ("rpn_c", rpn[i][2])):
+                for k, v in inst.get_fields().items():
+                    close((v.tensor if isinstance(v, Boxes) else v).cpu(), z[f"it{it}::{name}{i}.{k}"], 1e-5, f"it{it} {name}{i}.{k}")
+        ref = {k[len(f"it{it}::loss::"):]: float(z[k]) for k in z.files if k.startswith(f"it{it}::loss::")}
+        assert set(records[it]) == set(ref), (sorted(records[it]), sorted(ref))
+        bad = {k: (records[it][k], v) for k, v in ref.items() if not abs(records[it][k] - v) < 1e-4 * max(1.0, abs(v))}
+        assert not bad, (it, bad)
+    for k, v in merge.state_dict().items():
+        close(v.cpu(), z["it1::m_after::" + k], tol, "merge " + k)
+    sd = student.state_dict()
+    for k in names:
+        close(sd[k].float().cpu(), T(z["it1::s_after::" + k]).float(), tol, "student " + k)
+
+
 # ------------------------------------------------------------------------------------------ sync-free (packed) losses
 def losses_packed_pretrain(device):
     """`losses_packed` (fixed-shape rows with per-row labels / validity) == FastRCNNOutputLayers.losses('pre_train') of the reference

@@ -483,6 +483,14 @@ def test_cointrainer_run_step_vs_reference_scripted_iteration():
     cointrainer_scripted_iteration("cpu")
 
 
+def test_cointrainer_constructor_two_iterations_vs_reference_scripted_iterations():
+    """The real `CoinTrainer(cfg)` constructor over two iterations (EMA due at both) against the reference-scripted fixture (host
+    logic, kernels shimmed); the MI355X run with the teacher stream on is tests/test_parity_gpu.py."""
+    from parity_cases import cointrainer_two_iterations_through_constructor
+
+    cointrainer_two_iterations_through_constructor("cpu")
+
+
 def test_product_rpn_labelling_losses_and_proposals_vs_reference():
     """DualTeacherRPN.label_and_sample_anchors / losses / proposals (rpn.py:41-345) of the PRODUCT vs rpn.npz: sampled labels,
     matched boxes and indices bit for bit (GPU twin in tests/test_parity_gpu.py)."""

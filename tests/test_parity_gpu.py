@@ -37,6 +37,13 @@ def test_cointrainer_run_step_on_device_vs_reference_scripted_iteration():
     PC.cointrainer_scripted_iteration(DEV, tol=2e-5)
 
 
+@pytest.mark.parametrize("teacher_stream", [True, False])
+def test_cointrainer_constructor_two_iterations_on_device_vs_reference_scripted_iterations(teacher_stream):
+    """`CoinTrainer(cfg)` as the reference builds it, AMD.TEACHER_STREAM on (prepare_next pipelining) and off, two iterations with an
+    EMA due at each, against tests/golden/e2e_coin_two_steps.npz."""
+    PC.cointrainer_two_iterations_through_constructor(DEV, tol=2e-5, teacher_stream=teacher_stream)
+
+
 def test_pretrain_step_with_samplers_in_the_loop_on_device():
     """Nothing is fed in: the device RPN / NMS / anchor labelling / RoI sampling must draw the reference's samples, so the losses
     land on the golden values; gradients as in test_e2e_gpu (fp64-calibrated bounds)."""
