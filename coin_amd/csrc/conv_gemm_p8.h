@@ -16,3 +16,4 @@ COIN_HIDDEN int coin_p8_tn_launch(const void* GY, const void* X, int mode, int H
 COIN_HIDDEN extern int coin_conv_gemm_force_impl;
 COIN_HIDDEN extern int coin_p8_debug;
 COIN_HIDDEN extern int coin_p8_splitk;
+COIN_HIDDEN extern int coin_p8_stagger;

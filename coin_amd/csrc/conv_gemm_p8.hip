@@ -89,7 +89,8 @@ struct P8Args {
   // slab[(tile - whole_tiles) * split + piece] and conv_gemm_p8_tail_kernel sums a tile's pieces in piece order and runs the epilogue.
   float* slab; int whole_tiles, rem, split;
   unsigned a_bytes, b_bytes;  // operand sizes for the range-checked DMA
-  int dbg;  // lab only: bit 0 = every A / B DMA reads the zero page
+  int stagger_first, stagger_phases, stagger_ticks;   // see the kernel entry (0 phases: off)
+  int dbg;  // lab only: bit 0 = every A / B DMA reads the zero page, bit 2 = no epilogue
 };
 
 // Work items of workgroup b (grid G): its whole tiles b, b + G, ... (n_whole of them) first, then at most one split-K piece.
@@ -198,6 +199,7 @@ __device__ __forceinline__ void p8_epilogue(const P8Args& p, f32x4 (&acc)[2][2][
   const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
   const int m0 = tm * PM, n0 = tn * PN;
   const int chunk = threadIdx.x & 15, rsub = threadIdx.x >> 4;
+  if (p.dbg & 4) return;  // lab only: main loop without the epilogue
 #pragma unroll
   for (int bh = 0; bh < 2; ++bh) {
     float s1[8], s2[8], piv[8];
@@ -236,7 +238,10 @@ __device__ __forceinline__ void p8_epilogue(const P8Args& p, f32x4 (&acc)[2][2][
 #pragma unroll
           for (int i = 0; i < 8; ++i) v[i] = (bf16_t)((float)v[i] + (float)r[i]);
         }
-        if (grow < p.M) *reinterpret_cast<bf16x8*>(p.C + (size_t)grow * p.ldc + gcol) = v;
+        if (grow < p.M) {
+          if (p.dbg & 16) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p.C + (size_t)grow * p.ldc + gcol));
+          else *reinterpret_cast<bf16x8*>(p.C + (size_t)grow * p.ldc + gcol) = v;
+        }
         if (STATS && (long long)grow < p.stats_rows) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
@@ -297,6 +302,14 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(const P8Args p) {
   const int G = gridDim.x, nk = p.K / PK;
   const P8Items items = p8_items(p, blockIdx.x, G, nk);
   if (items.n_items == 0) return;
+  // De-phasing hook (lab: coin_p8_stagger; off by default -- measured no effect, the CUs do not run in lockstep): workgroups that own
+  // one tile less than the others may start late, spread over `stagger_phases` offsets inside one tile time.
+  if (p.stagger_phases > 1 && (int)blockIdx.x >= p.stagger_first) {
+    const int ph = ((int)blockIdx.x >> 3) % p.stagger_phases;   // blockIdx.x & 7 = XCD: every XCD spreads its own CUs
+    const long long wait = (long long)p.stagger_ticks * ph;
+    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+    while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+  }
   int total_kt = items.n_whole * nk;
   if (items.n_items > items.n_whole) total_kt += items.ke(items.n_whole) - items.kb(items.n_whole);   // (>= 2: every item holds at least two K-tiles)
   int item_idx = 0;
@@ -896,6 +909,7 @@ static int p8_grid(int ntiles) {
 }
 
 int coin_p8_debug = 0;  // lab hook, see TnArgs::dbg
+int coin_p8_stagger = -1;  // lab hook: phases of the start-time stagger (-1: default, 0/1: off)
 int coin_p8_splitk = -1;  // lab hook: -1 = default policy, 0 = never split the tail round, 1 = split whenever it is possible
 
 bool coin_p8_nt_ok(int M, int N, int K, int mode, int Cin, int lda, int ldb) {
@@ -937,6 +951,7 @@ int coin_p8_nt_launch(const void* A, int lda, int mode, int H, int W, int Cin, c
   a.stats = stats; a.stats_rows = stats_rows;
   a.tiles_m = (M + PM - 1) / PM; a.tiles_n = N / PN;
   a.dbg = coin_p8_debug;
+  a.stagger_first = a.stagger_phases = a.stagger_ticks = 0;
   a.a_bytes = (unsigned)((size_t)M * (mode == 1 ? Cin : lda) * 2);
   a.b_bytes = (unsigned)((size_t)N * ldb * 2);
   const int ntiles = a.tiles_m * a.tiles_n;
@@ -946,6 +961,17 @@ int coin_p8_nt_launch(const void* A, int lda, int mode, int H, int W, int Cin, c
   p8_nt_plan(ntiles, K / PK, grid, workspace != nullptr, force, a.whole_tiles, a.rem, a.split);
   if ((size_t)a.rem * a.split * 65536 * sizeof(float) > workspace_bytes) { a.whole_tiles = ntiles; a.rem = 0; a.split = 1; }
   a.slab = (float*)workspace;
+  {
+    static const int env_st = [] { const char* e = getenv("COIN_CONV_GEMM_STAGGER"); return e ? atoi(e) : -1; }();  // measurements only
+    const int phases = coin_p8_stagger >= 0 ? coin_p8_stagger : (env_st >= 0 ? env_st : 0);   // off: no effect measured (lab13)
+    const int r = ntiles % grid;
+    if (phases > 1 && a.split == 1 && ntiles > grid && r != 0) {
+      const int tile_ticks = (K / PK) * 150 + 300;   // 10 ns ticks: ~1.5 us per K-tile of 64 at ~1 PFLOP/s + the epilogue
+      a.stagger_first = r;
+      a.stagger_phases = phases;
+      a.stagger_ticks = tile_ticks / phases;
+    }
+  }
 #define P8_LAUNCH(G3, ST)                                                                                                          \
   do {                                                                                                                             \
     static bool attr_set = false;                                                                                                  \

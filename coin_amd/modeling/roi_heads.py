@@ -213,7 +213,9 @@ class OpenVocabularyRes5ROIHeads(nn.Module):
                 pb = torch.cat([pb, pb.new_zeros(pad, 4)])
                 pv = torch.cat([pv, torch.zeros(pad, dtype=torch.bool, device=dev)])
             if g > 0:
-                idx, lab = self.proposal_matcher(pairwise_iou(t.gt_boxes, Boxes(pb)))
+                # IoU + arg-max + threshold band in one launch (coin_anchor_match; bit-identical to Matcher(pairwise_iou(...)))
+                idx, lab, _ = self.proposal_matcher.match_boxes([t.gt_boxes.tensor], pb, want_boxes=False)
+                idx, lab = idx[0], lab[0]
                 cls = torch.where(lab == 1, t.gt_classes_offline[idx], torch.full_like(idx, k))
                 gtb = torch.where((lab == 1).unsqueeze(1), t.gt_boxes.tensor[idx], pb)
                 pr = t.gt_probs_offline[idx]
@@ -256,7 +258,8 @@ class OpenVocabularyRes5ROIHeads(nn.Module):
             m = pb.shape[0]
             if la + lb + lc > 0:
                 tboxes = Boxes.cat([a.gt_boxes, b.gt_boxes, c.gt_boxes])
-                idx, lab = self.proposal_matcher(pairwise_iou(tboxes, Boxes(pb)))
+                idx, lab, _ = self.proposal_matcher.match_boxes([tboxes.tensor], pb, want_boxes=False)   # one fused launch
+                idx, lab = idx[0], lab[0]
                 fg = lab == 1
                 in_a, in_b = idx < la, (idx >= la) & (idx < la + lb)
                 role = torch.where(fg & in_a, 0, torch.where(fg & in_b, 1, torch.where(fg, -1, 2)))  # fg on a C box -> ignored

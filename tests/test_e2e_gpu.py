@@ -223,15 +223,19 @@ def test_inference_fp32_vs_reference_golden():
     for i, r in enumerate(res):
         inst = r["instances"].to("cpu")
         assert len(inst) == z[f"det{i}.scores"].shape[0]
-        # canonical row order on both sides (scores tie when one box survives under several classes)
-        ours = torch.cat([inst.pred_classes.double().unsqueeze(1), inst.scores.double().unsqueeze(1), inst.pred_boxes.tensor.double()], dim=1).numpy()
-        ref = np.concatenate([z[f"det{i}.pred_classes"].astype(np.float64)[:, None], z[f"det{i}.scores"].astype(np.float64)[:, None],
-                              z[f"det{i}.pred_boxes"].astype(np.float64)], axis=1)
-        key = lambda m: np.lexsort((np.round(m[:, 2], 1), np.round(m[:, 1], 3), m[:, 0]))
-        ours, ref = ours[key(ours)], ref[key(ref)]
-        assert (ours[:, 0] == ref[:, 0]).all()
-        np.testing.assert_allclose(ours[:, 1], ref[:, 1], atol=1e-4)
-        np.testing.assert_allclose(ours[:, 2:], ref[:, 2:], atol=2e-2)
+        # Pair the rows: the reference's order among tied scores (one box surviving under several classes, neighbouring anchors with
+        # the same score) is an artefact of its sort, so every detection is matched to the nearest unused reference row of its class.
+        ob, oc, osc = inst.pred_boxes.tensor.double().numpy(), inst.pred_classes.numpy(), inst.scores.double().numpy()
+        rb, rc, rsc = z[f"det{i}.pred_boxes"].astype(np.float64), z[f"det{i}.pred_classes"], z[f"det{i}.scores"].astype(np.float64)
+        used = np.zeros(len(rb), dtype=bool)
+        for j in range(len(ob)):
+            d = np.abs(rb - ob[j]).max(axis=1) + 1e3 * (rc != oc[j]) + 1e6 * used
+            k = int(d.argmin())
+            used[k] = True
+            assert rc[k] == oc[j]
+            assert d[k] <= 1e-3, (i, j, d[k])                       # fp32 decode: boxes to 1e-3 px (measured 3e-5 on 256-px images)
+            assert abs(rsc[k] - osc[j]) <= 1e-5, (i, j, rsc[k], osc[j])
+        assert used.all()
 
 
 def test_cointrainer_constructor_teacher_stream_equals_the_synchronous_run_over_ema_iterations():

@@ -71,6 +71,7 @@ static const Shape kShapes[] = {{"l4.0.conv1", 2048, 14, 14, 1024, 512, 1}, {"l4
 static void* g_ws = nullptr;
 static size_t g_ws_bytes = 0;
 static int g_split = -1;   // coin_p8_splitk for the next p8 launches
+static int g_stag = -1;    // coin_p8_stagger for the next p8 launches
 
 static int run_gemm(int impl, const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb, void* C, int ldc, const void* R, int ldr,
                     int M, int N, int K, float* stats, int64_t stats_rows) {
@@ -82,9 +83,11 @@ static int run_gemm(int impl, const void* A, int lda, int mode, int H, int W, in
   }
   coin_conv_gemm_force_impl = impl;
   coin_p8_splitk = g_split;
+  coin_p8_stagger = g_stag >= 0 ? g_stag : (getenv("LAB_STAG") ? atoi(getenv("LAB_STAG")) : -1);
   const int rc = coin_conv_gemm_bf16_ws(A, lda, mode, H, W, Cin, B, ldb, C, ldc, R, ldr, M, N, K, stats, stats_rows, g_ws, g_ws_bytes, nullptr);
   coin_conv_gemm_force_impl = 0;
   coin_p8_splitk = -1;
+  coin_p8_stagger = -1;
   return rc;
 }
 
@@ -212,14 +215,17 @@ static void bench_shape(const Shape& sh, int iters, int rounds) {
     fill(B, bn, 0x9876u + dir, 0.05f);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const int impls[4] = {1, 2, 1, 1};
-    const bool stats[4] = {false, false, true, false};
-    const int splits[4] = {-1, -1, -1, 0};
-    const char* names[4] = {"p8", "sq", "p8+stats", "p8nosplit"};
-    std::vector<float> best(4, 1e30f), med[4];
+    constexpr int NV = 5;
+    const int impls[NV] = {1, 1, 1, 1, 1};
+    const bool stats[NV] = {false, false, true, true, false};
+    const int splits[NV] = {-1, -1, -1, -1, 0};
+    const int stags[NV] = {-1, 0, -1, 0, -1};
+    const char* names[NV] = {"p8", "p8nostag", "p8+stats", "p8+stats_nostag", "p8nosplit"};
+    std::vector<float> best(NV, 1e30f), med[NV];
     for (int r = 0; r < rounds; ++r)
-      for (int v = 0; v < 4; ++v) {
+      for (int v = 0; v < NV; ++v) {
         g_split = splits[v];
+        g_stag = stags[v];
         if (dir == 1 && stats[v]) continue;
         run_gemm(impls[v], A, Cin, mode, sh.h, sh.w, Cin, B, K, C, N, nullptr, 0, M, N, K, stats[v] ? S : nullptr, M);  // warm
         float ms = 0;
@@ -245,7 +251,8 @@ static void bench_shape(const Shape& sh, int iters, int rounds) {
     const double flop = 2.0 * M * (double)N * K;
     printf("{\"shape\": \"%s\", \"dir\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d", sh.name, dir == 0 ? "fwd" : "dgrad", M, N, K);
     g_split = -1;
-    for (int v = 0; v < 4; ++v) {
+    g_stag = -1;
+    for (int v = 0; v < NV; ++v) {
       if (med[v].empty()) continue;
       std::sort(med[v].begin(), med[v].end());
       const float m = med[v][med[v].size() / 2];
@@ -444,6 +451,7 @@ int main(int argc, char** argv) {
     fails += check_wgrad("3x3 tiny", 49 * 2, 256, 256, 1, 7, 7);
     printf("WCHECK total failures: %d\n", fails);
   }
+  if (getenv("LAB_DBG")) coin_p8_debug = atoi(getenv("LAB_DBG"));   // e.g. 4: main loops without the epilogue
   if (!strcmp(what, "bench") || !strcmp(what, "all")) {
     for (const Shape& s : kShapes) bench_shape(s, iters, g_cold ? 2 : 5);
   }
