@@ -150,31 +150,95 @@ class _ConvGemm(Function):
     @once_differentiable
     def backward(ctx, gy, _gpart, g_tap=None):
         x, wq = ctx.saved_tensors
-        ks, pad = ctx.ks, ctx.ks // 2
+        gyn = _as_nhwc(gy)
+        if gyn.dtype != torch.bfloat16:
+            gyn = gyn.to(torch.bfloat16)
+        dx, dw = _conv_gemm_grads(x, wq, gyn, ctx.ks, ctx.needs_input_grad[0], ctx.needs_input_grad[1], g_tap)
+        return dx, dw, None, None, None
+
+
+def _conv_gemm_grads(x, wq, gyn, ks, need_dx, need_dw, g_tap=None):
+    """(dx, dw) of the GEMM convolutions; gyn: bf16 NHWC gradient of the output, x: the saved (logical NCHW) input, wq: bf16 weight."""
+    pad = ks // 2
+    n, h, w, co = gyn.shape
+    ci = wq.shape[1]
+    dx = dw = None
+    if need_dx:
+        # dgrad = the same contraction over (flipped tap, Cout): weight re-laid [Cin][ky'][kx'][Cout] (a few MB, once per call)
+        wd = wq.flip(2, 3).permute(1, 2, 3, 0).contiguous().reshape(ci, ks * ks * co)
+        res = None
+        if g_tap is not None:
+            res = _as_nhwc(g_tap)
+            res = (res if res.dtype == torch.bfloat16 else res.to(torch.bfloat16)).reshape(n * h * w, ci)
+        gx, _ = K.conv_gemm(gyn.reshape(n * h * w, co), wd, spatial=(h, w, co) if ks == 3 else None, residual=res)
+        dx = gx.view(n, h, w, ci).permute(0, 3, 1, 2)
+    if need_dw:
+        if CONV_GEMM["wgrad"] and K.conv_wgrad_ok(co, ci):
+            xn = _as_nhwc(x)
+            dw2 = K.conv_wgrad(gyn.reshape(n * h * w, co), xn.reshape(n * h * w, ci), spatial=(h, w, ci) if ks == 3 else None)
+            dw = dw2.view(co, ks, ks, ci).permute(0, 3, 1, 2)  # fp32, already in the parameter's channels-last layout
+        else:
+            dw = torch.ops.aten.convolution_backward(gyn.permute(0, 3, 1, 2), x, wq, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1].float()
+    return dx, dw
+
+
+class _ConvGemmBiasRelu(Function):
+    """relu(conv(x) + bias) for a 3x3 / pad 1 (or 1x1) convolution WITH bias on the hand-written GEMM: the RPN head's shared
+    convolution (detectron2 StandardRPNHead, coin/modeling/proposal_generator/rpn.py:53-59 -- 1024 -> 1024 channels on res4, 313 GFLOP
+    per pass at the timed shape, the largest convolution left on the library).  The GEMM stores bf16(conv), one streaming pass adds
+    the bias and clamps (the frozen-BatchNorm apply kernel with mean 0 / scale 1 / shift = bias)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, wq):
+        xn = _as_nhwc(x)
+        n, h, w, c = xn.shape
+        co, ks = wq.shape[0], wq.shape[2]
+        wk = wq.permute(0, 2, 3, 1)
+        wk = (wk if wk.is_contiguous() else wk.contiguous()).reshape(co, ks * ks * c)
+        z, _ = K.conv_gemm(xn.reshape(n * h * w, c), wk, spatial=(h, w, c) if ks == 3 else None)
+        one, zero = _unit_consts(co, x.device)
+        y = K.bn_apply_fwd(z.view(n, h, w, co), zero, one, one, bias.detach().float().contiguous(), None, True, 1)
+        ctx.save_for_backward(x, wq, y)
+        ctx.ks = ks
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, wq, y = ctx.saved_tensors
         gyn = _as_nhwc(gy)
         if gyn.dtype != torch.bfloat16:
             gyn = gyn.to(torch.bfloat16)
         n, h, w, co = gyn.shape
-        ci = wq.shape[1]
-        dx = dw = None
-        if ctx.needs_input_grad[0]:
-            # dgrad = the same contraction over (flipped tap, Cout): weight re-laid [Cin][ky'][kx'][Cout] (a few MB, once per call)
-            wd = wq.flip(2, 3).permute(1, 2, 3, 0).contiguous().reshape(ci, ks * ks * co)
-            res = None
-            if g_tap is not None:
-                res = _as_nhwc(g_tap)
-                res = (res if res.dtype == torch.bfloat16 else res.to(torch.bfloat16)).reshape(n * h * w, ci)
-            gx, _ = K.conv_gemm(gyn.reshape(n * h * w, co), wd, spatial=(h, w, co) if ks == 3 else None, residual=res)
-            dx = gx.view(n, h, w, ci).permute(0, 3, 1, 2)
-        if ctx.needs_input_grad[1]:
-            if CONV_GEMM["wgrad"] and K.conv_wgrad_ok(co, ci):
-                xn = _as_nhwc(x)
-                dw2 = K.conv_wgrad(gyn.reshape(n * h * w, co), xn.reshape(n * h * w, ci), spatial=(h, w, ci) if ks == 3 else None)
-                dw = dw2.view(co, ks, ks, ci).permute(0, 3, 1, 2)  # fp32, already in the parameter's channels-last layout
-            else:
-                dw = torch.ops.aten.convolution_backward(gyn.permute(0, 3, 1, 2), x, wq, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
-                                                         [False, True, False])[1].float()
-        return dx, dw, None, None, None
+        dz, dbias = K.bias_act_bwd(gyn.reshape(n * h * w, co), y.view(n * h * w, co), K.ACT_RELU)
+        dx, dw = _conv_gemm_grads(x, wq, dz.view(n, h, w, co), ctx.ks, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dx, dw, (dbias if ctx.needs_input_grad[2] else None), None
+
+
+_UNIT: Dict[Tuple[int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def _unit_consts(c: int, device):
+    key = (c, str(device))
+    if key not in _UNIT:
+        _UNIT[key] = (torch.ones(c, dtype=torch.float32, device=device), torch.zeros(c, dtype=torch.float32, device=device))
+    return _UNIT[key]
+
+
+def conv_bias_relu(x: torch.Tensor, conv: torch.nn.Conv2d, min_rows: int = 8192) -> torch.Tensor:
+    """relu(conv(x)) for a convolution with bias: on the hand-written GEMM in the bf16 mode when the shape fits (stride 1, 'same'
+    padding, Cin % 64 == 0, Cout % 256 == 0, at least `min_rows` output pixels), else the library convolution + relu."""
+    ks = conv.kernel_size
+    if (CONV_GEMM["enabled"] and x.is_cuda and x.dim() == 4 and compute_dtype_of(x) == torch.bfloat16 and conv.bias is not None
+            and ks in ((1, 1), (3, 3)) and conv.stride == (1, 1) and conv.padding == (ks[0] // 2, ks[1] // 2) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.in_channels % 64 == 0 and conv.out_channels % 256 == 0
+            and x.shape[0] * x.shape[2] * x.shape[3] >= min_rows):
+        if x.dtype != torch.bfloat16:
+            x = x.to(torch.bfloat16)
+        wq = _shadow_entry(conv.weight, torch.bfloat16).tensor
+        return _ConvGemmBiasRelu.apply(x, conv.weight, conv.bias, wq)
+    return torch.nn.functional.relu(conv2d(x, conv))
 
 
 def conv2d_gemm(x: torch.Tensor, conv: torch.nn.Conv2d, stats_rows: Optional[int] = None, fork: bool = False):

@@ -33,7 +33,7 @@ class StandardRPNHead(nn.Module):
     def forward(self, features: List[torch.Tensor]):
         lg, dl = [], []
         for x in features:
-            t = F.relu(L.conv2d(x, self.conv))
+            t = L.conv_bias_relu(x, self.conv)   # 3x3 + bias + ReLU: hand-written GEMM in the bf16 mode
             lg.append(L.conv2d(t, self.objectness_logits))
             dl.append(L.conv2d(t, self.anchor_deltas))
         return lg, dl

@@ -320,6 +320,50 @@ def test_bottleneck_gradient_fan_in_fused_in_dgrad_epilogue(monkeypatch, inplane
     torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-2, atol=1e-2 * float(res[1][2].abs().max()))
 
 
+@pytest.mark.parametrize("shape", [(2, 256, 40, 56, 256), (4, 1024, 50, 83, 1024)])   # small; the RPN head at the timed shape
+def test_rpn_head_conv_bias_relu_on_the_gemm_path_vs_fp64(monkeypatch, shape):
+    """relu(conv3x3(x) + bias) of the RPN head (StandardRPNHead, rpn.py:53-59) on coin_conv_gemm_bf16 + the streaming bias/clamp pass
+    (layers.conv_bias_relu) against the fp64 convolution of the same bf16 operands: output to bf16 rounding, and the three
+    gradients (input through the masked dgrad, weight through coin_conv_wgrad_bf16, bias) to the bf16 noise of their inputs."""
+    import sys
+
+    sys.path.insert(0, __import__("os").path.dirname(__file__))
+    import seeded
+    from coin_amd import layers as L
+
+    n, c, h, w, co = shape
+    monkeypatch.setitem(L.CONV_GEMM, "enabled", True)
+    conv = torch.nn.Conv2d(c, co, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(seeded.randn(tuple(conv.weight.shape), 5) * (2.0 / (9 * c)) ** 0.5)
+        conv.bias.copy_(seeded.randn((co,), 6) * 0.2)
+    conv = conv.cuda()
+    x = (seeded.randn((n, c, h, w), 7).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)).requires_grad_(True)
+    calls = []
+    real = L._ConvGemmBiasRelu.apply
+    monkeypatch.setattr(L._ConvGemmBiasRelu, "apply", lambda *a: (calls.append(1), real(*a))[1])
+    y = L.conv_bias_relu(x, conv, min_rows=0)
+    assert y.dtype == torch.bfloat16 and calls == [1], "the hand-written path did not run"
+    gy = seeded.randn(tuple(y.shape), 8).cuda().to(torch.bfloat16)
+    y.backward(gy)
+    # fp64 reference on the same bf16 operands (weights as the bf16 shadow the kernel reads)
+    xr = x.detach().double().requires_grad_(True)
+    wr = conv.weight.detach().to(torch.bfloat16).double().requires_grad_(True)
+    br = conv.bias.detach().double().requires_grad_(True)
+    # the product rounds conv(x) to bf16 before the bias: take the mask / values from the same intermediate
+    z = F.conv2d(xr, wr, None, padding=1)
+    yr = torch.relu(z.to(torch.bfloat16).double().detach() + (z - z.detach()) + br.view(1, -1, 1, 1))
+    yr.backward(gy.double())
+    scale = float(yr.detach().abs().max())
+    assert float((y.detach().double() - yr.detach()).abs().max()) <= 2.0 ** -7 * scale           # two bf16 roundings
+    for got, ref, what in ((x.grad, xr.grad, "dx"), (conv.weight.grad, wr.grad, "dw"), (conv.bias.grad, br.grad, "dbias")):
+        err = float((got.double() - ref).abs().max())
+        ref_scale = float(ref.abs().max())
+        # dx is stored in bf16 (2^-8 relative per element, measured against the tensor's scale as everywhere in this file); dw / dbias are
+        # fp32 sums of bf16 products, their error is that of the bf16 dz rows (mask + rounding of gy already in the reference)
+        assert err <= (2.0 ** -7 if what == "dx" else 2e-3) * ref_scale, (what, err, ref_scale)
+
+
 def test_gemm_rejects_bad_shapes(K):
     from coin_amd._lib import CoinHipError
 
