@@ -921,6 +921,7 @@ bool coin_p8_nt_ok(int M, int N, int K, int mode, int Cin, int lda, int ldb) {
 
 // Split-K plan of the tail round (see P8Args): only where a tile is long enough for the combine pass (two passes over `rem * split`
 // fp32 tiles of 256 KiB) to cost less than the idle CUs it removes -- K >= 2048 -- and the tail fills at most half of the CUs.
+// G = the number of CUs (also when there are fewer tiles than CUs: then every tile is a leftover tile and is cut along K).
 static void p8_nt_plan(int ntiles, int nk, int G, bool have_ws, int force, int& whole, int& rem, int& split) {
   whole = ntiles; rem = 0; split = 1;
   const int r = ntiles % G;
@@ -936,7 +937,7 @@ size_t coin_p8_nt_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N % PN || K % PK) return 0;
   const int ntiles = ((M + PM - 1) / PM) * (N / PN), G = p8_grid(1 << 30);
   int whole, rem, split;
-  p8_nt_plan(ntiles, K / PK, G < ntiles ? G : ntiles, true, 1, whole, rem, split);   // upper bound: as if forced on
+  p8_nt_plan(ntiles, K / PK, G, true, 1, whole, rem, split);   // upper bound: as if forced on
   return (size_t)rem * split * 65536 * sizeof(float);
 }
 
@@ -955,11 +956,13 @@ int coin_p8_nt_launch(const void* A, int lda, int mode, int H, int W, int Cin, c
   a.a_bytes = (unsigned)((size_t)M * (mode == 1 ? Cin : lda) * 2);
   a.b_bytes = (unsigned)((size_t)N * ldb * 2);
   const int ntiles = a.tiles_m * a.tiles_n;
-  const int grid = p8_grid(ntiles);
+  const int cus = p8_grid(1 << 30);
+  int grid = ntiles < cus ? ntiles : cus;
   static const int env_split = [] { const char* e = getenv("COIN_CONV_GEMM_SPLITK"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();  // measurements only
   const int force = coin_p8_splitk >= 0 ? coin_p8_splitk : env_split;
-  p8_nt_plan(ntiles, K / PK, grid, workspace != nullptr, force, a.whole_tiles, a.rem, a.split);
+  p8_nt_plan(ntiles, K / PK, cus, workspace != nullptr, force, a.whole_tiles, a.rem, a.split);
   if ((size_t)a.rem * a.split * 65536 * sizeof(float) > workspace_bytes) { a.whole_tiles = ntiles; a.rem = 0; a.split = 1; }
+  if (a.split > 1 && a.whole_tiles == 0) grid = a.rem * a.split;   // fewer tiles than CUs: only pieces (<= cus of them)
   a.slab = (float*)workspace;
   {
     static const int env_st = [] { const char* e = getenv("COIN_CONV_GEMM_STAGGER"); return e ? atoi(e) : -1; }();  // measurements only

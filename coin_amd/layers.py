@@ -121,7 +121,12 @@ def _conv_gemm_ok(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
         return False
     if conv.groups != 1 or conv.bias is not None or conv.in_channels % 64 or conv.out_channels % 64:
         return False
-    return x.shape[0] * x.shape[2] * x.shape[3] >= CONV_GEMM["min_rows"]
+    rows = x.shape[0] * x.shape[2] * x.shape[3]
+    if rows >= CONV_GEMM["min_rows"]:
+        return True
+    # long-K 3x3 convolutions with few output tiles (layer3's conv2 on the res4 map: 65 tiles for 256 CUs): the split-K plan cuts every
+    # tile along K, measured 47 / 47 / 55 us (forward / dgrad / wgrad) against the library's 50 / 132 us (tools/gemm_lab, l3.x.conv2)
+    return ks == (3, 3) and rows >= CONV_GEMM["min_rows"] // 2 and conv.in_channels % 256 == 0 and conv.out_channels % 256 == 0
 
 
 class _ConvGemm(Function):

@@ -66,7 +66,8 @@ struct Shape {
 };
 
 static const Shape kShapes[] = {{"l4.0.conv1", 2048, 14, 14, 1024, 512, 1}, {"l4.0.conv2", 2048, 14, 14, 512, 512, 3}, {"l4.0.conv3", 2048, 7, 7, 512, 2048, 1},
-                                {"l4.0.down", 2048, 7, 7, 1024, 2048, 1},   {"l4.1.conv1", 2048, 7, 7, 2048, 512, 1},  {"l4.1.conv2", 2048, 7, 7, 512, 512, 3}};
+                                {"l4.0.down", 2048, 7, 7, 1024, 2048, 1},   {"l4.1.conv1", 2048, 7, 7, 2048, 512, 1},  {"l4.1.conv2", 2048, 7, 7, 512, 512, 3},
+                                {"rpn.conv", 4, 50, 83, 1024, 1024, 3},     {"l3.x.conv2", 4, 50, 83, 256, 256, 3}};   // backbone-resolution convolutions
 
 static void* g_ws = nullptr;
 static size_t g_ws_bytes = 0;
@@ -441,6 +442,8 @@ int main(int argc, char** argv) {
     fails += check_case("splitK 1x1 few tiles", 256 * 3, 256, 512, 0, 0, 0, 0, false, 700, 1);
     fails += check_case("splitK 3x3 7x7", 100352, 512, 4608, 1, 7, 7, 512, true, 100352, 1);
     fails += check_case("splitK 3x3 14x14", 196 * 700, 512, 4608, 1, 14, 14, 512, false, 196 * 700, 1);
+    fails += check_case("fewer tiles than CUs 3x3 (default policy)", 4 * 50 * 83, 256, 2304, 1, 50, 83, 256, false, 4 * 50 * 83, -1);
+    fails += check_case("RPN head 3x3 1024 (default policy)", 4 * 50 * 83, 1024, 9216, 1, 50, 83, 1024, true, 0, -1);
     printf("CHECK total failures: %d\n", fails);
   }
   if (!strcmp(what, "wcheck") || !strcmp(what, "all")) {
