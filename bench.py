@@ -42,8 +42,8 @@ ENTRY_KERNELS = {
     "coin_roi_align_fwd": ["roi_align_fwd_nhwc_kernel"], "coin_roi_align_bwd": ["roi_align_bwd_gather_kernel"],
     "coin_bn_stats": ["bn_stats_kernel", "bn_finalize_kernel"], "coin_bn_apply_fwd": ["bn_apply_kernel | bn_apply_mean_kernel"],
     "coin_bn_bwd": ["bn_bwd_reduce_kernel", "bn_bwd_finalize_kernel", "bn_bwd_dx_kernel"], "coin_gemm_nt": ["gemm_nt_bf16_kernel"],
-    "coin_conv_gemm_bf16": ["conv_gemm_p8_kernel (+ conv_gemm_p8_tail_kernel where the tail round is split along K) | conv_gemm256_bf16_kernel | "
-                            "conv_gemm_bf16_kernel  (<GATHER3, STATS> instantiations)"],
+    "coin_conv_gemm_bf16": ["conv_gemm_p8_kernel (+ conv_gemm_p8_slab_sum_kernel, conv_gemm_p8_tail_kernel where leftover tiles are cut along K) | "
+                            "conv_gemm256_bf16_kernel | conv_gemm_bf16_kernel  (<GATHER3, STATS> instantiations)"],
     "coin_conv_wgrad_bf16": ["conv_wgrad_p8_kernel", "tn_reduce_kernel"],
     "coin_conv_gemm_stats_finalize": ["conv_stats_finalize_kernel"],
 }

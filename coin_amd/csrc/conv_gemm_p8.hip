@@ -90,7 +90,7 @@ struct P8Args {
   float* slab; int whole_tiles, rem, split;
   unsigned a_bytes, b_bytes;  // operand sizes for the range-checked DMA
   int stagger_first, stagger_phases, stagger_ticks;   // see the kernel entry (0 phases: off)
-  int dbg;  // lab only: bit 0 = every A / B DMA reads the zero page, bit 2 = no epilogue
+  int dbg;  // lab only: bit 0 = every A / B DMA reads the zero page, bit 2 = no epilogue, bit 4 = non-temporal output stores
 };
 
 // Work items of workgroup b (grid G): its whole tiles b, b + G, ... (n_whole of them) first, then at most one split-K piece.

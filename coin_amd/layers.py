@@ -190,7 +190,7 @@ def _conv_gemm_grads(x, wq, gyn, ks, need_dx, need_dw, g_tap=None):
 
 class _ConvGemmBiasRelu(Function):
     """relu(conv(x) + bias) for a 3x3 / pad 1 (or 1x1) convolution WITH bias on the hand-written GEMM: the RPN head's shared
-    convolution (detectron2 StandardRPNHead, coin/modeling/proposal_generator/rpn.py:53-59 -- 1024 -> 1024 channels on res4, 313 GFLOP
+    convolution (detectron2 0.5 `StandardRPNHead.forward`, called at coin/modeling/proposal_generator/rpn.py:65 -- 1024 -> 1024 channels on res4, 313 GFLOP
     per pass at the timed shape, the largest convolution left on the library).  The GEMM stores bf16(conv), one streaming pass adds
     the bias and clamps (the frozen-BatchNorm apply kernel with mean 0 / scale 1 / shift = bias)."""
 

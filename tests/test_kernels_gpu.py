@@ -322,7 +322,7 @@ def test_bottleneck_gradient_fan_in_fused_in_dgrad_epilogue(monkeypatch, inplane
 
 @pytest.mark.parametrize("shape", [(2, 256, 40, 56, 256), (4, 1024, 50, 83, 1024)])   # small; the RPN head at the timed shape
 def test_rpn_head_conv_bias_relu_on_the_gemm_path_vs_fp64(monkeypatch, shape):
-    """relu(conv3x3(x) + bias) of the RPN head (StandardRPNHead, rpn.py:53-59) on coin_conv_gemm_bf16 + the streaming bias/clamp pass
+    """relu(conv3x3(x) + bias) of the RPN head (StandardRPNHead, called at rpn.py:65) on coin_conv_gemm_bf16 + the streaming bias/clamp pass
     (layers.conv_bias_relu) against the fp64 convolution of the same bf16 operands: output to bf16 rounding, and the three
     gradients (input through the masked dgrad, weight through coin_conv_wgrad_bf16, bias) to the bf16 noise of their inputs."""
     import sys
