@@ -123,6 +123,7 @@ __global__ __launch_bounds__(AM_THREADS) void anchor_low_quality_kernel(const fl
 // `rank < k` of an ascending stable sort by key selects (coin_amd/box_ops.py:sample_masks), found by a 3-pass radix select on the
 // 24-bit keys instead of sorting all M keys.  out[m] = 1 (chosen positive) / 0 (chosen negative) / -1.
 constexpr int SS_THREADS = 1024;
+constexpr int SS_TIE_CAP = 2048;   // elements of the threshold bin that are ranked exactly (more only with thousands of equal keys: index order)
 
 __device__ int block_sum(int v, int* scratch) {  // all threads get the sum
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -150,9 +151,11 @@ __device__ int block_excl_scan(int v, int* scratch) {
   return base + inc - v;
 }
 
-// keys are compared at torch.rand's own resolution: k24 = floor(key * 2^24) (exact for torch.rand's multiples of 2^-24); uniform
-// 24-bit integers give evenly filled radix bins, and each wave counts into its own LDS histogram (a shared histogram of raw float
-// bits serialised ~60 000 atomics on the few exponent bins: 0.79 ms per launch, measured)
+// The radix select runs on k24 = floor(key * 2^24): uniform 24-bit integers give evenly filled radix bins, and each wave counts into
+// its own LDS histogram (a shared histogram of raw float bits serialised ~60 000 atomics on the few exponent bins: 0.79 ms per
+// launch, measured).  k24 is monotone in the key but not injective -- the CPU generator's torch.rand draws multiples of 2^-24, the
+// device generator's are finer below 0.5 -- so the elements that share the threshold's 24-bit bin are ranked by (raw float bits,
+// index) afterwards: the selection is exactly the ascending stable sort by the float key (round-2 ADVICE).
 __device__ __forceinline__ unsigned key24(float k) {
   const float v = k * 16777216.0f;
   return v <= 0.f ? 0u : (v >= 16777215.0f ? 16777215u : (unsigned)v);
@@ -166,6 +169,8 @@ __global__ __launch_bounds__(SS_THREADS) void sample_labels_kernel(const CLS* __
   __shared__ int scratch[SS_THREADS / 64];
   __shared__ unsigned s_prefix;
   __shared__ int s_k;
+  __shared__ int s_tidx[SS_TIE_CAP];
+  __shared__ unsigned s_tbits[SS_TIE_CAP];
   const int img = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const CLS* c = cls + (size_t)img * M;
@@ -236,10 +241,37 @@ __global__ __launch_bounds__(SS_THREADS) void sample_labels_kernel(const CLS* __
     for (int m = threadIdx.x; m < M; m += SS_THREADS)
       if (member(m) && key24(ky[m]) == T) ++ties;
     const int n_ties = block_sum(ties, scratch);
-    if (n_ties <= kk) {             // the usual case (distinct keys: one element equals T): no ranking needed
+    if (n_ties <= kk) {             // the usual case (one element in the threshold bin): no ranking needed
       for (int m = threadIdx.x; m < M; m += SS_THREADS)
         if (member(m) && key24(ky[m]) <= T) o[m] = mark;
-    } else {                        // repeated keys at the threshold: rank them in index order, 1024 indices per round
+    } else if (n_ties <= SS_TIE_CAP) {
+      // several elements in the threshold bin: gather them (index order), rank by (raw key bits, index) -- non-negative floats order
+      // as unsigned integers -- and take the first kk
+      int base = 0;
+      for (int m0 = 0; m0 < M; m0 += SS_THREADS) {
+        const int m = m0 + threadIdx.x;
+        const bool mem = m < M && member(m);
+        const unsigned u = mem ? key24(ky[m]) : 0xffffffffu;
+        const int tie = mem && u == T;
+        const int pos = base + block_excl_scan(tie, scratch);
+        if (tie) {
+          s_tidx[pos] = m;
+          s_tbits[pos] = __float_as_uint(ky[m]);
+        }
+        if (mem && u < T) o[m] = mark;
+        base += block_sum(tie, scratch);
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < n_ties; i += SS_THREADS) {
+        const unsigned bi = s_tbits[i];
+        int r = 0;
+        for (int j = 0; j < n_ties; ++j) {
+          const unsigned bj = s_tbits[j];
+          r += (bj < bi) || (bj == bi && j < i);
+        }
+        if (r < kk) o[s_tidx[i]] = mark;
+      }
+    } else {                        // thousands of keys in the threshold bin (equal keys): rank them in index order, 1024 indices per round
       int base = 0;
       for (int m0 = 0; m0 < M; m0 += SS_THREADS) {
         const int m = m0 + threadIdx.x;

@@ -34,13 +34,6 @@ constexpr int P_KT = 4 * P_HALF;       // A-lo | A-hi | B-lo | B-hi
 constexpr int P_IMG = 2 * P_KT;        // epilogue image: 128 rows x 256 B
 constexpr int P_LDS = P_IMG + 128 * 256;
 
-__device__ __attribute__((aligned(256))) unsigned char p8_zero_page[512];  // 3x3 taps outside the image / pixels beyond M
-
-__device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
 // Range-checked buffer LDS-DMA of 16 bytes per lane: address = base + voff (per lane) + soff (wave-uniform); an offset at or beyond
 // `bytes` writes zeros.  (A plain function on purpose: called with these builtins directly, the function TEMPLATES below are rejected
 // by the host pass of hipcc 7.2 with a bare "substitution failure".)

@@ -149,9 +149,31 @@ class CoinTrainer(BASE_Trainer):
         and the teacher's (small, low-occupancy) inference kernels share the GPU with that backward.  The only cross-stream
         dependency is the EMA, which reads the weights the optimizer has just written: the teacher stream waits for the main
         stream when an EMA is due.  The targets stay on the host until `run_step` uploads them on the main stream."""
-        cfg, burn = self.cfg, self.cfg.CLOUD.BURN_UP_STEP
-        ema_due = self.iter >= burn and (self.iter - burn) % cfg.CLOUD.OFFLINE_TEACHER_UPDATE_ITER == 0
-        side = None
+        return self._fetch_end(self._fetch_begin(self.iter))
+
+    _teacher_mods = None
+
+    def _teacher_mode(self, training: bool):
+        """`self.offline_teacher.train(training)` without nn.Module.train()'s recursive Python walk (600 modules, 1.2 ms per call and
+        four calls per iteration: the reference brackets every teacher pass with eval() / train(), trainer.py:175-177)."""
+        if self._teacher_mods is None:
+            self._teacher_mods = list(self.offline_teacher.modules())
+        for m in self._teacher_mods:
+            object.__setattr__(m, "training", training)
+
+    def _ema_due(self, it: int) -> bool:
+        burn = self.cfg.CLOUD.BURN_UP_STEP
+        return it >= burn and (it - burn) % self.cfg.CLOUD.OFFLINE_TEACHER_UPDATE_ITER == 0
+
+    def _fetch_begin(self, it: int):
+        """First half of `_fetch` for iteration `it`: draw the batch, EMA when due, and ENQUEUE the teacher's inference pass without a
+        host round trip (OpenVocabularyRCNN.inference_begin; a detector that has no fixed-shape pass leaves everything to the second
+        half).  While the teacher is frozen (no EMA due for `it`: the whole step_one phase, trainer.py:170-172) `run_step` calls this
+        for iteration i+1 BEFORE it enqueues the student's step i: the same computation on the same weights, but the teacher's
+        device work and the read-back of its detections then hide under the student's step instead of following it."""
+        cfg = self.cfg
+        ema_due = self._ema_due(it)
+        side = main = None
         if self.device.type == "cuda" and getattr(getattr(cfg, "AMD", None), "TEACHER_STREAM", True):
             main = torch.cuda.current_stream(self.device)
             if self._teacher_stream is None:
@@ -166,10 +188,19 @@ class CoinTrainer(BASE_Trainer):
             strong, weak = next(self._data_loader_iter)
             if ema_due:
                 self.update_teacher(cfg.CLOUD.EMA_KEEP_RATE_OFFLINE)
+            if hasattr(self.offline_teacher, "inference_begin"):
+                self._teacher_mode(False)
+                self.offline_teacher.inference_begin(weak, branch="test")
+                self._teacher_mode(True)
+        return strong, weak, side, main
+
+    def _fetch_end(self, begun):
+        strong, weak, side, main = begun
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             with torch.no_grad():
-                self.offline_teacher.eval()
-                offline_results = self.offline_teacher(weak, branch="test")
-                self.offline_teacher.train()
+                self._teacher_mode(False)
+                offline_results = self.offline_teacher(weak, branch="test")   # picks the begun pass up (same `weak` object)
+                self._teacher_mode(True)
                 targets = self.match_boxes(weak, offline_results, to_device=side is None)
         if side is not None:
             for d in strong:  # consumed by the main stream (after its wait_stream in run_step)
@@ -184,6 +215,7 @@ class CoinTrainer(BASE_Trainer):
         return [mv(t) for t in rcnn], [mv(t) for t in rpn]
 
     _pending = None
+    _early = None          # (strong, weak, streams) of iteration i+1 whose teacher pass was enqueued ahead of step i
     _teacher_stream = None
     reducer = reducer_merge = None  # coin_amd.parallel.GradReducer when world_size > 1
 
@@ -192,7 +224,11 @@ class CoinTrainer(BASE_Trainer):
         assert self.model.training, "[PTrainer] model was changed to eval mode!"
         burn = cfg.CLOUD.BURN_UP_STEP
         if self._pending is None:
-            strong, dual_teacher_instances = self._fetch()
+            if self._early is not None:   # a caller that does not use prepare_next(): finish the pass begun during the last step
+                early, self._early = self._early, None
+                strong, dual_teacher_instances = self._fetch_end(early)
+            else:
+                strong, dual_teacher_instances = self._fetch()
         else:
             strong, dual_teacher_instances = self._pending
             self._pending = None
@@ -201,6 +237,11 @@ class CoinTrainer(BASE_Trainer):
             # may overtake it.  By now its work is finished in practice (the host waited for the detections), so this costs nothing.
             torch.cuda.current_stream(self.device).wait_stream(self._teacher_stream)
             dual_teacher_instances = self._targets_to_device(dual_teacher_instances)
+        if (self._early is None and self.device.type == "cuda" and self.iter + 1 < self.max_iter
+                and not self._ema_due(self.iter + 1) and getattr(getattr(cfg, "AMD", None), "TEACHER_PREFETCH", True)):
+            # frozen teacher: issue the NEXT iteration's teacher pass now, ahead of this iteration's student step (see _fetch_begin);
+            # AFTER the wait above, so that the student's forward does not queue behind it.  It reads the teacher's weights only.
+            self._early = self._fetch_begin(self.iter + 1)
         start = cfg.CLOUD.PROTOTYPE_UPDATE_START
         update_prototype = start != -1 and self.iter >= start
         branch = "step_one" if self.iter < burn else "step_two"
@@ -245,7 +286,11 @@ class CoinTrainer(BASE_Trainer):
         `train()` AFTER `after_step()`, so a checkpoint written for iteration i holds the teacher as iteration i left it
         (the reference saves in after_step, before the next iteration's EMA: trainer.py:149-172)."""
         if self._pending is None and self.iter < self.max_iter:
-            self._pending = self._fetch()
+            if self._early is not None:
+                early, self._early = self._early, None
+                self._pending = self._fetch_end(early)
+            else:
+                self._pending = self._fetch()
 
     def resume_or_load(self, resume: bool = False):
         """trainer.py:220-262: ``MODEL.WEIGHTS`` = "offline_teacher.pth+cloud_results.pth" (start of adaptation) or one CoinTrainer
@@ -257,7 +302,7 @@ class CoinTrainer(BASE_Trainer):
             return
         assert not (resume and "+" in self.cfg.MODEL.WEIGHTS), "resume need only one model."
         load_cointrainer_weights(self, self.cfg.MODEL.WEIGHTS, resume=resume)
-        self._pending, self._ema = None, None
+        self._pending, self._ema, self._early = None, None, None
 
     def after_step(self):
         """trainer.py:149-157 + MyPeriodicCheckpointer (hooks.py:60-84): ``burn_up_<iter>.pth`` at the end of the burn-up phase,

@@ -41,7 +41,15 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+try:  # `torch.cuda.current_stream().cuda_stream` builds two Python objects per kernel launch (10 us; ~900 launches per targetDET step)
+    _raw_stream, _cur_dev = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+except AttributeError:  # pragma: no cover
+    _raw_stream = _cur_dev = None
+
+
 def _stream():
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(_cur_dev()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -206,9 +214,12 @@ def conv_gemm(a: torch.Tensor, w: torch.Tensor, spatial: Optional[Tuple[int, int
     wsb = _lib.lib().coin_conv_gemm_workspace_bytes(m, n, k)   # fp32 partial tiles of the split-K tail round (0: not needed for this shape)
     ws = None
     if wsb:
-        ws = _GEMM_WS.get(a.device)
-        if ws is None or ws.numel() < wsb:   # one buffer per device, grown to the largest request (calls on one stream are ordered)
-            ws = _GEMM_WS[a.device] = torch.empty(wsb, dtype=torch.uint8, device=a.device)
+        # one buffer per (device, stream), grown to the largest request: calls on one stream are ordered, but the EMA teacher's pass
+        # runs on its own stream beside the student's step and must not share the slabs with it
+        key = (a.device, _stream().value)
+        ws = _GEMM_WS.get(key)
+        if ws is None or ws.numel() < wsb:
+            ws = _GEMM_WS[key] = torch.empty(wsb, dtype=torch.uint8, device=a.device)
     with _timed("coin_conv_gemm_bf16", 2 * m * n * k):  # "bytes" slot carries FLOPs for the MFMA entry point
         check(_lib.lib().coin_conv_gemm_bf16_ws(_p(a), a.stride(0), mode, h, wd, cin, _p(w), w.stride(0), _p(out), out.stride(0),
                                                 _p(residual), residual.stride(0) if residual is not None else 0, m, n, k,
@@ -238,8 +249,8 @@ def conv_wgrad(gy: torch.Tensor, x: torch.Tensor, spatial: Optional[Tuple[int, i
     nbytes = _lib.lib().coin_conv_wgrad_workspace_bytes(m, cout, ktot)
     if nbytes == 0:
         raise CoinHipError("conv_wgrad: Cout and Cin must be multiples of 256")
-    key = (gy.device, nbytes)
-    ws = _WGRAD_WS.get(key)  # one slab buffer per size, reused (calls on one stream are ordered)
+    key = (gy.device, _stream().value, nbytes)
+    ws = _WGRAD_WS.get(key)  # one slab buffer per (stream, size), reused (calls on one stream are ordered)
     if ws is None:
         ws = _WGRAD_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=gy.device)
     dw = torch.empty((cout, ktot), dtype=torch.float32, device=gy.device)

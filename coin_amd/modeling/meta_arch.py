@@ -10,6 +10,7 @@ from __future__ import annotations
 from typing import Dict, List, Optional
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .. import kernels as K
@@ -191,9 +192,55 @@ class OpenVocabularyRCNN(nn.Module):
         losses.update(proposal_losses)
         return losses
 
+    # ------------------------------------------------------------------ inference in two halves (the EMA teacher's pass)
+    # `inference_begin` enqueues everything up to the per-image score filter with FIXED shapes and without a host round trip
+    # (packed RPN proposals: exactly POST_NMS_TOPK_TEST rows per image + a validity mask; rows without a proposal get probability
+    # 0 and never pass the score threshold); `inference` picks the begun pass up and runs the reference's per-image filter /
+    # class-wise NMS / top-k on it (fast_rcnn.py:116-175).  CoinTrainer issues the first half for batch i+1 BEFORE the student's
+    # step i whenever the teacher is not due for an EMA, so that the teacher's device work and read-back hide under that step.
+    _begun = None
+
+    def _static_inference_ok(self) -> bool:
+        return self.proposal_generator is not None and type(self.roi_heads).__name__ == "OpenVocabularyRes5ROIHeads" and self.pixel_mean.is_cuda
+
+    @torch.no_grad()
+    def inference_begin(self, batched_inputs, branch="test") -> bool:
+        assert (not self.training) or branch == "test"
+        if not self._static_inference_ok():
+            return False
+        images = self.preprocess_image(batched_inputs)
+        with self._autocast():
+            features = self.backbone(images.tensor)
+            packed, _ = self.proposal_generator(images, features, None, branch, packed=True)
+            n, p = packed.boxes.shape[:2]
+            bidx = torch.arange(n, device=packed.boxes.device, dtype=packed.boxes.dtype).repeat_interleave(p).unsqueeze(1)
+            rois = torch.cat([bidx, packed.boxes.reshape(-1, 4)], dim=1)
+            feats = self.roi_heads._pooled(features, rois, self.backbone.layer4, self.backbone.attnpool, fixed_shape=True)
+            scores, deltas = self.roi_heads.box_predictor(feats, branch=branch)
+        bp = self.roi_heads.box_predictor
+        boxes = bp.box2box_transform.apply_deltas(deltas.float(), rois[:, 1:])
+        probs = F.softmax(scores.float(), dim=-1) * packed.valid.reshape(-1, 1).to(torch.float32)
+        self._begun = (batched_inputs, boxes.view(n, p, -1), probs.view(n, p, -1), images.image_sizes)
+        return True
+
+    def _inference_finish(self, begun, do_postprocess=True):
+        from .fast_rcnn import fast_rcnn_inference_single_image
+
+        batched_inputs, boxes, probs, sizes = begun
+        bp = self.roi_heads.box_predictor
+        results = [fast_rcnn_inference_single_image(boxes[i], probs[i], tuple(sizes[i]), bp.test_score_thresh, bp.test_nms_thresh, bp.test_topk_per_image)[0]
+                   for i in range(len(batched_inputs))]
+        if not do_postprocess:
+            return results
+        return [{"instances": detector_postprocess(r, inp.get("height", size[0]), inp.get("width", size[1]))}
+                for r, inp, size in zip(results, batched_inputs, sizes)]
+
     @torch.no_grad()
     def inference(self, batched_inputs, branch=None, detected_instances=None, do_postprocess=True):
         assert (not self.training) or branch == "test"
+        begun, self._begun = self._begun, None
+        if begun is not None and begun[0] is batched_inputs:
+            return self._inference_finish(begun, do_postprocess)
         images = self.preprocess_image(batched_inputs)
         with self._autocast():
             features = self.backbone(images.tensor)

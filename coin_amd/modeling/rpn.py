@@ -119,7 +119,9 @@ class DualTeacherRPN(nn.Module):
             BG_TRAIN=cfg.CLOUD.BG_TRAIN)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, images: ImageList, features: Dict[str, torch.Tensor], gt_instances=None, branch=None):
+    def forward(self, images: ImageList, features: Dict[str, torch.Tensor], gt_instances=None, branch=None, packed: Optional[bool] = None):
+        """packed=True forces the fixed-shape proposal result (PackedProposals: no host round trip) also outside training: the
+        inference pass of the EMA teacher is issued without a sync (OpenVocabularyRCNN.inference_begin)."""
         feats = [features[f] for f in self.in_features]
         anchors = self.anchor_generator(feats)
         lg, dl = self.rpn_head(feats)
@@ -155,7 +157,8 @@ class DualTeacherRPN(nn.Module):
                 losses.update(self.losses(anchors, logits, dlabels, None, None, teacher_probs=teacher, only_distillation=True))
             else:
                 raise NotImplementedError
-        packed = self.training and ((self.sync_free and branch == "pre_train") or (self.sync_free_step and branch in ("step_one", "step_two")))
+        if packed is None:
+            packed = self.training and ((self.sync_free and branch == "pre_train") or (self.sync_free_step and branch in ("step_one", "step_two")))
         proposals = self.predict_proposals(anchors, logits, deltas, images.image_sizes, packed=packed)
         return proposals, losses
 

@@ -153,8 +153,7 @@ def _sample_labels(cls, keys, bg_label, num_samples, pos_cap):
     pos = (cls != -1) & (cls != bg_label)
     neg = cls == bg_label
     tier = torch.where(pos, 0.0, torch.where(neg, 2.0, 4.0)).double()
-    k24 = (keys.double() * 16777216.0).floor().clamp(0, 16777215)       # the kernel compares keys at torch.rand's 2^-24 resolution
-    order = (k24 + tier * 16777216.0).argsort(dim=1, stable=True)
+    order = (keys.double().clamp(0.0, 1.0) + tier).argsort(dim=1, stable=True)   # keys in [0, 1): the tiers (0 / 2 / 4) never mix
     rank = torch.empty_like(order)
     rank.scatter_(1, order, torch.arange(m).expand(n, m))
     cnt_pos = pos.sum(dim=1, keepdim=True)

@@ -766,6 +766,15 @@ def test_sample_labels_is_the_stable_sort_definition(K):
         assert torch.equal(out.cpu(), ref), [int((out[i].cpu() != ref[i]).sum()) for i in range(n)]
     out = K.sample_labels(dev(cls[:, :300].contiguous()), dev(keys[:, :300].contiguous()), 0, 64, 16)
     assert torch.equal(out.cpu(), _sample_labels(cls[:, :300], keys[:, :300], 0, 64, 16))
+    # keys finer than 2^-24 (what the DEVICE generator's torch.rand draws below 0.5): distinct floats that share a 24-bit radix bin
+    # must still be taken in key order, not index order
+    fine = torch.randperm(m, generator=g).float() * 2.0 ** -30          # 64 distinct keys per 2^-24 bin, shuffled over the indices
+    keys2 = torch.stack([fine, fine.flip(0), (fine * 3.0).clamp(max=0.99)])
+    cls2 = torch.randint(-1, 3, (3, m), generator=g)
+    for quota, cap in ((256, 128), (1000, 37), (64, 63)):
+        out = K.sample_labels(dev(cls2), dev(keys2), 0, quota, cap)
+        ref = _sample_labels(cls2, keys2, 0, quota, cap)
+        assert torch.equal(out.cpu(), ref), (quota, cap, [int((out[i].cpu() != ref[i]).sum()) for i in range(3)])
 
 
 # ------------------------------------------------------------------------------------------ NMS

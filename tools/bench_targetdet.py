@@ -16,18 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--images", type=int, default=2)
-    ap.add_argument("--step-two", action="store_true")
-    ap.add_argument("--config", default="foggy", choices=["foggy", "bdd100k_rn101", "swint_fpn", "rn101_fpn"],
-                    help="swint_fpn / rn101_fpn: the FPN extension (configs/coin/FPN, no counterpart in the reference)")
-    ap.add_argument("--sync-free-step", action="store_true", help="(default since round 2) cfg.AMD.SYNC_FREE_STEP: fixed-shape samplers + packed losses")
-    ap.add_argument("--reference-samplers", action="store_true", help="cfg.AMD.SYNC_FREE_STEP off: the reference-shaped nonzero / randperm samplers")
-    ap.add_argument("--no-teacher-stream", action="store_true", help="cfg.AMD.TEACHER_STREAM off: teacher pass on the main stream (A/B measurement)")
-    args = ap.parse_args()
+def build_trainer(config: str, images: int, step_two: bool, reference_samplers: bool = False, teacher_stream: bool = True, extra=()):
+    """CoinTrainer of one of the synthetic targetDET configs; the (random-init) teacher's detections are replaced by CLIPDET-like ones
+    AFTER its real inference pass has run, so that the A / B / C sets are populated."""
     import torch
 
     from coin_amd.config import get_cfg
@@ -38,10 +29,10 @@ def main():
     cfg = get_cfg()
     files = {"foggy": ("GDINO", "foggy_synthetic.yaml"), "bdd100k_rn101": ("GDINO", "bdd100k_rn101_synthetic.yaml"),
              "swint_fpn": ("FPN", "targetdet_swint_fpn_synthetic.yaml"), "rn101_fpn": ("FPN", "targetdet_rn101_fpn_synthetic.yaml")}
-    cfg.merge_from_file(os.path.join(ROOT, "configs", "coin", *files[args.config]))
-    cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", args.images, "AMD.SYNTHETIC.NUM_IMAGES", args.images, "AMD.TEXT_TEMPLATES", 4,
-                         "MODEL.DEVICE", "cuda:0", "CLOUD.BURN_UP_STEP", 0 if args.step_two else 10 ** 9, "CLOUD.PROTOTYPE_UPDATE_START", 0,
-                         "AMD.SYNC_FREE_STEP", not args.reference_samplers, "AMD.TEACHER_STREAM", not args.no_teacher_stream])
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "coin", *files[config]))
+    cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", images, "AMD.SYNTHETIC.NUM_IMAGES", images, "AMD.TEXT_TEMPLATES", 4,
+                         "MODEL.DEVICE", "cuda:0", "CLOUD.BURN_UP_STEP", 0 if step_two else 10 ** 9, "CLOUD.PROTOTYPE_UPDATE_START", 0,
+                         "AMD.SYNC_FREE_STEP", not reference_samplers, "AMD.TEACHER_STREAM", teacher_stream] + list(extra))
     torch.manual_seed(cfg.SEED)
     tr = CoinTrainer(cfg)
     real_forward, g = tr.offline_teacher.forward, torch.Generator().manual_seed(7)
@@ -52,6 +43,26 @@ def main():
 
     tr.offline_teacher.forward = teacher
     tr.max_iter = 10 ** 9
+    return tr
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--images", type=int, default=2)
+    ap.add_argument("--step-two", action="store_true")
+    ap.add_argument("--config", default="foggy", choices=["foggy", "bdd100k_rn101", "swint_fpn", "rn101_fpn"],
+                    help="swint_fpn / rn101_fpn: the FPN extension (configs/coin/FPN, no counterpart in the reference)")
+    ap.add_argument("--sync-free-step", action="store_true", help="(default since round 2) cfg.AMD.SYNC_FREE_STEP: fixed-shape samplers + packed losses")
+    ap.add_argument("--reference-samplers", action="store_true", help="cfg.AMD.SYNC_FREE_STEP off: the reference-shaped nonzero / randperm samplers")
+    ap.add_argument("--no-prefetch", action="store_true", help="cfg.AMD.TEACHER_PREFETCH off: the frozen teacher's pass follows the student's step (A/B measurement)")
+    ap.add_argument("--no-teacher-stream", action="store_true", help="cfg.AMD.TEACHER_STREAM off: teacher pass on the main stream (A/B measurement)")
+    args = ap.parse_args()
+    import torch
+
+    tr = build_trainer(args.config, args.images, args.step_two, reference_samplers=args.reference_samplers, teacher_stream=not args.no_teacher_stream,
+                       extra=["AMD.TEACHER_PREFETCH", not args.no_prefetch])
     for _ in range(args.warmup):
         tr.run_step()
         tr.prepare_next()   # as CoinTrainer.train(): the next iteration's teacher pass / matching overlaps this backward
@@ -74,7 +85,7 @@ def main():
     dt = (time.perf_counter() - t0) / args.steps
     in_order = [round(g, 1) for g in groups]
     groups.sort()
-    print(json.dumps({"config": args.config, "workload": "targetDET " + ("step_two" if args.step_two else "step_one") + (" (reference-shaped samplers)" if args.reference_samplers else "") + (" (teacher on the main stream)" if args.no_teacher_stream else ""), "images_per_step": args.images, "ms_per_step": dt * 1e3, "median_group_ms_per_step": groups[len(groups) // 2], "fastest_group_ms_per_step": groups[0], "groups_ms_per_step_in_order": in_order,
+    print(json.dumps({"config": args.config, "workload": "targetDET " + ("step_two" if args.step_two else "step_one") + (" (reference-shaped samplers)" if args.reference_samplers else "") + (" (teacher on the main stream)" if args.no_teacher_stream else "") + (" (no teacher prefetch)" if args.no_prefetch else ""), "images_per_step": args.images, "ms_per_step": dt * 1e3, "median_group_ms_per_step": groups[len(groups) // 2], "fastest_group_ms_per_step": groups[0], "groups_ms_per_step_in_order": in_order,
                       "student_views_per_s": args.images / dt, "losses": {k: round(float(v), 4) for k, v in rec.items()}}))
 
 
