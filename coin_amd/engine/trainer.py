@@ -174,7 +174,14 @@ class CoinTrainer(BASE_Trainer):
         cfg = self.cfg
         ema_due = self._ema_due(it)
         side = main = None
-        if self.device.type == "cuda" and getattr(getattr(cfg, "AMD", None), "TEACHER_STREAM", True):
+        amd = getattr(cfg, "AMD", None)
+        # An EMA-due pass has to follow the optimizer step on the device whatever stream it is on (the EMA reads the new weights), so it
+        # loses nothing on the default stream -- and from there its fixed-shape half can be replayed as ONE HIP graph (graph replay
+        # from a side stream serialises the device on this runtime).
+        use_graph = (ema_due and self.device.type == "cuda" and getattr(amd, "TEACHER_GRAPH", True) and os.environ.get("COIN_TEACHER_GRAPH", "1") != "0"
+                     and hasattr(self.offline_teacher, "inference_begin") and not getattr(self.offline_teacher, "graph_failed", False)
+                     and self.offline_teacher._static_inference_ok())
+        if self.device.type == "cuda" and getattr(amd, "TEACHER_STREAM", True) and not use_graph:
             main = torch.cuda.current_stream(self.device)
             if self._teacher_stream is None:
                 self._teacher_stream = torch.cuda.Stream(device=self.device)
@@ -190,7 +197,10 @@ class CoinTrainer(BASE_Trainer):
                 self.update_teacher(cfg.CLOUD.EMA_KEEP_RATE_OFFLINE)
             if hasattr(self.offline_teacher, "inference_begin"):
                 self._teacher_mode(False)
-                self.offline_teacher.inference_begin(weak, branch="test")
+                if use_graph:
+                    self.offline_teacher.inference_begin(weak, branch="test", graph=True)
+                else:
+                    self.offline_teacher.inference_begin(weak, branch="test")
                 self._teacher_mode(True)
         return strong, weak, side, main
 

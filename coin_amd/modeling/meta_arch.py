@@ -203,14 +203,12 @@ class OpenVocabularyRCNN(nn.Module):
     def _static_inference_ok(self) -> bool:
         return self.proposal_generator is not None and type(self.roi_heads).__name__ == "OpenVocabularyRes5ROIHeads" and self.pixel_mean.is_cuda
 
-    @torch.no_grad()
-    def inference_begin(self, batched_inputs, branch="test") -> bool:
-        assert (not self.training) or branch == "test"
-        if not self._static_inference_ok():
-            return False
-        images = self.preprocess_image(batched_inputs)
+    def _inference_core(self, x, image_sizes, branch="test"):
+        """Device-only, fixed-shape part of the inference pass: x = the normalised / padded batch (logical NCHW, channels-last bytes)
+        -> (boxes [N, P, 4k], probabilities [N, P, K+1] with zero rows where the RPN kept fewer than P proposals)."""
+        images = ImageList(x, image_sizes)
         with self._autocast():
-            features = self.backbone(images.tensor)
+            features = self.backbone(x)
             packed, _ = self.proposal_generator(images, features, None, branch, packed=True)
             n, p = packed.boxes.shape[:2]
             bidx = torch.arange(n, device=packed.boxes.device, dtype=packed.boxes.dtype).repeat_interleave(p).unsqueeze(1)
@@ -220,8 +218,70 @@ class OpenVocabularyRCNN(nn.Module):
         bp = self.roi_heads.box_predictor
         boxes = bp.box2box_transform.apply_deltas(deltas.float(), rois[:, 1:])
         probs = F.softmax(scores.float(), dim=-1) * packed.valid.reshape(-1, 1).to(torch.float32)
-        self._begun = (batched_inputs, boxes.view(n, p, -1), probs.view(n, p, -1), images.image_sizes)
+        return boxes.view(n, p, -1), probs.view(n, p, -1)
+
+    # The fixed-shape half as ONE HIP graph (cfg.AMD.TEACHER_GRAPH; CoinTrainer uses it for the EMA-due iterations, whose teacher
+    # pass follows the optimizer step on the device anyway and can therefore be replayed from the default stream): ~900 launches
+    # of the frozen teacher -> one graph launch.  The graph re-reads the weights in place (the EMA kernel writes through the same
+    # storage); the refresh of the bf16 weight shadows and the prompt transformer are captured INSIDE the graph (both are marked stale
+    # before the capture), so a replay after an EMA sees the new weights without a host-side walk over the parameters.
+    _graphs = None
+    _graph_seen = None
+    graph_failed = False
+
+    @torch.no_grad()
+    def inference_begin(self, batched_inputs, branch="test", graph: bool = False) -> bool:
+        assert (not self.training) or branch == "test"
+        if not self._static_inference_ok():
+            return False
+        images = self.preprocess_image(batched_inputs)
+        sizes = tuple(tuple(int(v) for v in s) for s in images.image_sizes)
+        if graph and not self.graph_failed and not torch.cuda.is_current_stream_capturing():
+            out = self._graph_replay(images.tensor, sizes, branch)
+            if out is not None:
+                self._begun = (batched_inputs, out[0], out[1], images.image_sizes)
+                return True
+        boxes, probs = self._inference_core(images.tensor, images.image_sizes, branch)
+        self._begun = (batched_inputs, boxes, probs, images.image_sizes)
         return True
+
+    def _graph_replay(self, x, sizes, branch):
+        key = (tuple(x.shape), tuple(x.stride()), x.dtype, sizes, branch)
+        if self._graphs is None:
+            self._graphs, self._graph_seen = {}, {}
+        ent = self._graphs.get(key)
+        if ent is None:
+            n = self._graph_seen.get(key, 0) + 1
+            self._graph_seen[key] = n
+            if n < 3 or len(self._graphs) >= 4:   # capture only shapes that repeat (real data: a few resized sizes), at most four
+                return None
+            try:
+                ent = self._graph_capture(x, sizes, branch)
+            except Exception as e:  # same kernels either way: eager launches
+                import warnings
+
+                warnings.warn(f"teacher inference: HIP graph capture failed ({type(e).__name__}: {e}); running it eagerly")
+                self.graph_failed = True
+                return None
+            self._graphs[key] = ent
+        static_in, g, boxes, probs = ent
+        static_in.copy_(x)
+        g.replay()
+        return boxes, probs
+
+    def _graph_capture(self, x, sizes, branch):
+        static_in = x.clone()
+        for _ in range(2):   # library solver searches, workspaces, anchor / size caches: everything that allocates or syncs happens here
+            self._inference_core(static_in, sizes, branch)
+        torch.cuda.synchronize()
+        L.invalidate_shadows(list(self.parameters()))     # -> the bf16 shadow refreshes are captured: every replay re-derives them
+        for m in self.modules():
+            if hasattr(m, "invalidate_text_cache"):
+                m.invalidate_text_cache()                 # -> the prompt transformer is captured: every replay re-encodes the classes
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):   # loader threads may touch the device meanwhile
+            boxes, probs = self._inference_core(static_in, sizes, branch)
+        return static_in, g, boxes, probs
 
     def _inference_finish(self, begun, do_postprocess=True):
         from .fast_rcnn import fast_rcnn_inference_single_image

@@ -336,7 +336,8 @@ def cointrainer_two_iterations_through_constructor(device, tol=1e-5, teacher_str
     cfg = get_cfg()
     cfg.merge_from_file(root)
     cfg.merge_from_list([
-        "MODEL.DEVICE", str(device), "AMD.COMPUTE_DTYPE", "fp32", "AMD.TEACHER_STREAM", bool(teacher_stream), "AMD.SYNC_FREE", False, "AMD.SYNC_FREE_STEP", False,
+        "MODEL.DEVICE", str(device), "AMD.COMPUTE_DTYPE", "fp32", "AMD.TEACHER_STREAM", bool(teacher_stream), "AMD.TEACHER_GRAPH", not teacher_stream,
+        "AMD.SYNC_FREE", False, "AMD.SYNC_FREE_STEP", False,
         "AMD.CLASS_NAMES", ["car", "person", "bus"], "AMD.TEXT_TEMPLATES", 2, "DATASETS.TRAIN_UNLABEL", ("foggytrain_0.02",),
         "AMD.ARCH.LAYERS", [1, 1, 2, 2], "AMD.ARCH.WIDTH", 8, "AMD.ARCH.TEXT_WIDTH", 32, "AMD.ARCH.TEXT_LAYERS", 2, "AMD.ARCH.TEXT_HEADS", 2,
         "AMD.ARCH.TEXT_DIM", 32, "AMD.ARCH.CONTEXT_LENGTH", 16, "AMD.ARCH.VOCAB_SIZE", 64, "MODEL.MERGE_DIM", 32, "MODEL.BACKBONE.FREEZE_AT", 2,
