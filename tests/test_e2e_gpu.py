@@ -326,3 +326,55 @@ def test_cointrainer_constructor_teacher_stream_equals_the_synchronous_run_over_
         assert set(la) == set(lb)
         for k in la:
             assert abs(la[k] - lb[k]) <= 5e-3 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
+
+
+def test_cointrainer_teacher_prefetch_equals_the_unprefetched_run_in_step_one():
+    """step_one (iter < BURN_UP_STEP: the teacher is frozen, trainer.py:170-172): with `AMD.TEACHER_PREFETCH` the teacher pass of batch
+    i+1 is enqueued BEFORE the student's step i (first half, fixed shapes, no host round trip) and read back after it; without it the
+    pass follows the step.  Same weights, same batches in the same order -> the same (A, B, C) targets reach the student and the
+    losses agree to the run-to-run spread of the library convolutions; also with a caller that never calls prepare_next()."""
+    import os
+    import random
+
+    from coin_amd.config import get_cfg
+    from coin_amd.engine import CoinTrainer
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "coin", "GDINO", "foggy_synthetic.yaml")
+
+    def run(prefetch: bool, use_prepare_next: bool = True):
+        cfg = get_cfg()
+        cfg.merge_from_file(root)
+        cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", 2, "AMD.SYNTHETIC.NUM_IMAGES", 4, "AMD.SYNTHETIC.HEIGHT", 256, "AMD.SYNTHETIC.WIDTH", 384,
+                             "AMD.TEXT_TEMPLATES", 2, "MODEL.DEVICE", "cuda:0", "AMD.COMPUTE_DTYPE", "fp32", "CLOUD.BURN_UP_STEP", 10 ** 6,
+                             "CLOUD.PROTOTYPE_UPDATE_START", 0, "AMD.TEACHER_PREFETCH", prefetch, "SEED", 7])
+        torch.manual_seed(7)
+        np.random.seed(7)
+        random.seed(7)
+        tr = CoinTrainer(cfg)
+        tr.max_iter = 10
+        seen, match = [], tr.match_boxes
+        cnt = lambda x: 0 if x is None else len(x)
+        tr.match_boxes = lambda b, o, **kw: (lambda t: (seen.append([[cnt(x[0]), cnt(x[1]), cnt(x[2])] for x in t[0]]), t)[1])(match(b, o, **kw))
+        begun = []
+        begin = tr.offline_teacher.inference_begin
+        tr.offline_teacher.inference_begin = lambda *a, **k: (begun.append(tr.iter), begin(*a, **k))[1]
+        losses = []
+        for _ in range(4):
+            rec = tr.run_step()
+            if use_prepare_next:
+                tr.prepare_next()
+            torch.cuda.synchronize()
+            losses.append({k: float(v) for k, v in rec.items()})
+        return seen, losses, begun
+
+    seen_a, loss_a, begun_a = run(True)
+    seen_b, loss_b, begun_b = run(False)
+    seen_c, loss_c, _ = run(True, use_prepare_next=False)
+    # with the prefetch the first half of batch i+1 is issued while `tr.iter` is still i (before the step), without it after the step
+    assert begun_a[1:4] == [0, 1, 2] and begun_b[1:4] == [1, 2, 3], (begun_a, begun_b)
+    assert seen_a[:4] == seen_b[:4] == seen_c[:4], (seen_a, seen_b, seen_c)
+    for la, lb, lc in zip(loss_a, loss_b, loss_c):
+        assert set(la) == set(lb) == set(lc)
+        for k in la:
+            assert abs(la[k] - lb[k]) <= 5e-3 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
+            assert abs(lc[k] - lb[k]) <= 5e-3 * max(1.0, abs(lb[k])), (k, lc[k], lb[k])
