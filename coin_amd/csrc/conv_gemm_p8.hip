@@ -221,24 +221,40 @@ __device__ __forceinline__ void p8_epilogue(const P8Args& p, f32x4 (&acc)[2][2][
           s1[i] = s2[i] = 0.f;
         }
       }
+      // the four rows of this thread: R rows requested first (they queue behind nothing but the previous pass's stores), then the four
+      // image reads back to back, then add / store / statistics -- one LDS latency and one memory latency per pass instead of four
+      bf16x8 v[4], rr[4];
+      const bool has_r = p.R != nullptr;
+      if (has_r) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int grow = m0 + ah * 128 + q * 32 + rsub;
+          grow = grow < p.M ? grow : p.M - 1;
+          rr[q] = *reinterpret_cast<const bf16x8*>(p.R + (size_t)grow * p.ldr + gcol);
+        }
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = q * 32 + rsub;
-        const int grow = m0 + ah * 128 + row;
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(img + row * 256 + ((chunk ^ (row & 15)) << 4));
-        if (p.R != nullptr && grow < p.M) {  // C = bf16(bf16(A.B^T) + R): what two separate launches would store
-          const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.R + (size_t)grow * p.ldr + gcol);
+        v[q] = *reinterpret_cast<const bf16x8*>(img + row * 256 + ((chunk ^ (row & 15)) << 4));
+      }
+      if (has_r) {  // C = bf16(bf16(A.B^T) + R): what two separate launches would store
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = (bf16_t)((float)v[i] + (float)r[i]);
-        }
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[q][i] = (bf16_t)((float)v[q][i] + (float)rr[q][i]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int grow = m0 + ah * 128 + q * 32 + rsub;
         if (grow < p.M) {
-          if (p.dbg & 16) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p.C + (size_t)grow * p.ldc + gcol));
-          else *reinterpret_cast<bf16x8*>(p.C + (size_t)grow * p.ldc + gcol) = v;
+          if (p.dbg & 16) __builtin_nontemporal_store(v[q], reinterpret_cast<bf16x8*>(p.C + (size_t)grow * p.ldc + gcol));
+          else *reinterpret_cast<bf16x8*>(p.C + (size_t)grow * p.ldc + gcol) = v[q];
         }
         if (STATS && (long long)grow < p.stats_rows) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            const float d = (float)v[i] - piv[i];
+            const float d = (float)v[q][i] - piv[i];
             s1[i] += d;
             s2[i] += d * d;
           }
