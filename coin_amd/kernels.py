@@ -58,8 +58,18 @@ _TIMING = None
 
 
 def timing_begin(names: Sequence[str]) -> None:
-    global _TIMING
+    global _TIMING, _PAUSED
     _TIMING = {n: [] for n in names}
+    _PAUSED = False
+
+
+def timing_pause() -> None:
+    """Stop recording (what was recorded stays for timing_end): a long run must not keep creating two events per launch."""
+    global _PAUSED
+    _PAUSED = True
+
+
+_PAUSED = False
 
 
 def timing_end() -> dict:
@@ -76,7 +86,7 @@ def timing_end() -> dict:
 
 class _timed:
     def __init__(self, name: str, alg_bytes: int = 0):
-        self.on = _TIMING is not None and name in _TIMING
+        self.on = _TIMING is not None and not _PAUSED and name in _TIMING
         self.name, self.bytes = name, alg_bytes
 
     def __enter__(self):
