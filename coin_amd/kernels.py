@@ -753,9 +753,10 @@ class EmaTable:
                 raise CoinHipError("EMA needs dense float32 tensors with identical layout (contiguous or channels_last)")
             host[i].teacher, host[i].student, host[i].numel = t.data_ptr(), s.data_ptr(), t.numel()
         self._keep = (list(teacher), list(student))
+        self._teacher_ptrs = frozenset(t.data_ptr() for t in teacher)
         self._dev = torch.frombuffer(memoryview(host).cast("B"), dtype=torch.uint8).to(teacher[0].device) if self.n else None
 
     def update(self, keep: float):
         check(_lib.lib().coin_ema_update(_p(self._dev), self.n, self.max_numel, float(keep), _stream()), "coin_ema_update")
         from . import layers  # late import (layers imports this module): the teacher's bf16 weight shadows are now stale
-        layers.invalidate_shadows(self._keep[0])
+        layers.invalidate_storage(self._teacher_ptrs)   # by storage: the table's tensors are state_dict() aliases, not the Parameters

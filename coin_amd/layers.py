@@ -67,6 +67,21 @@ def invalidate_shadows(params: Sequence[torch.Tensor]) -> None:
             e.version = -1
 
 
+def invalidate_storage(ptrs) -> None:
+    """Everything derived from the storages at `ptrs` (a set of data_ptr()s) is stale: bf16 weight shadows and the frozen-norm
+    constants.  For writers that only know raw pointers -- `EmaTable` is built from `state_dict()` tensors, which are detached
+    aliases of the Parameters (another id(), the same storage), and its kernel bumps no `_version` (round-3 ADVICE, high)."""
+    for e in _SHADOWS.values():
+        if e.ptr in ptrs:
+            e.version = -1
+    for cache in _DERIVED_CACHES:   # entries are (key, ...) with key = ((data_ptr, _version), ..., [dtype])
+        for k in [k for k, hit in cache.items() if any(isinstance(it, tuple) and it[0] in ptrs for it in hit[0])]:
+            cache.pop(k, None)
+
+
+_DERIVED_CACHES: list = []   # per-module constants derived from parameters / buffers, keyed by (data_ptr, _version) tuples
+
+
 class _ShadowCast(Function):
     @staticmethod
     def forward(ctx, param, shadow):
@@ -431,6 +446,7 @@ def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm2d, relu: bool, residual: Opti
 
 
 _FROZEN_CONSTS: dict = {}
+_DERIVED_CACHES.append(_FROZEN_CONSTS)
 
 
 def frozen_bn_fusable(x: torch.Tensor, channels: int) -> bool:

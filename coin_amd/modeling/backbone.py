@@ -84,6 +84,7 @@ def _conv_bn(x, conv: nn.Conv2d, bn: nn.Module, relu: bool, residual=None, pool:
 
 
 _FOLDED: dict = {}
+L._DERIVED_CACHES.append(_FOLDED)   # dropped by L.invalidate_storage when the EMA kernel rewrites a source tensor in place
 
 
 def _folded(conv: nn.Conv2d, bn: "FrozenBatchNorm2d", dtype: torch.dtype):

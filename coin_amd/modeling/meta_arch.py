@@ -262,6 +262,9 @@ class OpenVocabularyRCNN(nn.Module):
 
                 warnings.warn(f"teacher inference: HIP graph capture failed ({type(e).__name__}: {e}); running it eagerly")
                 self.graph_failed = True
+                # the aborted capture RECORDED the shadow refreshes and the text encoding without running them, yet marked them
+                # fresh (and the cached text features live in the dead graph's pool): stale again before the eager pass reads them
+                self._invalidate_derived()
                 return None
             self._graphs[key] = ent
         static_in, g, boxes, probs = ent
@@ -269,15 +272,20 @@ class OpenVocabularyRCNN(nn.Module):
         g.replay()
         return boxes, probs
 
+    def _invalidate_derived(self):
+        """bf16 weight shadows, frozen-norm constants and cached text features of this model are stale."""
+        L.invalidate_storage({t.data_ptr() for t in list(self.parameters()) + list(self.buffers())})
+        L.invalidate_shadows(list(self.parameters()))
+        for m in self.modules():
+            if hasattr(m, "invalidate_text_cache"):
+                m.invalidate_text_cache()
+
     def _graph_capture(self, x, sizes, branch):
         static_in = x.clone()
         for _ in range(2):   # library solver searches, workspaces, anchor / size caches: everything that allocates or syncs happens here
             self._inference_core(static_in, sizes, branch)
         torch.cuda.synchronize()
-        L.invalidate_shadows(list(self.parameters()))     # -> the bf16 shadow refreshes are captured: every replay re-derives them
-        for m in self.modules():
-            if hasattr(m, "invalidate_text_cache"):
-                m.invalidate_text_cache()                 # -> the prompt transformer is captured: every replay re-encodes the classes
+        self._invalidate_derived()   # -> shadow refreshes + prompt transformer are captured: every replay re-derives them
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):   # loader threads may touch the device meanwhile
             boxes, probs = self._inference_core(static_in, sizes, branch)

@@ -378,3 +378,69 @@ def test_cointrainer_teacher_prefetch_equals_the_unprefetched_run_in_step_one():
         for k in la:
             assert abs(la[k] - lb[k]) <= 5e-3 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
             assert abs(lc[k] - lb[k]) <= 5e-3 * max(1.0, abs(lb[k])), (k, lc[k], lb[k])
+
+
+def test_teacher_bf16_shadows_and_frozen_constants_follow_the_ema_kernel():
+    """Round-3 ADVICE (high): `coin_ema_update` writes the teacher's fp32 masters through raw pointers taken from `state_dict()`
+    tensors (detached aliases: another id(), no `_version` bump), so everything DERIVED from them -- bf16 weight shadows, folded
+    frozen convolutions, frozen-norm constants -- has to be marked stale by storage, or every eager bf16 teacher pass after an EMA
+    reads the pre-EMA weights (ts_ensemble.py:39-69, trainer.py:170-177).  bf16 trainer, TEACHER_GRAPH off (the eager pass is the one
+    at risk): after an EMA with a student that differs strongly from the teacher, every bf16 shadow of the teacher must equal a fresh
+    cast of its master, and the eager teacher pass must equal the pass of the same model after ALL derived state was dropped."""
+    import os
+    import random
+
+    from coin_amd import layers as L
+    from coin_amd.config import get_cfg
+    from coin_amd.engine import CoinTrainer
+    from coin_amd.modeling import backbone as B
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "coin", "GDINO", "foggy_synthetic.yaml")
+    cfg = get_cfg()
+    cfg.merge_from_file(root)
+    cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", 2, "AMD.SYNTHETIC.NUM_IMAGES", 2, "AMD.SYNTHETIC.HEIGHT", 256, "AMD.SYNTHETIC.WIDTH", 384,
+                         "AMD.TEXT_TEMPLATES", 2, "MODEL.DEVICE", "cuda:0", "AMD.COMPUTE_DTYPE", "bf16", "CLOUD.BURN_UP_STEP", 0,
+                         "CLOUD.OFFLINE_TEACHER_UPDATE_ITER", 1, "CLOUD.EMA_KEEP_RATE_OFFLINE", 0.5, "AMD.TEACHER_STREAM", False,
+                         "AMD.TEACHER_GRAPH", False, "AMD.TEACHER_PREFETCH", False, "SEED", 11])
+    torch.manual_seed(11)
+    np.random.seed(11)
+    random.seed(11)
+    tr = CoinTrainer(cfg)
+    teacher = tr.offline_teacher
+    _strong, weak = next(tr._data_loader_iter)
+
+    def detect():
+        tr._teacher_mode(False)
+        try:
+            with torch.no_grad():
+                out = teacher(weak, branch="test")   # (the model opens its own bf16 autocast region, AMD.COMPUTE_DTYPE)
+        finally:
+            tr._teacher_mode(True)
+        return [(o["instances"].pred_boxes.tensor.float().cpu(), o["instances"].scores.float().cpu()) for o in out]
+
+    detect()   # builds every shadow / folded weight / frozen constant of the teacher from the PRE-EMA weights
+    n_shadows = sum(1 for p in teacher.parameters() if L.shadow_of(p) is not None)
+    assert n_shadows > 20, "the teacher pass did not run on bf16 shadows: the test would prove nothing"
+    with torch.no_grad():
+        for p in tr.model.parameters():   # a student far from the teacher, so that a stale read is visible
+            p.mul_(1.0 + 0.5 * torch.rand_like(p))
+        for m in tr.model.modules():
+            if hasattr(m, "running_var") and m.running_var is not None:
+                m.running_var.mul_(1.7)
+                m.running_mean.add_(0.05)
+    tr.update_teacher(0.5)
+    got = detect()
+    stale = [n for n, p in teacher.named_parameters() if L.shadow_of(p) is not None and not torch.equal(L.shadow_of(p), p.detach().to(L.shadow_of(p).dtype))]
+    assert not stale, f"bf16 shadows still hold the pre-EMA weights: {stale[:5]} (+{max(0, len(stale) - 5)})"
+    # reference: drop ALL derived state by hand, run again
+    L._SHADOWS.clear()
+    L._FROZEN_CONSTS.clear()
+    B._FOLDED.clear()
+    for m in teacher.modules():
+        if hasattr(m, "invalidate_text_cache"):
+            m.invalidate_text_cache()
+    want = detect()
+    for (gb, gs), (wb, ws) in zip(got, want):
+        assert gb.shape == wb.shape, (gb.shape, wb.shape)
+        torch.testing.assert_close(gs, ws, rtol=0, atol=2e-3)
+        torch.testing.assert_close(gb, wb, rtol=0, atol=0.5)
