@@ -211,9 +211,25 @@ def self_launch(args, argv) -> int:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = [subprocess.Popen(child_argv(argv), env=child_env(r, args.gpus, port), cwd=ROOT) for r in range(args.gpus)]
-    rc = 0
-    for pr in procs:
-        rc = max(rc, abs(pr.wait()))
+    # poll: a rank that dies (import error, out of memory) leaves its siblings blocked in the rendezvous / an all-reduce until the
+    # process-group timeout -- end them (they are this process's own children) and report the first failure instead
+    rc, live = 0, list(procs)
+    while live and rc == 0:
+        time.sleep(0.2)
+        for pr in list(live):
+            code = pr.poll()
+            if code is not None:
+                live.remove(pr)
+                if code != 0:
+                    rc = abs(code)
+    for pr in live:
+        pr.terminate()
+    for pr in live:
+        try:
+            pr.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            pr.wait()
     return rc
 
 
@@ -277,15 +293,19 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     ktimes = K.timing_end()
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+    loss = float(sum(rec.values()))
+    per_rank = [[dt, loss]]
+    if world > 1:   # every rank's wall time and final loss: the line reports the slowest rank (value) and the spread (stragglers)
+        mine = torch.tensor([dt, loss], device="cuda", dtype=torch.float64)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[float(a[0]), float(a[1])] for a in allr]
+        dt = max(t for t, _ in per_rank)
     views_per_step = IMAGES_PER_GPU * VIEWS_PER_IMAGE * world
     value = views_per_step * args.steps / dt
-    loss = float(sum(rec.values()))
-    if not (loss == loss and abs(loss) < 1e6):
-        raise SystemExit(f"bench.py: the training loss is not finite ({loss}) after {args.warmup + args.steps} steps: the run is invalid")
+    for r, (_t, lr_) in enumerate(per_rank):
+        if not (lr_ == lr_ and abs(lr_) < 1e6):
+            raise SystemExit(f"bench.py: the training loss of rank {r} is not finite ({lr_}) after {args.warmup + args.steps} steps: the run is invalid")
 
     if rank == 0:
         # dominant hand-written kernel by total time inside the timed region
@@ -322,6 +342,8 @@ def main():
                                    "images x (strong+weak) = 4 views, real RPN + sampler, 512 RoIs/view, 8 classes, 32 cached teacher "
                                    "boxes/image, random-init weights, SGD",
                        "views_per_gpu_per_step": IMAGES_PER_GPU * VIEWS_PER_IMAGE, "parallelism": f"dp{world}", "final_loss": loss,
+                       "rank_ms_per_step": {"min": min(t for t, _ in per_rank) / args.steps * 1e3, "max": max(t for t, _ in per_rank) / args.steps * 1e3},
+                       "rank_final_loss": [l for _, l in per_rank],
                        "end_to_end_mfma_frac": value / world * FLOP_PER_VIEW / (MFMA_BF16_PEAK_TFLOPS * 1e12)},
             "roofline": roofline, "kernels": detail,
         }

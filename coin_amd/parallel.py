@@ -171,5 +171,19 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> N
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
     with torch.no_grad():
+        # one collective per dtype instead of one per tensor (~600 tiny broadcasts for the detector: each is a full ring hop over xGMI):
+        # pack -> broadcast -> unpack.  Duplicated (tied) tensors are sent once.
+        seen, by_dtype = set(), {}
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src=src, group=group)
+            if id(t) in seen:
+                continue
+            seen.add(id(t))
+            by_dtype.setdefault(t.dtype, []).append(t.data)
+        for dtype, tensors in by_dtype.items():
+            flat = torch.cat([t.reshape(-1) for t in tensors]) if len(tensors) > 1 else tensors[0].reshape(-1).clone()
+            dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for t in tensors:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view(t.shape))   # logical order on both sides: any memory format
+                off += n

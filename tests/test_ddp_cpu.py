@@ -72,7 +72,7 @@ def test_two_rank_gloo_training_keeps_parameters_in_sync(tmp_path):
     assert a["loss"] != b["loss"]  # each rank trained on its own shard
 
 
-def _coin_worker(rank, world, port, out_dir):
+def _coin_worker(rank, world, port, out_dir, b_ranks=None):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -86,12 +86,13 @@ def _coin_worker(rank, world, port, out_dir):
     cfg = get_cfg()
     cfg.merge_from_file(os.path.join(HERE, "..", "configs", "coin", "GDINO", "foggy_synthetic.yaml"))
     cfg.merge_from_list(["MODEL.DEVICE", "cpu", "AMD.COMPUTE_DTYPE", "fp32", "AMD.SYNTHETIC.HEIGHT", 96, "AMD.SYNTHETIC.WIDTH", 128,
-                         "AMD.SYNTHETIC.BOXES_PER_IMAGE", 6, "AMD.SYNTHETIC.NUM_IMAGES", 2, "SOLVER.IMG_PER_BATCH_UNLABEL", 2,
+                         "AMD.SYNTHETIC.BOXES_PER_IMAGE", 6, "AMD.SYNTHETIC.NUM_IMAGES", world, "SOLVER.IMG_PER_BATCH_UNLABEL", world,
                          "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 16, "MODEL.RPN.PRE_NMS_TOPK_TRAIN", 100, "MODEL.RPN.POST_NMS_TOPK_TRAIN", 30,
                          "MODEL.RPN.PRE_NMS_TOPK_TEST", 60, "MODEL.RPN.POST_NMS_TOPK_TEST", 20, "AMD.TEXT_TEMPLATES", 1, "MODEL.MERGE_DIM", 32,
                          "AMD.ARCH.LAYERS", [1, 1, 1, 1], "AMD.ARCH.WIDTH", 8, "AMD.ARCH.TEXT_WIDTH", 32, "AMD.ARCH.TEXT_LAYERS", 2,
                          "AMD.ARCH.TEXT_HEADS", 2, "AMD.ARCH.TEXT_DIM", 32, "AMD.ARCH.CONTEXT_LENGTH", 16, "AMD.ARCH.VOCAB_SIZE", 64,
-                         "CLOUD.BURN_UP_STEP", 1, "CLOUD.PROTOTYPE_UPDATE_START", 0, "CLOUD.CLS_B_THRESH", 0.2])
+                         "CLOUD.BURN_UP_STEP", 1, "CLOUD.PROTOTYPE_UPDATE_START", 0, "CLOUD.CLS_B_THRESH", 0.2,
+                         "SOLVER.WARMUP_FACTOR", 1.0, "SOLVER.BASE_LR", 0.01])   # (a warm-up step of 1e-6 would not move an fp32 weight at all)
     with cpu_kernels():
         torch.manual_seed(0)
         tr = CoinTrainer(cfg)
@@ -101,16 +102,25 @@ def _coin_worker(rank, world, port, out_dir):
 
         def teacher(batched_inputs, branch=None, **kw):
             real_forward(batched_inputs, branch=branch, **kw)
-            return [synthetic_offline_detections(tr.model_CLOUD.entry(d["file_name"]), g_det) for d in batched_inputs]
+            # b_ranks: only these ranks' teachers disagree with the cloud detector about labels (-> inconsistent 'B' boxes)
+            frac = 0.25 if b_ranks is None else (1.0 if rank in b_ranks else 0.0)
+            extra = 8 if b_ranks is None or rank in b_ranks else 0   # (a private box that overlaps a cloud box of another class is a B box too)
+            return [synthetic_offline_detections(tr.model_CLOUD.entry(d["file_name"]), g_det, relabel_frac=frac, extra=extra) for d in batched_inputs]
 
         tr.offline_teacher.forward = teacher
         with torch.no_grad():
             for n, p in tr.model.named_parameters():
                 if n.endswith("bn3.weight"):
                     p.fill_(0.5)
+        merge0 = {k: v.clone() for k, v in tr.merge.state_dict().items()}
+        had_merge, ema_due = [], []
         for _ in range(2):  # step_one, then step_two with the EMA teacher update
+            ema_due.append(tr._ema_due(tr.iter))
             rec = tr.run_step()
+            had_merge.append("loss_merge_a" in rec)
     torch.save({"sd": {k: v.clone() for k, v in tr.model.state_dict().items()}, "merge": {k: v.clone() for k, v in tr.merge.state_dict().items()},
+                "merge0": merge0, "had_merge": had_merge, "ema_due": ema_due,
+                "teacher": {k: v.clone() for k, v in tr.offline_teacher.state_dict().items()},
                 "loss": {k: float(v) for k, v in rec.items()}}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -134,6 +144,35 @@ def test_two_rank_gloo_cointrainer_keeps_student_and_ckg_in_sync(tmp_path):
     assert a["loss"] != b["loss"]
     # the CKG update ran (at least one rank had B boxes; a rank without them joins the all-reduce with a zero gradient)
     assert "loss_merge_grad" in a["loss"] or "loss_merge_grad" in b["loss"]
+
+
+def test_four_rank_gloo_cointrainer_b_boxes_on_a_strict_subset_of_ranks(tmp_path):
+    """Four ranks, an EMA-due step_two iteration, and inconsistent ('B') boxes on ranks 0 and 1 ONLY: the CKG module's gradient
+    all-reduce is entered by all four ranks (ranks 2 and 3 contribute zeros -- the reference, trainer.py:66-72 + 192-197, would
+    dead-lock here), the CKG parameters move and stay identical everywhere, the student stays identical, and every rank's EMA
+    teacher follows the (identical) student."""
+    world, port = 4, _free_port()
+    mp.start_processes(_coin_worker, args=(world, port, str(tmp_path), (0, 1)), nprocs=world, join=True, start_method="spawn")
+    r = [torch.load(tmp_path / f"rank{i}.pt") for i in range(world)]
+    assert all(x["ema_due"] == [False, True] for x in r)
+    with_b = [i for i in range(world) if any(r[i]["had_merge"])]
+    assert with_b and set(with_b) <= {0, 1}, with_b            # a strict, non-empty subset of the ranks saw B boxes
+    for i in range(1, world):
+        for k in r[0]["sd"]:
+            if "running_" in k or "num_batches" in k or "per_class_feat" in k or "prototype" in k:
+                continue
+            assert torch.allclose(r[0]["sd"][k], r[i]["sd"][k], rtol=0, atol=1e-7), f"student {k} diverged on rank {i}"
+        for k in r[0]["merge"]:
+            assert torch.allclose(r[0]["merge"][k], r[i]["merge"][k], rtol=0, atol=1e-7), f"CKG {k} diverged on rank {i}"
+    assert any(not torch.equal(r[0]["merge"][k], r[0]["merge0"][k]) for k in r[0]["merge"]), "the CKG update did not run"
+    # EMA: the teachers' float parameters agree across ranks (per-rank buffers aside), since the students do
+    n = 0
+    for k, v in r[0]["teacher"].items():
+        if v.dtype != torch.float32 or "running_" in k or "per_class_feat" in k or "prototype" in k:
+            continue
+        assert torch.allclose(v, r[3]["teacher"][k], rtol=0, atol=1e-6), f"teacher {k} differs between ranks 0 and 3"
+        n += 1
+    assert n > 50
 
 
 def _reducer_worker(rank, world, port, out_dir):
