@@ -28,6 +28,11 @@ class CoinHipError(RuntimeError):
     pass
 
 
+class RoiLevel(ctypes.Structure):
+    """coin_roi_level (include/coin_hip.h): one pyramid level of the multi-level pooler."""
+    _fields_ = [("feat", c_void_p), ("H", c_int), ("W", c_int), ("spatial_scale", c_float)]
+
+
 class SgdTensor(ctypes.Structure):
     _fields_ = [
         ("param", c_void_p), ("grad", c_void_p), ("momentum_buf", c_void_p), ("bf16_shadow", c_void_p),
@@ -45,12 +50,15 @@ _P, _I, _F, _L, _Z = c_void_p, c_int, c_float, c_int64, ctypes.c_size_t
 SIGNATURES = {
     "coin_roi_align_fwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _F, _I, _I, _P, _I, _P],
     "coin_roi_align_bwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _F, _I, _I, _P, _I, _P],
+    "coin_roi_align_fwd_levels": [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P],
+    "coin_roi_align_bwd_level": [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P, _I, _P],
     "coin_gemm_nt": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _F, _I, _I, _P],
     "coin_conv_gemm_bf16": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P],
     "coin_conv_gemm_bf16_ws": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P, _Z, _P],
     "coin_conv_gemm_stats_finalize": [_P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P],
     "coin_conv_wgrad_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "coin_window_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "coin_window_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "coin_anchor_match": [_P, _P, _I, _P, _I, _F, _F, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "coin_sample_labels": [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P],
     "coin_aug_resize_bilinear_u8": [_P, _I, _I, _P, _I, _I, _I, _P, _P],
@@ -123,6 +131,8 @@ def lib() -> ctypes.CDLL:
     l.coin_conv_wgrad_workspace_bytes.restype = ctypes.c_size_t
     l.coin_conv_gemm_workspace_bytes.argtypes = [c_int, c_int, c_int]
     l.coin_conv_gemm_workspace_bytes.restype = ctypes.c_size_t
+    l.coin_window_attn_bwd_workspace_bytes.argtypes = [c_int, c_int]
+    l.coin_window_attn_bwd_workspace_bytes.restype = ctypes.c_size_t
     l.coin_abi_version.restype = c_int
     l.coin_build_arch.restype = c_char_p
     _lib = l

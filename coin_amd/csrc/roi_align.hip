@@ -80,10 +80,17 @@ __device__ __forceinline__ void vec_fma(float (&acc)[Vec16<T>::N], const typenam
 // ------------------------------------------------------------------------------------------
 // forward, NHWC
 // ------------------------------------------------------------------------------------------
-template <typename T>
+// Pyramid levels of the multi-level pooler (FPN extension): RoI r is pooled from level roi_level[r] -- one launch for all levels.
+struct RoiLevelTable {
+  const void* feat[COIN_ROI_MAX_LEVELS];
+  int H[COIN_ROI_MAX_LEVELS], W[COIN_ROI_MAX_LEVELS];
+  float scale[COIN_ROI_MAX_LEVELS];
+};
+
+template <typename T, bool ML>
 __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_kernel(
     const T* __restrict__ feat, const float* __restrict__ rois, T* __restrict__ out, int C, int H, int W, int R,
-    int ph, int pw, float scale, int sampling_ratio, int aligned) {
+    int ph, int pw, float scale, int sampling_ratio, int aligned, const RoiLevelTable lv, const int* __restrict__ roi_level, int nlevels) {
   constexpr int VEC = Vec16<T>::N;
   typedef typename Vec16<T>::type vec_t;
   // XCD-aware: the ph row-blocks of one RoI share blockIdx % 8.
@@ -92,6 +99,23 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_kernel(
   const int roi = xcd + 8 * (s / ph);
   const int py = s % ph;
   if (roi >= R) return;
+  if (ML) {
+    int l = roi_level[roi];
+    l = l < 0 ? 0 : (l >= nlevels ? nlevels - 1 : l);
+    // (wave-uniform selects from the by-value table: scalar registers)
+    feat = (const T*)lv.feat[0];
+    H = lv.H[0];
+    W = lv.W[0];
+    scale = lv.scale[0];
+#pragma unroll
+    for (int k = 1; k < COIN_ROI_MAX_LEVELS; ++k)
+      if (l == k) {
+        feat = (const T*)lv.feat[k];
+        H = lv.H[k];
+        W = lv.W[k];
+        scale = lv.scale[k];
+      }
+  }
   const RoiGeom g = roi_geom(rois + (size_t)roi * 5, ph, pw, scale, sampling_ratio, aligned);
   const int ncg = C / VEC;                     // 16-byte channel groups per pixel
   const int tpp = ncg < 256 ? ncg : 256;       // threads per pixel
@@ -282,7 +306,7 @@ constexpr int BT_ROWS = 4, BT_COLS = 8, BT_LC = 32;
 template <typename T>
 __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
     const T* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gfeat, int C, int H, int W, int R, int ph, int pw,
-    float scale, int sampling_ratio, int aligned, int tiles_x, int tiles_y, int ntiles, int nparts) {
+    float scale, int sampling_ratio, int aligned, int tiles_x, int tiles_y, int ntiles, int nparts, const int* __restrict__ roi_level, int level) {
   constexpr int VEC = Vec16<T>::N;
   typedef typename Vec16<T>::type vec_t;
   __shared__ unsigned short list[LIST_CAP];
@@ -322,7 +346,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
       bool hit = false;
       if (i < lim) {
         const RoiGeom g = roi_geom(rois + (size_t)(base + i) * 5, ph, pw, scale, sampling_ratio, aligned);
-        if (g.n == n && g.gh > 0 && g.gw > 0) {
+        if (g.n == n && g.gh > 0 && g.gw > 0 && (roi_level == nullptr || roi_level[base + i] == level)) {   // multi-level pooler: this level's RoIs only
           // conservative footprint: first / last sample of each axis, +-1 pixel for the bilinear taps (the border rows /
           // columns also collect the clamped samples from [-1, 0] and [size-1, size])
           const float ys0 = g.y0 + 0.5f * g.bh / (float)g.gh, ys1 = g.y0 + ((float)(ph - 1) + ((float)g.gh - 0.5f) / (float)g.gh) * g.bh;
@@ -566,12 +590,13 @@ extern "C" int coin_roi_align_fwd(const void* feat, int N, int C, int H, int W, 
   // kernel at the benchmark shape; each output needs 4-16 taps out of L2 and the kernel is bound by those gathers, so it was removed.)
   if (layout == COIN_NHWC) {
     const int grid = ((R + 7) / 8) * 8 * ph;
+    const RoiLevelTable none = {};
     if (dtype == COIN_F32)
-      roi_align_fwd_nhwc_kernel<float><<<grid, 256, 0, st>>>((const float*)feat, rois, (float*)out, C, H, W, R, ph,
-                                                               pw, spatial_scale, sampling_ratio, aligned);
+      roi_align_fwd_nhwc_kernel<float, false><<<grid, 256, 0, st>>>((const float*)feat, rois, (float*)out, C, H, W, R, ph,
+                                                                      pw, spatial_scale, sampling_ratio, aligned, none, nullptr, 0);
     else
-      roi_align_fwd_nhwc_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)feat, rois, (bf16_t*)out, C, H, W, R,
-                                                                ph, pw, spatial_scale, sampling_ratio, aligned);
+      roi_align_fwd_nhwc_kernel<bf16_t, false><<<grid, 256, 0, st>>>((const bf16_t*)feat, rois, (bf16_t*)out, C, H, W, R,
+                                                                       ph, pw, spatial_scale, sampling_ratio, aligned, none, nullptr, 0);
   } else {
     const size_t total = (size_t)R * C * ph * pw;
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
@@ -585,9 +610,9 @@ extern "C" int coin_roi_align_fwd(const void* feat, int N, int C, int H, int W, 
   return coin_launch_status();
 }
 
-extern "C" int coin_roi_align_bwd(const void* grad_out, int N, int C, int H, int W, int layout, const float* rois,
-                                  int R, int ph, int pw, float spatial_scale, int sampling_ratio, int aligned,
-                                  float* grad_feat, int dtype, void* stream) {
+static int roi_align_bwd_impl(const void* grad_out, int N, int C, int H, int W, int layout, const float* rois,
+                              int R, int ph, int pw, float spatial_scale, int sampling_ratio, int aligned,
+                              float* grad_feat, int dtype, void* stream, const int* roi_level, int level) {
   int rc = check_common(grad_out, rois, grad_feat, N, C, H, W, layout, R, ph, pw, dtype);
   if (rc) return rc;
   if (!grad_feat) return COIN_EINVAL;
@@ -603,12 +628,14 @@ extern "C" int coin_roi_align_bwd(const void* grad_out, int N, int C, int H, int
     if (dtype == COIN_F32) {
       const int nparts = (C + 64 * 4 - 1) / (64 * 4);
       roi_align_bwd_gather_kernel<float><<<ntiles * nparts, 256, 0, st>>>((const float*)grad_out, rois, grad_feat, C, H, W, R, ph, pw, spatial_scale,
-                                                                          sampling_ratio, aligned, tiles_x, tiles_y, ntiles, nparts);
+                                                                          sampling_ratio, aligned, tiles_x, tiles_y, ntiles, nparts, roi_level, level);
     } else {
       const int nparts = (C + 64 * 8 - 1) / (64 * 8);
       roi_align_bwd_gather_kernel<bf16_t><<<ntiles * nparts, 256, 0, st>>>((const bf16_t*)grad_out, rois, grad_feat, C, H, W, R, ph, pw, spatial_scale,
-                                                                           sampling_ratio, aligned, tiles_x, tiles_y, ntiles, nparts);
+                                                                           sampling_ratio, aligned, tiles_x, tiles_y, ntiles, nparts, roi_level, level);
     }
+  } else if (roi_level != nullptr) {
+    return COIN_ESHAPE;   // the level filter exists in the tile-gather kernel only (channels-last, bins <= 16 x 16)
   } else if (layout == COIN_NHWC) {
     if (hipMemsetAsync(grad_feat, 0, sizeof(float) * (size_t)N * C * H * W, st) != hipSuccess) return coin_launch_status();
     if (R == 0) return COIN_OK;
@@ -639,4 +666,42 @@ extern "C" int coin_roi_align_bwd(const void* grad_out, int N, int C, int H, int
                                                                 ph, pw, spatial_scale, sampling_ratio, aligned);
   }
   return coin_launch_status();
+}
+
+extern "C" int coin_roi_align_bwd(const void* grad_out, int N, int C, int H, int W, int layout, const float* rois,
+                                  int R, int ph, int pw, float spatial_scale, int sampling_ratio, int aligned,
+                                  float* grad_feat, int dtype, void* stream) {
+  return roi_align_bwd_impl(grad_out, N, C, H, W, layout, rois, R, ph, pw, spatial_scale, sampling_ratio, aligned, grad_feat, dtype, stream, nullptr, 0);
+}
+
+// ---- multi-level pooler (FPN extension; no counterpart in the reference, whose pooler has one level: clip_roi_heads.py:172-176)
+extern "C" int coin_roi_align_fwd_levels(const coin_roi_level* levels, int nlevels, int N, int C, const float* rois, const int* roi_level,
+                                         int R, int ph, int pw, int sampling_ratio, int aligned, void* out, int dtype, void* stream) {
+  if (!levels || nlevels <= 0 || nlevels > COIN_ROI_MAX_LEVELS) return COIN_EINVAL;
+  if (R > 0 && !roi_level) return COIN_EINVAL;
+  RoiLevelTable t = {};
+  for (int k = 0; k < nlevels; ++k) {
+    int rc = check_common(levels[k].feat, rois, out, N, C, levels[k].H, levels[k].W, COIN_NHWC, R, ph, pw, dtype);
+    if (rc) return rc;
+    t.feat[k] = levels[k].feat;
+    t.H[k] = levels[k].H;
+    t.W[k] = levels[k].W;
+    t.scale[k] = levels[k].spatial_scale;
+  }
+  if (R == 0) return COIN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = ((R + 7) / 8) * 8 * ph;
+  if (dtype == COIN_F32)
+    roi_align_fwd_nhwc_kernel<float, true><<<grid, 256, 0, st>>>(nullptr, rois, (float*)out, C, 0, 0, R, ph, pw, 0.f, sampling_ratio, aligned, t, roi_level, nlevels);
+  else
+    roi_align_fwd_nhwc_kernel<bf16_t, true><<<grid, 256, 0, st>>>(nullptr, rois, (bf16_t*)out, C, 0, 0, R, ph, pw, 0.f, sampling_ratio, aligned, t, roi_level, nlevels);
+  return coin_launch_status();
+}
+
+extern "C" int coin_roi_align_bwd_level(const void* grad_out, int N, int C, int H, int W, const float* rois, const int* roi_level, int level,
+                                        int R, int ph, int pw, float spatial_scale, int sampling_ratio, int aligned, float* grad_feat, int dtype,
+                                        void* stream) {
+  if (R > 0 && !roi_level) return COIN_EINVAL;
+  if (ph > 16 || pw > 16) return COIN_ESHAPE;
+  return roi_align_bwd_impl(grad_out, N, C, H, W, COIN_NHWC, rois, R, ph, pw, spatial_scale, sampling_ratio, aligned, grad_feat, dtype, stream, roi_level, level);
 }

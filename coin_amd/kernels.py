@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import ACT_LEAKY_RELU, ACT_NONE, ACT_RELU, COIN_BF16, COIN_F32, COIN_NCHW, COIN_NHWC, CoinHipError, check
 
 __all__ = [
-    "roi_align_fwd", "roi_align_bwd", "gemm_nt", "conv_gemm", "conv_wgrad", "window_attn_fwd", "conv_stats_finalize", "transpose2d", "bias_act_bwd", "cosine_logits_fwd",
+    "roi_align_fwd", "roi_align_bwd", "gemm_nt", "conv_gemm", "conv_wgrad", "window_attn_fwd", "window_attn_bwd", "roi_align_fwd_levels", "roi_align_bwd_level", "conv_stats_finalize", "transpose2d", "bias_act_bwd", "cosine_logits_fwd",
     "cosine_logits_bwd", "bn_stats", "bn_apply_fwd", "bn_bwd", "avgpool2_fwd", "avgpool2_bwd", "nms_batched", "mil_ce", "mil_focal", "kl_div", "box_reg_l1", "l1_mean", "rpn_losses", "normalize_pad",
     "SgdTable", "EmaTable",
 ]
@@ -285,6 +285,74 @@ def window_attn_fwd(qkv: torch.Tensor, bias64: torch.Tensor, mask64: Optional[to
     check(_lib.lib().coin_window_attn_fwd(_p(qkv), _p(bias64), _p(mask64), _p(out), b, mask64.shape[0] if mask64 is not None else 1, heads, t, 32,
                                           float(scale), _stream()), "coin_window_attn_fwd")
     return out
+
+
+_WATTN_WS: dict = {}
+
+
+def window_attn_bwd(qkv: torch.Tensor, bias64: torch.Tensor, mask64: Optional[torch.Tensor], dout: torch.Tensor, heads: int, scale: float):
+    """Backward of `window_attn_fwd` (coin_window_attn_bwd) -> (dqkv bf16 like qkv, dbias fp32 [heads, T, T])."""
+    _dev(qkv, bias64, mask64, dout)
+    b, t, c3 = qkv.shape
+    if qkv.dtype != torch.bfloat16 or not qkv.is_contiguous() or c3 != 3 * heads * 32:
+        raise CoinHipError("window_attn_bwd needs a contiguous bf16 [B, T, 3*heads*32] tensor")
+    if dout.dtype != torch.bfloat16 or not dout.is_contiguous() or tuple(dout.shape) != (b, t, heads * 32):
+        raise CoinHipError("window_attn_bwd: dout must be a contiguous bf16 [B, T, heads*32] tensor")
+    _f32c(bias64, "bias64")
+    if bias64.shape != (heads, 64, 64) or (mask64 is not None and (mask64.dim() != 3 or mask64.shape[1:] != (64, 64) or b % mask64.shape[0])):
+        raise CoinHipError("window_attn_bwd: bias must be [heads, 64, 64], mask [nW, 64, 64] with B % nW == 0")
+    if mask64 is not None:
+        _f32c(mask64, "mask64")
+    nbytes = _lib.lib().coin_window_attn_bwd_workspace_bytes(b, heads)
+    key = (str(qkv.device), torch.cuda.current_stream(qkv.device).cuda_stream if qkv.is_cuda else 0)
+    ws = _WATTN_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _WATTN_WS[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=qkv.device)
+    dqkv = torch.empty_like(qkv)
+    dbias = torch.empty((heads, t, t), dtype=torch.float32, device=qkv.device)
+    check(_lib.lib().coin_window_attn_bwd(_p(qkv), _p(bias64), _p(mask64), _p(dout), _p(dqkv), _p(dbias), _p(ws), b,
+                                          mask64.shape[0] if mask64 is not None else 1, heads, t, 32, float(scale), _stream()), "coin_window_attn_bwd")
+    return dqkv, dbias
+
+
+def roi_align_fwd_levels(feats: Sequence[torch.Tensor], scales: Sequence[float], rois: torch.Tensor, levels: torch.Tensor, output_size: Tuple[int, int],
+                         sampling_ratio: int = 0, aligned: bool = True) -> torch.Tensor:
+    """Multi-level RoIAlign in ONE launch (coin_roi_align_fwd_levels): feats = contiguous NHWC maps [N, H_l, W_l, C] of one dtype, RoI r
+    is pooled from feats[levels[r]] (int32, device) -> [R, ph, pw, C]."""
+    _dev(*feats, rois, levels)
+    if not 1 <= len(feats) <= 4 or len(scales) != len(feats):
+        raise CoinHipError("roi_align_fwd_levels: 1..4 pyramid levels with one scale each")
+    n, _, _, c = feats[0].shape
+    for f in feats:
+        if not f.is_contiguous() or f.dim() != 4 or f.shape[0] != n or f.shape[3] != c or f.dtype != feats[0].dtype:
+            raise CoinHipError("roi_align_fwd_levels: every level must be a contiguous [N, H, W, C] map of the same N, C and dtype")
+    rois = _f32c(rois, "rois")
+    if levels.dtype != torch.int32 or not levels.is_contiguous() or levels.numel() != rois.shape[0]:
+        raise CoinHipError("roi_align_fwd_levels: levels must be a contiguous int32 [R] tensor")
+    ph, pw = output_size
+    r = rois.shape[0]
+    out = torch.empty((r, ph, pw, c), dtype=feats[0].dtype, device=feats[0].device)
+    table = (_lib.RoiLevel * len(feats))()
+    for i, (f, s) in enumerate(zip(feats, scales)):
+        table[i].feat, table[i].H, table[i].W, table[i].spatial_scale = f.data_ptr(), f.shape[1], f.shape[2], float(s)
+    check(_lib.lib().coin_roi_align_fwd_levels(ctypes.cast(table, ctypes.c_void_p), len(feats), n, c, _p(rois), _p(levels), r, ph, pw,
+                                               int(sampling_ratio), int(aligned), _p(out), _dt(feats[0]), _stream()), "coin_roi_align_fwd_levels")
+    return out
+
+
+def roi_align_bwd_level(grad_out: torch.Tensor, rois: torch.Tensor, levels: torch.Tensor, level: int, feat_shape: Sequence[int], spatial_scale: float,
+                        sampling_ratio: int = 0, aligned: bool = True) -> torch.Tensor:
+    """float32 gradient map [N, H, W, C] of pyramid level `level`: the RoIs with levels[r] == level only (coin_roi_align_bwd_level)."""
+    _dev(grad_out, rois, levels)
+    if not grad_out.is_contiguous():
+        raise CoinHipError("grad_out must be contiguous")
+    rois = _f32c(rois, "rois")
+    n, h, w, c = feat_shape
+    r, ph, pw, _ = grad_out.shape
+    g = torch.empty((n, h, w, c), dtype=torch.float32, device=grad_out.device)
+    check(_lib.lib().coin_roi_align_bwd_level(_p(grad_out), n, c, h, w, _p(rois), _p(levels), int(level), r, ph, pw, float(spatial_scale),
+                                              int(sampling_ratio), int(aligned), _p(g), _dt(grad_out), _stream()), "coin_roi_align_bwd_level")
+    return g
 
 
 def conv_stats_finalize(part: torch.Tensor, m: int, n: int, rows: int, eps: float, momentum: float,

@@ -335,6 +335,42 @@ def roi_align(feat: torch.Tensor, rois: torch.Tensor, output_size: Tuple[int, in
     return out.permute(0, 3, 1, 2)
 
 
+class _ROIAlignLevels(Function):
+    """Multi-level pooler of the FPN extension (no reference counterpart): RoI r from pyramid level levels[r]; one forward launch for all
+    levels (coin_roi_align_fwd_levels), one atomic-free gather launch per level in the backward (coin_roi_align_bwd_level)."""
+
+    @staticmethod
+    def forward(ctx, rois, levels, output_size, scales, sampling_ratio, aligned, *feats_nhwc):
+        out = K.roi_align_fwd_levels(feats_nhwc, scales, rois, levels, output_size, sampling_ratio, aligned)
+        ctx.save_for_backward(rois, levels)
+        ctx.meta = ([tuple(f.shape) for f in feats_nhwc], [f.dtype for f in feats_nhwc], tuple(scales), sampling_ratio, aligned)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        rois, levels = ctx.saved_tensors
+        shapes, dtypes, scales, sr, aligned = ctx.meta
+        go = grad_out.contiguous()
+        grads = []
+        for i, (shape, dt, sc) in enumerate(zip(shapes, dtypes, scales)):
+            grads.append(K.roi_align_bwd_level(go, rois, levels, i, shape, sc, sr, aligned).to(dt) if ctx.needs_input_grad[6 + i] else None)
+        return (None, None, None, None, None, None) + tuple(grads)
+
+
+def roi_align_levels(feats: Sequence[torch.Tensor], scales: Sequence[float], rois: torch.Tensor, levels: torch.Tensor, output_size: Tuple[int, int],
+                     sampling_ratio: int = 0, aligned: bool = True) -> torch.Tensor:
+    """feats: logical [N,C,H_l,W_l] maps in channels_last memory format, levels: pyramid level index per RoI -> logical [R,C,ph,pw]
+    (channels_last).  Level selection happens inside the launch: each RoI is pooled once, on its own level."""
+    nhwc = []
+    for f in feats:
+        v = f.permute(0, 2, 3, 1)
+        nhwc.append(v if v.is_contiguous() else v.contiguous())
+    out = _ROIAlignLevels.apply(rois.float().contiguous(), levels.to(torch.int32).contiguous(), tuple(output_size), tuple(float(s) for s in scales),
+                                int(sampling_ratio), bool(aligned), *nhwc)
+    return out.permute(0, 3, 1, 2)
+
+
 # --------------------------------------------------------------------------- fused BatchNorm(train) [+res] [+ReLU] [+pool]
 def _as_nhwc(t: torch.Tensor) -> torch.Tensor:
     v = t.permute(0, 2, 3, 1)

@@ -129,9 +129,10 @@ def assign_levels(boxes: torch.Tensor, min_level: int = 2, max_level: int = 5, c
 
 
 class MultiLevelROIPooler(nn.Module):
-    """7x7 RoIAlign (aligned, adaptive sampling: coin_roi_align_fwd / _bwd) of every RoI on the pyramid level its size selects.
-    Sync-free: every level pools ALL rows and the rows assigned elsewhere are masked out (4 x [R, 7, 7, 256] passes of the kernel;
-    no `nonzero`, no data-dependent shape -- the same policy as the sync-free samplers)."""
+    """7x7 RoIAlign (aligned, adaptive sampling) of every RoI on the pyramid level its size selects.  Sync-free (no `nonzero`, no
+    data-dependent shape -- the same policy as the sync-free samplers): on the device the level index of each RoI is an operand of
+    ONE launch (coin_roi_align_fwd_levels; backward: one filtered gather launch per level); the host / mixed-dtype formulation below
+    pools every level for all rows and masks."""
 
     def __init__(self, output_size: int, scales, sampling_ratio: int = 0, min_level: int = 2):
         super().__init__()
@@ -140,6 +141,9 @@ class MultiLevelROIPooler(nn.Module):
 
     def forward(self, feats: List[torch.Tensor], rois: torch.Tensor) -> torch.Tensor:
         lvl = assign_levels(rois[:, 1:], self.min_level, self.min_level + len(feats) - 1)
+        if rois.is_cuda and len(feats) <= 4 and all(f.dtype == feats[0].dtype for f in feats):
+            # the level index rides into the kernel: every RoI is pooled ONCE, on its own level (no per-level pass over all rows, no masks)
+            return L.roi_align_levels(feats, self.scales, rois, lvl, self.output_size, self.sampling_ratio, True)
         out = None
         for i, (f, s) in enumerate(zip(feats, self.scales)):
             x = L.roi_align(f, rois, self.output_size, s, self.sampling_ratio, True)

@@ -6,8 +6,8 @@ against this repository's own restatement (oracle/fpn.py): parity unpinned by co
 
 MI355X path: activations stay [N, H, W, C] (channels-last is the natural layout of every LayerNorm / Linear here); in the bf16
 throughput mode the attention of all windows x heads of a block is ONE launch of ``coin_window_attn_fwd`` (QK^T, bias + shift
-mask, softmax and PV on MFMA, csrc/window_attn.hip).  Its backward recomputes the attention with differentiable torch ops (the
-relative-position-bias table is trained, so d bias is needed too); fp32 / CPU runs use that same torch formulation forward.
+mask, softmax and PV on MFMA, csrc/window_attn.hip); its backward is ``coin_window_attn_bwd`` (dQ, dK, dV on MFMA and the gradient
+of the trained relative-position-bias table, summed over the windows in a fixed order).  fp32 / CPU runs use the torch formulation.
 """
 from __future__ import annotations
 
@@ -50,18 +50,17 @@ class _WindowAttn(Function):
     def forward(ctx, qkv, bias, mask, mask64, heads, scale):
         out = K.window_attn_fwd(qkv, _pad64(bias.detach().float(), -1e30), mask64, heads, scale)
         ctx.save_for_backward(qkv, bias, mask if mask is not None else qkv.new_zeros(0))
-        ctx.heads, ctx.scale, ctx.has_mask = heads, scale, mask is not None
+        ctx.heads, ctx.scale, ctx.has_mask, ctx.mask64 = heads, scale, mask is not None, mask64
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
         qkv, bias, mask = ctx.saved_tensors
-        with torch.enable_grad():
-            q_, b_ = qkv.detach().requires_grad_(True), bias.detach().requires_grad_(True)
-            out = window_attention_reference(q_, b_, mask if ctx.has_mask else None, ctx.heads, ctx.scale)
-            gq, gb = torch.autograd.grad(out, (q_, b_), dout.to(out.dtype))
-        return gq, gb, None, None, None, None
+        # coin_window_attn_bwd: P recomputed with the forward's arithmetic, dP / dV / dQ / dK on MFMA, d bias summed over the windows in
+        # a fixed order (round 3 recomputed the attention with differentiable torch ops here: ~25 launches and fp32 [B, heads, T, T] tensors)
+        gq, gb = K.window_attn_bwd(qkv, _pad64(bias.detach().float(), -1e30), ctx.mask64, dout.contiguous().to(torch.bfloat16), ctx.heads, ctx.scale)
+        return gq, gb.to(bias.dtype), None, None, None, None
 
 
 def window_attention(qkv, bias, mask, mask64, heads: int, scale: float) -> torch.Tensor:

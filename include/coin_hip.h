@@ -71,6 +71,24 @@ int coin_roi_align_bwd(const void* grad_out, int N, int C, int H, int W, int lay
                        const float* rois, int R, int ph, int pw, float spatial_scale,
                        int sampling_ratio, int aligned, float* grad_feat, int dtype, void* stream);
 
+/* Multi-level RoIAlign of the FPN extension (coin_amd/modeling/fpn.py; the reference's pooler has a single level,
+ * clip_roi_heads.py:172-176): RoI r is pooled from pyramid level roi_level[r] (device int32, clamped to [0, nlevels)) -- ONE launch for
+ * all levels, every output row written exactly once.  Channels-last maps only; `levels` is a HOST array of nlevels <= COIN_ROI_MAX_LEVELS
+ * entries (device map pointer, its height / width, its spatial scale), all maps [N, H_l, W_l, C].  The backward is run once per level:
+ * coin_roi_align_bwd_level overwrites that level's float32 gradient map with the contributions of the RoIs whose roi_level == level
+ * (the atomic-free tile gather; bins <= 16 x 16). */
+#define COIN_ROI_MAX_LEVELS 4
+typedef struct coin_roi_level {
+  const void* feat;
+  int H, W;
+  float spatial_scale;
+} coin_roi_level;
+int coin_roi_align_fwd_levels(const coin_roi_level* levels, int nlevels, int N, int C, const float* rois, const int* roi_level, int R,
+                              int ph, int pw, int sampling_ratio, int aligned, void* out, int dtype, void* stream);
+int coin_roi_align_bwd_level(const void* grad_out, int N, int C, int H, int W, const float* rois, const int* roi_level, int level, int R,
+                             int ph, int pw, float spatial_scale, int sampling_ratio, int aligned, float* grad_feat, int dtype,
+                             void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Box-head GEMM   (replaces the nn.Linear calls of FastRCNNOutputLayers.forward,
  *                  coin/modeling/roi_heads/fast_rcnn.py:331-337: `trans` MLP, `cls_score`,
@@ -200,6 +218,15 @@ int coin_conv_wgrad_bf16(const void* gy, const void* x, int mode, int H, int W, 
  * 64); mask float32 [windows_per_image][64][64] or NULL; out bf16 [num_windows][tokens][heads*32].  tokens <= 64, head_dim == 32. */
 int coin_window_attn_fwd(const void* qkv, const float* bias, const float* mask, void* out, int num_windows, int windows_per_image,
                          int heads, int tokens, int head_dim, float scale, void* stream);
+
+/* Its backward (replaces the autograd of the same published formulation; no reference counterpart): given dout bf16
+ * [num_windows][tokens][heads*32] -> dqkv bf16 (qkv's layout, every element written) and dbias float32 [heads][tokens][tokens]
+ * (OVERWRITTEN; the sum over all windows, reduced through `workspace` in a fixed order: no atomics).  P is recomputed from qkv / bias /
+ * mask with the forward's arithmetic; dQ, dK, dV, dP run on MFMA.  workspace: coin_window_attn_bwd_workspace_bytes, 16-byte aligned. */
+size_t coin_window_attn_bwd_workspace_bytes(int num_windows, int heads);
+int coin_window_attn_bwd(const void* qkv, const float* bias, const float* mask, const void* dout, void* dqkv, float* dbias,
+                         void* workspace, int num_windows, int windows_per_image, int heads, int tokens, int head_dim, float scale,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused losses: each computes the scalar loss AND the gradient w.r.t. its differentiable

@@ -84,6 +84,28 @@ def window_attention(qkv: np.ndarray, bias: np.ndarray, mask, heads: int, scale:
     return out
 
 
+def window_attention_t(qkv: torch.Tensor, bias: torch.Tensor, mask, heads: int, scale: float) -> torch.Tensor:
+    """The same loops as `window_attention` on float64 torch tensors (differentiable: the gradients of the Swin blocks and of the
+    window-attention backward kernel are checked against autograd through THIS formulation).  mask: tensor [nW, T, T] or None."""
+    b, t, c3 = qkv.shape
+    hd = c3 // (3 * heads)
+    x = qkv.double().reshape(b, t, 3, heads, hd)
+    rows = []
+    for w in range(b):
+        cols = []
+        for h in range(heads):
+            q, k, v = x[w, :, 0, h], x[w, :, 1, h], x[w, :, 2, h]
+            s = scale * (q @ k.t()) + bias[h].double()
+            if mask is not None:
+                s = s + mask[w % mask.shape[0]].double()
+            s = s - s.max(dim=1, keepdim=True).values.detach()
+            p = torch.exp(s)
+            p = p / p.sum(dim=1, keepdim=True)
+            cols.append(p @ v)
+        rows.append(torch.cat(cols, dim=1))
+    return torch.stack(rows)
+
+
 def _layer_norm(x, w, b, eps=1e-5):
     mu = x.mean(-1, keepdim=True)
     var = ((x - mu) ** 2).mean(-1, keepdim=True)
@@ -107,7 +129,7 @@ def swin_block(x: torch.Tensor, sd: Dict[str, torch.Tensor], heads: int, ws: int
     yp[:, :h, :w] = y
     if min(hp, wp) <= ws:
         shift = 0
-    bias = sd["relative_position_bias_table"].double()[rel_index.view(-1)].view(t, t, heads).permute(2, 0, 1).numpy()
+    bias = sd["relative_position_bias_table"].double()[rel_index.view(-1)].view(t, t, heads).permute(2, 0, 1)
     scale = (c // heads) ** -0.5
     outp = torch.zeros_like(yp)
     for b in range(n):
@@ -121,9 +143,9 @@ def swin_block(x: torch.Tensor, sd: Dict[str, torch.Tensor], heads: int, ws: int
                 m = None
                 if shift:
                     rid = np.array([_region_id(wy * ws + i, wx * ws + j, hp, wp, ws, shift) for i in range(ws) for j in range(ws)])
-                    m = np.where(rid[:, None] != rid[None, :], -100.0, 0.0)[None]
-                att = window_attention(qkv.numpy()[None], bias, m, heads, scale)[0]
-                o = torch.from_numpy(att) @ sd["proj.weight"].double().t() + sd["proj.bias"].double()
+                    m = torch.from_numpy(np.where(rid[:, None] != rid[None, :], -100.0, 0.0))[None]
+                att = window_attention_t(qkv[None], bias, m, heads, scale)[0]
+                o = att @ sd["proj.weight"].double().t() + sd["proj.bias"].double()
                 k = 0
                 for yy in ys:
                     for xx in xs:

@@ -155,3 +155,15 @@ def test_swin_fpn_detector_targetdet_step_on_cpu():
     assert all(math.isfinite(v) for v in rec.values()), rec
     moved = [n for n, p in tr.model.backbone.bottom_up.named_parameters() if not torch.equal(p.detach(), before[n])]
     assert any("relative_position_bias_table" in n for n in moved) and any("qkv.weight" in n for n in moved), moved[:5]
+
+
+def test_oracle_torch_window_attention_equals_the_numpy_loops():
+    """oracle.fpn.window_attention_t (the differentiable float64 twin used for the gradient checks on the device) == the numpy loops."""
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(6, 49, 3 * 3 * 32, generator=g)
+    bias = torch.randn(3, 49, 49, generator=g)
+    mask = torch.where(torch.rand(3, 49, 49, generator=g) < 0.2, -100.0, 0.0)
+    for m in (None, mask):
+        a = O.window_attention_t(qkv, bias, m, 3, 32 ** -0.5).numpy()
+        b = O.window_attention(qkv.numpy(), bias.numpy(), None if m is None else m.numpy(), 3, 32 ** -0.5)
+        np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-12)
