@@ -33,6 +33,11 @@ class RoiLevel(ctypes.Structure):
     _fields_ = [("feat", c_void_p), ("H", c_int), ("W", c_int), ("spatial_scale", c_float)]
 
 
+class WdTensor(ctypes.Structure):
+    """coin_wd_tensor (include/coin_hip.h): one weight of the one-launch data-gradient re-layout."""
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("cout", ctypes.c_int32), ("cin", ctypes.c_int32), ("ks", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 class SgdTensor(ctypes.Structure):
     _fields_ = [
         ("param", c_void_p), ("grad", c_void_p), ("momentum_buf", c_void_p), ("bf16_shadow", c_void_p),
@@ -55,7 +60,7 @@ SIGNATURES = {
     "coin_gemm_nt": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _F, _I, _I, _P],
     "coin_conv_gemm_bf16": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P],
     "coin_conv_gemm_bf16_ws": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P, _Z, _P],
-    "coin_conv_gemm_stats_finalize": [_P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P],
+    "coin_conv_gemm_stats_finalize": [_P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P, _P],
     "coin_conv_wgrad_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "coin_window_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "coin_window_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
@@ -75,13 +80,14 @@ SIGNATURES = {
     "coin_l1_mean_fwd_bwd": [_P, _P, _L, _P, _P, _P],
     "coin_rpn_losses_fwd_bwd": [_P, _P, _P, _P, _P, _L, _L, _I, _P, _P, _P, _P, _P],
     "coin_normalize_pad": [_P, _I, _I, ctypes.POINTER(c_float), ctypes.POINTER(c_float), _P, _I, _I, _I, _I, _I, _P],
-    "coin_bn_stats": [_P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _I, _P],
+    "coin_bn_stats": [_P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P],
     "coin_bn_apply_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "coin_bn_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "coin_avgpool2_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "coin_avgpool2_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "coin_nms_batched": [_P, _P, _I, _I, _F, _I, _P, _P, _P, _P],
     "coin_sgd_step": [_P, _I, _L, _F, _F, _F, _I, _P],
+    "coin_weight_dgrad_layout": [_P, _I, _I, _P],
     "coin_ema_update": [_P, _I, _L, _F, _P],
 }
 

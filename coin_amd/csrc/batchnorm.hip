@@ -104,8 +104,9 @@ template <typename T>
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const T* __restrict__ x, const float* __restrict__ sums, int nparts, int64_t M,
                                                             int C, float eps, float momentum, float* __restrict__ mean,
                                                             float* __restrict__ rstd, float* __restrict__ running_mean,
-                                                            float* __restrict__ running_var) {
+                                                            float* __restrict__ running_var, int64_t* __restrict__ nbt) {
   __shared__ float red[16][64];
+  if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   const int which = wave >> 3, w8 = wave & 7;
@@ -550,7 +551,8 @@ int walk_grid(int64_t rows, int ncg) {
   } while (0)
 
 extern "C" int coin_bn_stats(const void* x, int N, int H, int W, int C, float eps, float momentum, float* sums_workspace,
-                             float* mean, float* rstd, float* running_mean, float* running_var, int dtype, void* stream) {
+                             float* mean, float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, int dtype,
+                             void* stream) {
   int rc = bn_check(x, N, H, W, C, 1, dtype);
   if (rc) return rc;
   if (!sums_workspace || !mean || !rstd) return COIN_EINVAL;
@@ -562,7 +564,7 @@ extern "C" int coin_bn_stats(const void* x, int N, int H, int W, int C, float ep
   if (g > COIN_BN_MAX_PARTS) g = COIN_BN_MAX_PARTS;
   const size_t lds = sizeof(float) * BN_THREADS * 2 * v;
 #define GO(T) bn_stats_kernel<T><<<(int)g, BN_THREADS, lds, st>>>((const T*)x, M, C, sums_workspace); \
-  bn_finalize_kernel<T><<<(C + 63) / 64, 1024, 0, st>>>((const T*)x, sums_workspace, (int)g, M, C, eps, momentum, mean, rstd, running_mean, running_var)
+  bn_finalize_kernel<T><<<(C + 63) / 64, 1024, 0, st>>>((const T*)x, sums_workspace, (int)g, M, C, eps, momentum, mean, rstd, running_mean, running_var, num_batches_tracked)
   BN_DISPATCH(dtype, GO(float), GO(bf16_t));
 #undef GO
   return coin_launch_status();

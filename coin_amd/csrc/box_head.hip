@@ -215,6 +215,47 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in
   }
 }
 
+// Data-gradient layout of every convolution / linear weight in ONE launch: dst[ci][ks-1-ky][ks-1-kx][co] = src[co][ky][kx][ci]
+// (bf16; src = the channels-last compute shadow of a conv weight, or a linear weight [N, K] with ks = 1, i.e. its transpose).
+// The dgrad GEMMs (coin_conv_gemm_bf16 / coin_gemm_nt with B = W^T) read these; before, every backward call re-laid its weight with
+// flip + permute + copy launches (46 + 11 per step).  grid = (max tiles over the table, entries); 64 x 64 tiles through LDS.
+__global__ __launch_bounds__(256) void weight_dgrad_layout_kernel(const coin_wd_tensor* __restrict__ table) {
+  __shared__ uint16_t tile[64][72];   // row pitch 144 B: 16-byte aligned rows, column reads spread over the banks
+  const coin_wd_tensor t = table[blockIdx.y];
+  const int tco = (t.cout + 63) >> 6, tci = (t.cin + 63) >> 6;
+  const int per_tap = tco * tci;
+  if ((int)blockIdx.x >= per_tap * t.ks * t.ks) return;
+  const int tap = blockIdx.x / per_tap, rem = blockIdx.x - tap * per_tap;
+  const int co0 = (rem / tci) << 6, ci0 = (rem % tci) << 6;
+  const int ftap = t.ks * t.ks - 1 - tap;   // (ks-1-ky) * ks + (ks-1-kx)
+  const int taps = t.ks * t.ks;
+  // load: thread -> (row = co, 16-byte chunk of 8 ci); cin % 8 == 0
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = it * 256 + threadIdx.x, r = idx >> 3, c = (idx & 7) << 3;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (co0 + r < t.cout && ci0 + c < t.cin) v = *reinterpret_cast<const uint4*>(t.src + ((size_t)(co0 + r) * taps + tap) * t.cin + ci0 + c);
+    *reinterpret_cast<uint4*>(&tile[r][c]) = v;
+  }
+  __syncthreads();
+  // store: thread -> (row = ci, 8 consecutive co); cout % 8 == 0
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = it * 256 + threadIdx.x, r = idx >> 3, c = (idx & 7) << 3;
+    if (ci0 + r < t.cin && co0 + c < t.cout) {
+      uint16_t o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = tile[c + k][r];
+      uint4 v;
+      v.x = o[0] | ((uint32_t)o[1] << 16);
+      v.y = o[2] | ((uint32_t)o[3] << 16);
+      v.z = o[4] | ((uint32_t)o[5] << 16);
+      v.w = o[6] | ((uint32_t)o[7] << 16);
+      *reinterpret_cast<uint4*>(t.dst + ((size_t)(ci0 + r) * taps + ftap) * t.cout + co0 + c) = v;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // bias + activation backward
 // ------------------------------------------------------------------------------------------
@@ -398,6 +439,14 @@ extern "C" int coin_transpose2d(const void* in, void* out, int M, int N, int dty
     transpose_kernel<float><<<grid, 256, 0, st>>>((const float*)in, (float*)out, M, N);
   else
     transpose_kernel<uint16_t><<<grid, 256, 0, st>>>((const uint16_t*)in, (uint16_t*)out, M, N);
+  return coin_launch_status();
+}
+
+extern "C" int coin_weight_dgrad_layout(const coin_wd_tensor* table, int num_tensors, int max_tiles, void* stream) {
+  if (num_tensors < 0 || max_tiles < 0 || (num_tensors > 0 && !table)) return COIN_EINVAL;
+  if (num_tensors == 0 || max_tiles == 0) return COIN_OK;
+  if (num_tensors > 65535) return COIN_ESHAPE;
+  weight_dgrad_layout_kernel<<<dim3(max_tiles, num_tensors), 256, 0, (hipStream_t)stream>>>(table);
   return coin_launch_status();
 }
 

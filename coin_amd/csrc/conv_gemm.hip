@@ -605,8 +605,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 __global__ __launch_bounds__(1024) void conv_stats_finalize_kernel(const float* __restrict__ part, int tiles_m, int N, int64_t rows,
                                                                     float eps, float momentum, float* __restrict__ mean,
                                                                     float* __restrict__ rstd, float* __restrict__ running_mean,
-                                                                    float* __restrict__ running_var) {
+                                                                    float* __restrict__ running_var, int64_t* __restrict__ nbt) {
   __shared__ float red[64][3][16];
+  if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;   // nn.BatchNorm2d's counter rides along (it was a launch of its own)
   const int c16 = threadIdx.x & 15, tl = threadIdx.x >> 4;  // tile lane 0..63
   const int c = blockIdx.x * 16 + c16;
   float n_a = 0.f, mu_a = 0.f, m2_a = 0.f;
@@ -748,11 +749,11 @@ extern "C" int coin_conv_gemm_bf16_ws(const void* A, int lda, int mode, int H, i
 }
 
 extern "C" int coin_conv_gemm_stats_finalize(const float* partials, int M, int N, int64_t rows, float eps, float momentum, float* mean,
-                                             float* rstd, float* running_mean, float* running_var, void* stream) {
+                                             float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream) {
   if (!partials || !mean || !rstd || M <= 0 || N <= 0 || rows <= 0 || rows > M) return COIN_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return COIN_EINVAL;
   conv_stats_finalize_kernel<<<(N + 15) / 16, 1024, 0, (hipStream_t)stream>>>(partials, (M + GM - 1) / GM, N, rows, eps, momentum, mean, rstd,
-                                                                             running_mean, running_var);
+                                                                             running_mean, running_var, num_batches_tracked);
   return coin_launch_status();
 }
 

@@ -355,14 +355,21 @@ def roi_align_bwd_level(grad_out: torch.Tensor, rois: torch.Tensor, levels: torc
     return g
 
 
+def _nbt(t: Optional[torch.Tensor]):
+    if t is not None and (t.dtype != torch.int64 or t.numel() != 1):
+        raise CoinHipError("num_batches_tracked must be a one-element int64 tensor")
+    return t
+
+
 def conv_stats_finalize(part: torch.Tensor, m: int, n: int, rows: int, eps: float, momentum: float,
-                        running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None):
-    """Per-channel batch mean / rstd (+ in-place running statistics) from `conv_gemm`'s partials."""
-    _dev(part, running_mean, running_var)
+                        running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None,
+                        num_batches_tracked: Optional[torch.Tensor] = None):
+    """Per-channel batch mean / rstd (+ in-place running statistics, + the module's batch counter) from `conv_gemm`'s partials."""
+    _dev(part, running_mean, running_var, _nbt(num_batches_tracked))
     mean = torch.empty(n, dtype=torch.float32, device=part.device)
     rstd = torch.empty(n, dtype=torch.float32, device=part.device)
     check(_lib.lib().coin_conv_gemm_stats_finalize(_p(part), m, n, int(rows), float(eps), float(momentum), _p(mean), _p(rstd), _p(running_mean),
-                                                   _p(running_var), _stream()), "coin_conv_gemm_stats_finalize")
+                                                   _p(running_var), _p(num_batches_tracked), _stream()), "coin_conv_gemm_stats_finalize")
     return mean, rstd
 
 
@@ -550,16 +557,16 @@ def _nhwc(t: torch.Tensor, name: str):
 
 
 def bn_stats(x: torch.Tensor, eps: float, momentum: float, running_mean: Optional[torch.Tensor] = None,
-             running_var: Optional[torch.Tensor] = None):
-    """Batch mean / rstd of x [N,H,W,C] (+ in-place running-statistics update)."""
-    _dev(x, running_mean, running_var)
+             running_var: Optional[torch.Tensor] = None, num_batches_tracked: Optional[torch.Tensor] = None):
+    """Batch mean / rstd of x [N,H,W,C] (+ in-place running-statistics update, + the module's batch counter)."""
+    _dev(x, running_mean, running_var, _nbt(num_batches_tracked))
     n, h, w, c = _nhwc(x, "x")
     ws = torch.empty(BN_MAX_PARTS * 2 * c, dtype=torch.float32, device=x.device)
     mean = torch.empty(c, dtype=torch.float32, device=x.device)
     rstd = torch.empty(c, dtype=torch.float32, device=x.device)
     with _timed("coin_bn_stats", _nbytes(x)):
         check(_lib.lib().coin_bn_stats(_p(x), n, h, w, c, float(eps), float(momentum), _p(ws), _p(mean), _p(rstd), _p(running_mean),
-                                       _p(running_var), _dt(x), _stream()), "coin_bn_stats")
+                                       _p(running_var), _p(num_batches_tracked), _dt(x), _stream()), "coin_bn_stats")
     return mean, rstd
 
 
@@ -808,6 +815,27 @@ class SgdTable:
         check(_lib.lib().coin_sgd_step(_p(self._dev), len(self.params), self.max_numel, float(momentum),
                                        float(inv_loss_scale), float(lr_scale), int(self.first), _stream()), "coin_sgd_step")
         self.first = False
+
+
+class WdTable:
+    """Device table for `coin_weight_dgrad_layout`: (bf16 source weight, bf16 destination in the data-gradient layout, cout, cin, ks)."""
+
+    def __init__(self, entries):
+        self.n = len(entries)
+        host = (_lib.WdTensor * max(self.n, 1))()
+        self.max_tiles = 0
+        for i, (src, dst, cout, cin, ks) in enumerate(entries):
+            _dev(src, dst)
+            if src.dtype != torch.bfloat16 or dst.dtype != torch.bfloat16 or cout % 8 or cin % 8 or src.numel() != cout * cin * ks * ks or dst.numel() != src.numel():
+                raise CoinHipError("weight_dgrad_layout: bf16 weights with cout % 8 == 0 and cin % 8 == 0")
+            host[i].src, host[i].dst, host[i].cout, host[i].cin, host[i].ks = src.data_ptr(), dst.data_ptr(), cout, cin, ks
+            self.max_tiles = max(self.max_tiles, ks * ks * ((cout + 63) // 64) * ((cin + 63) // 64))
+        self._keep = entries
+        self._dev = torch.frombuffer(memoryview(host).cast("B"), dtype=torch.uint8).to(entries[0][0].device) if self.n else None
+
+    def run(self):
+        if self.n:
+            check(_lib.lib().coin_weight_dgrad_layout(_p(self._dev), self.n, self.max_tiles, _stream()), "coin_weight_dgrad_layout")
 
 
 class EmaTable:

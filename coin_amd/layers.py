@@ -74,12 +74,84 @@ def invalidate_storage(ptrs) -> None:
     for e in _SHADOWS.values():
         if e.ptr in ptrs:
             e.version = -1
+    for k in [k for k, e in _DGRAD.items() if e.ptr in ptrs]:
+        _DGRAD[k].version = -1
     for cache in _DERIVED_CACHES:   # entries are (key, ...) with key = ((data_ptr, _version), ..., [dtype])
         for k in [k for k, hit in cache.items() if any(isinstance(it, tuple) and it[0] in ptrs for it in hit[0])]:
             cache.pop(k, None)
 
 
 _DERIVED_CACHES: list = []   # per-module constants derived from parameters / buffers, keyed by (data_ptr, _version) tuples
+
+
+# --------------------------------------------------------------------------- data-gradient layouts of the weights
+# dX of a convolution / linear layer is the same contraction over (flipped tap, Cout) with the weight re-laid [Cin][ky'][kx'][Cout]
+# (a linear weight [N, K]: its transpose).  The re-layout used to be issued per backward call (flip + permute + copy: 46 + 11 launches
+# per step).  Now every weight that has been differentiated once keeps a persistent bf16 copy in that layout, and ONE launch
+# (coin_weight_dgrad_layout over a device table) rewrites all of them from the compute shadows, lazily at the first backward use after
+# an optimizer step (`weights_updated`).
+class _Dgrad:
+    __slots__ = ("ref", "tensor", "src", "version", "ptr", "dims")
+
+
+_DGRAD: dict = {}
+_DGRAD_STATE = {"dirty": False, "table": None, "event": None, "stream": None}
+
+
+def weights_updated() -> None:
+    """Called by the optimizer after its (raw-pointer) update of masters and shadows: the dgrad layouts are stale."""
+    if _DGRAD:
+        _DGRAD_STATE["dirty"] = True
+
+
+def _dgrad_reference(wq: torch.Tensor, ks: int) -> torch.Tensor:
+    if wq.dim() == 2:
+        return wq.t().contiguous()
+    co, ci = wq.shape[0], wq.shape[1]
+    return wq.flip(2, 3).permute(1, 2, 3, 0).contiguous().reshape(ci, ks * ks * co)
+
+
+def dgrad_weight(param: Optional[torch.Tensor], wq: torch.Tensor, ks: int) -> torch.Tensor:
+    """`wq` (bf16 compute copy of `param`: conv weight [Co, Ci, k, k] in channels-last memory, or linear weight [N, K]) in the
+    data-gradient layout [Ci, k*k*Co] (linear: [K, N])."""
+    co, ci = wq.shape[0], wq.shape[1]
+    dense = wq.is_contiguous() if wq.dim() == 2 else wq.is_contiguous(memory_format=torch.channels_last)
+    if param is None or not wq.is_cuda or wq.dtype != torch.bfloat16 or co % 8 or ci % 8 or not dense:
+        return _dgrad_reference(wq, ks)
+    e = _DGRAD.get(id(param))
+    if e is not None and (e.ref() is not param or e.src.data_ptr() != wq.data_ptr() or e.dims != (co, ci, ks)):
+        e = None
+    if e is None:
+        e = _Dgrad()
+        e.ref = weakref.ref(param, lambda _r, k=id(param): (_DGRAD.pop(k, None), _DGRAD_STATE.__setitem__("table", None)))
+        e.tensor = torch.empty((ci, ks * ks * co), dtype=torch.bfloat16, device=wq.device)
+        e.src, e.dims, e.version, e.ptr = wq, (co, ci, ks), -1, 0
+        _DGRAD[id(param)] = e
+        _DGRAD_STATE["table"] = None
+    st = _DGRAD_STATE
+    if st["dirty"]:
+        # one launch for every registered weight, on the stream of the first backward node that needs one; nodes on other streams wait
+        if st["table"] is None:
+            live = [x for x in _DGRAD.values() if x.ref() is not None]
+            st["table"] = K.WdTable([(x.src, x.tensor, *x.dims) for x in live])
+            st["live"] = live
+        st["table"].run()
+        for x in st["live"]:
+            p = x.ref()
+            if p is not None:
+                x.version, x.ptr = p._version, p.data_ptr()
+        st["dirty"] = False
+        st["stream"] = torch.cuda.current_stream(wq.device)
+        st["event"] = torch.cuda.Event()
+        st["event"].record(st["stream"])
+    elif st["event"] is not None and torch.cuda.current_stream(wq.device) != st["stream"]:
+        torch.cuda.current_stream(wq.device).wait_event(st["event"])
+    if e.version != param._version or e.ptr != param.data_ptr():
+        # first use, or the master was written by something other than the fused SGD kernel (init, load_state_dict)
+        with torch.no_grad():
+            e.tensor.copy_(_dgrad_reference(wq, ks))
+        e.version, e.ptr = param._version, param.data_ptr()
+    return e.tensor
 
 
 class _ShadowCast(Function):
@@ -158,6 +230,7 @@ class _ConvGemm(Function):
         out, part = K.conv_gemm(xn.reshape(n * h * w, c), wk, spatial=(h, w, c) if ks == 3 else None, stats_rows=stats_rows)
         ctx.save_for_backward(x, wq)
         ctx.ks = ks
+        ctx.param = weakref.ref(weight)
         if part is None:
             part = out.new_zeros(0, dtype=torch.float32)
         ctx.mark_non_differentiable(part)
@@ -173,19 +246,20 @@ class _ConvGemm(Function):
         gyn = _as_nhwc(gy)
         if gyn.dtype != torch.bfloat16:
             gyn = gyn.to(torch.bfloat16)
-        dx, dw = _conv_gemm_grads(x, wq, gyn, ctx.ks, ctx.needs_input_grad[0], ctx.needs_input_grad[1], g_tap)
+        dx, dw = _conv_gemm_grads(x, wq, gyn, ctx.ks, ctx.needs_input_grad[0], ctx.needs_input_grad[1], g_tap, param=ctx.param())
         return dx, dw, None, None, None
 
 
-def _conv_gemm_grads(x, wq, gyn, ks, need_dx, need_dw, g_tap=None):
-    """(dx, dw) of the GEMM convolutions; gyn: bf16 NHWC gradient of the output, x: the saved (logical NCHW) input, wq: bf16 weight."""
+def _conv_gemm_grads(x, wq, gyn, ks, need_dx, need_dw, g_tap=None, param=None):
+    """(dx, dw) of the GEMM convolutions; gyn: bf16 NHWC gradient of the output, x: the saved (logical NCHW) input, wq: bf16 weight,
+    param: the fp32 master of wq (key of the persistent data-gradient layout)."""
     pad = ks // 2
     n, h, w, co = gyn.shape
     ci = wq.shape[1]
     dx = dw = None
     if need_dx:
-        # dgrad = the same contraction over (flipped tap, Cout): weight re-laid [Cin][ky'][kx'][Cout] (a few MB, once per call)
-        wd = wq.flip(2, 3).permute(1, 2, 3, 0).contiguous().reshape(ci, ks * ks * co)
+        # dgrad = the same contraction over (flipped tap, Cout): weight re-laid [Cin][ky'][kx'][Cout] (persistent copy, see dgrad_weight)
+        wd = dgrad_weight(param, wq, ks)
         res = None
         if g_tap is not None:
             res = _as_nhwc(g_tap)
@@ -221,6 +295,7 @@ class _ConvGemmBiasRelu(Function):
         y = K.bn_apply_fwd(z.view(n, h, w, co), zero, one, one, bias.detach().float().contiguous(), None, True, 1)
         ctx.save_for_backward(x, wq, y)
         ctx.ks = ks
+        ctx.param = weakref.ref(weight)
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -232,7 +307,7 @@ class _ConvGemmBiasRelu(Function):
             gyn = gyn.to(torch.bfloat16)
         n, h, w, co = gyn.shape
         dz, dbias = K.bias_act_bwd(gyn.reshape(n * h * w, co), y.view(n * h * w, co), K.ACT_RELU)
-        dx, dw = _conv_gemm_grads(x, wq, dz.view(n, h, w, co), ctx.ks, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dx, dw = _conv_gemm_grads(x, wq, dz.view(n, h, w, co), ctx.ks, ctx.needs_input_grad[0], ctx.needs_input_grad[1], param=ctx.param())
         return dx, dw, (dbias if ctx.needs_input_grad[2] else None), None
 
 
@@ -400,7 +475,7 @@ class _BNAct(Function):
     as two HIP streams forward and two backward (coin_bn_stats / coin_bn_apply_fwd / coin_bn_bwd)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, pool, stats_part=None):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, pool, stats_part=None, nbt=None):
         xn = _as_nhwc(x)
         rn = _as_nhwc(residual) if residual is not None else None
         g, b = gamma.float().contiguous(), beta.float().contiguous()
@@ -409,9 +484,9 @@ class _BNAct(Function):
         if stats_part is not None:  # taken in the producing convolution's epilogue (coin_conv_gemm_bf16) over the same valid rows
             part, rows = stats_part
             assert rows == (xn.shape[0] if nv is None else nv) * xn.shape[1] * xn.shape[2]
-            mean, rstd = K.conv_stats_finalize(part, xn.shape[0] * xn.shape[1] * xn.shape[2], xn.shape[3], rows, eps, momentum, running_mean, running_var)
+            mean, rstd = K.conv_stats_finalize(part, xn.shape[0] * xn.shape[1] * xn.shape[2], xn.shape[3], rows, eps, momentum, running_mean, running_var, nbt)
         else:
-            mean, rstd = K.bn_stats(xn if nv is None else xn[:nv], eps, momentum, running_mean, running_var)
+            mean, rstd = K.bn_stats(xn if nv is None else xn[:nv], eps, momentum, running_mean, running_var, nbt)
         y = K.bn_apply_fwd(xn, mean, rstd, g, b, rn, relu, pool)
         ctx.relu, ctx.pool, ctx.has_res, ctx.nv = relu, pool, residual is not None, nv
         # pool 1: the saved output is only needed for the ReLU mask when a residual was added (otherwise coin_bn_bwd recomputes
@@ -444,7 +519,7 @@ class _BNAct(Function):
                 dres = torch.zeros_like(xn)
                 dres[:nv] = dresv
         return (dx.permute(0, 3, 1, 2), dgamma, dbeta, dres.permute(0, 3, 1, 2) if dres is not None else None,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
 def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm2d, relu: bool, residual: Optional[torch.Tensor] = None, pool: int = 1,
@@ -455,11 +530,14 @@ def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm2d, relu: bool, residual: Opti
     if bn.training:
         if bn.momentum is None:
             raise CoinHipError("cumulative-average BatchNorm (momentum=None) is not used by the reference")
-        if bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
         rm = bn.running_mean if bn.track_running_stats else None
         rv = bn.running_var if bn.track_running_stats else None
-        return _BNAct.apply(x, bn.weight, bn.bias, residual, rm, rv, float(bn.momentum), float(bn.eps), bool(relu), int(pool), stats_part)
+        nbt = bn.num_batches_tracked if bn.track_running_stats else None
+        if nbt is not None and not nbt.is_cuda:
+            nbt.add_(1)
+            nbt = None
+        # (on the device the counter is incremented by the launch that updates the running statistics: 42 `add_` launches per step before)
+        return _BNAct.apply(x, bn.weight, bn.bias, residual, rm, rv, float(bn.momentum), float(bn.eps), bool(relu), int(pool), stats_part, nbt)
     # eval mode (teacher inference): a per-channel affine map with the running statistics
     if x.is_cuda and not (torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad)):
         # no gradient wanted: the fused apply kernel with (running_mean, 1/sqrt(running_var + eps)) as the statistics
@@ -541,6 +619,7 @@ class _LinearAct(Function):
             wq = weight.to(x.dtype) if weight.dtype != x.dtype else weight
         y = K.gemm_nt(x, wq.contiguous(), bias.float() if bias is not None else None, act, alpha, out_dtype=out_dtype)
         ctx.act, ctx.alpha, ctx.has_bias = act, alpha, bias is not None
+        ctx.param = weakref.ref(weight)
         ctx.save_for_backward(x, wq, y if act != ACT_NONE else None)
         return y
 
@@ -566,7 +645,8 @@ class _LinearAct(Function):
         kmult = 64 if x.dtype == torch.bfloat16 else 16
         if ctx.needs_input_grad[0]:
             # dX[M,K] = dZ[M,N] . W[N,K]  ==  gemm_nt(dZ, W^T[K,N]); contraction N padded to the MFMA K-step
-            wt = K.transpose2d(wq)                      # [K, N]
+            # [K, N]: the persistent data-gradient layout (ks = 1) where the shape allows it, else a transposed copy per call
+            wt = dgrad_weight(ctx.param(), wq, 1) if (n % kmult == 0 and wq.is_contiguous()) else K.transpose2d(wq)
             if n % kmult:
                 padn = kmult - n % kmult
                 dzp = torch.cat([dz, dz.new_zeros(dz.shape[0], padn)], dim=1)

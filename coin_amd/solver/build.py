@@ -106,6 +106,7 @@ class FusedSGD:
                              lr_scale=1.0 if factor is None else factor, shadows=shadows)
         else:  # groups were edited independently: fall back to uploading the absolute rates
             self._table.step(grads, self.momentum, inv_loss_scale, lrs=[g["lr"] for g in self.param_groups], shadows=shadows)
+        L.weights_updated()   # the persistent data-gradient layouts are re-derived by ONE launch at the next backward
 
     def load_momentum(self, bufs):
         """Momentum buffers from a checkpoint (None entries = that tensor has not been stepped yet)."""

@@ -134,6 +134,8 @@ int coin_bias_act_bwd(const void* dC, const void* C, void* dZ, int ld, int M, in
  *                     pool == 2 writes y [N,H/2,W/2,C] (floor, as nn.AvgPool2d(2)); residual requires pool != 2.
  *                     pool == 0 writes only the spatial mean y [N,C] (the RoI head's `x.mean(dim=[2,3])`,
  *                     coin/modeling/roi_heads/clip_roi_heads.py:207-208): the activation itself is never stored.
+ *                     num_batches_tracked (may be NULL): the module's int64 counter, incremented by the same launch that
+ *                     updates the running statistics (nn.BatchNorm2d does `num_batches_tracked += 1` as a launch of its own).
  * coin_bn_bwd       : given dy (shape of y) computes dsums[0..C) = dbeta, dsums[C..2C) = dgamma (dsums must hold
  *                     (COIN_BN_MAX_PARTS+1)*2*C floats: the result followed by the partial sums), dx (shape of x)
  *                     and, if d_residual != NULL, d_residual = dy * relu'  (shape of y, pool == 1).
@@ -145,7 +147,8 @@ int coin_bias_act_bwd(const void* dC, const void* C, void* dZ, int ld, int M, in
  * ---------------------------------------------------------------------------------------- */
 #define COIN_BN_MAX_PARTS 512
 int coin_bn_stats(const void* x, int N, int H, int W, int C, float eps, float momentum, float* sums_workspace,
-                  float* mean, float* rstd, float* running_mean, float* running_var, int dtype, void* stream);
+                  float* mean, float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, int dtype,
+                  void* stream);
 int coin_bn_apply_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                       const void* residual, void* y, int N, int H, int W, int C, int relu, int pool, int dtype,
                       void* stream);
@@ -201,7 +204,8 @@ int coin_conv_gemm_bf16_ws(const void* A, int lda, int mode, int H, int W, int C
                            void* C, int ldc, const void* R, int ldr, int M, int N, int K, float* stats, int64_t stats_rows,
                            void* workspace, size_t workspace_bytes, void* stream);
 int coin_conv_gemm_stats_finalize(const float* partials, int M, int N, int64_t rows, float eps, float momentum,
-                                  float* mean, float* rstd, float* running_mean, float* running_var, void* stream);
+                                  float* mean, float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                  void* stream);
 
 /* Weight gradient of the same convolutions: dW[Cout][Ktot] (fp32, OVERWRITTEN) = gy[M,Cout]^T . Acol[M,Ktot] with Acol as in
  * coin_conv_gemm_bf16 (mode 0: Ktot = Cin; mode 1: Ktot = 9*Cin, (ky, kx, ci) = the channels-last weight layout).  gy and x are the
@@ -395,6 +399,17 @@ typedef struct coin_sgd_tensor {
 
 int coin_sgd_step(const coin_sgd_tensor* table, int num_tensors, int64_t max_numel, float momentum,
                   float inv_loss_scale, float lr_scale, int first_step, void* stream);
+
+/* Data-gradient layout of convolution / linear weights, all tensors of a DEVICE table in one launch (replaces the per-call
+ * flip + permute + copy of the weight in the backward of the res5 / RPN / box-head layers, coin/modeling/utils.py:77-90 under autograd):
+ *   dst[ci][ks-1-ky][ks-1-kx][co] = src[co][ky][kx][ci]     bf16; ks = 1 is the plain transpose of a linear weight [N, K].
+ * cout % 8 == 0, cin % 8 == 0, 16-byte aligned src / dst.  max_tiles >= ks*ks*ceil(cout/64)*ceil(cin/64) of every entry. */
+typedef struct coin_wd_tensor {
+  const uint16_t* src;
+  uint16_t* dst;
+  int32_t cout, cin, ks, reserved;
+} coin_wd_tensor;
+int coin_weight_dgrad_layout(const coin_wd_tensor* table, int num_tensors, int max_tiles, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Teacher EMA (replaces EnsembleTSModel.update_params, coin/modeling/meta_arch/ts_ensemble.py:39-69)

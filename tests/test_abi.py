@@ -60,6 +60,7 @@ def test_version_arch_and_workspace_query(lib):
 
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.SgdTensor) == 48 and ctypes.sizeof(_lib.EmaTensor) == 24
+    assert ctypes.sizeof(_lib.WdTensor) == 32 and _lib.WdTensor.cout.offset == 16
     assert ctypes.sizeof(_lib.RoiLevel) == 24 and _lib.RoiLevel.H.offset == 8 and _lib.RoiLevel.spatial_scale.offset == 16
 
 
@@ -71,6 +72,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.coin_nms_batched(None, None, 1, 20000, 0.5, 10, None, None, None, None) == -1
     assert lib.coin_conv_gemm_bf16(None, 64, 0, 0, 0, 0, None, 64, None, 8, None, 0, 256, 8, 64, None, 0, None) == -1
     assert lib.coin_conv_gemm_stats_bytes(401408, 512) == 1568 * 3 * 512 * 4
+    assert lib.coin_weight_dgrad_layout(None, 3, 8, None) == -1 and lib.coin_weight_dgrad_layout(None, 0, 0, None) == 0
     assert lib.coin_roi_align_fwd_levels(None, 4, 1, 8, None, None, 1, 7, 7, 0, 1, None, 1, None) == -1
     assert lib.coin_roi_align_bwd_level(None, 1, 8, 4, 4, None, None, 0, 1, 7, 7, 0.25, 0, 1, None, 1, None) == -1
     assert lib.coin_window_attn_bwd(None, None, None, None, None, None, None, 4, 1, 3, 49, 32, 0.17, None) == -1

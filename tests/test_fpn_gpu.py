@@ -121,6 +121,11 @@ def _rel(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
+def _rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
 def _oracle_grads(loss, tensors):
     return torch.autograd.grad(loss, tensors, allow_unused=False)
 
@@ -225,8 +230,21 @@ def test_multilevel_pooler_and_two_fc_on_device_vs_oracle_forward_and_gradients(
     assert _rel(pooled.float(), pooled_ref) < (1e-5 if dtype == "fp32" else 1e-2), _rel(pooled.float(), pooled_ref)
     assert _rel(out.float(), ref) < ftol, _rel(out.float(), ref)
     got = [f.grad for f in fd] + [dict(head.named_parameters())[k].grad for k in names]
+    # bf16: a hidden unit whose pre-activation (a 12 544-term bf16 dot product) lies within rounding of zero takes the other ReLU branch
+    # than the float64 oracle; ~3 of the ~500 active units of a row flip, i.e. sqrt(3 / 500) ~ 8 % of the gradient's L2 norm is inherent to
+    # the precision, not to the kernels -- so the bf16 run holds the gradients THROUGH THE HEAD to 15 % in L2 and checks the pooler's own
+    # backward (no ReLU behind it) separately and tightly below; the fp32 run holds everything to 3e-4 in the max norm
     for name, a, b in zip([f"p{i + 2}" for i in range(4)] + names, got, gref):
-        assert a is not None and _rel(a.float(), b) < gtol, (name, _rel(a.float(), b))
+        e = _rel(a.float(), b) if dtype == "fp32" else _rel_l2(a.float(), b)
+        assert a is not None and e < (gtol if dtype == "fp32" else 0.15), (name, e)
+    if dtype == "bf16":
+        w_pool = torch.randn(n, 256, 7, 7, generator=g)
+        gref_p = _oracle_grads((O.multilevel_roi_align(f64, strides, rois, 7) * w_pool.double()).sum(), f64)
+        for f in fd:
+            f.grad = None
+        (pool(fd, rois.cuda()).float() * w_pool.cuda()).sum().backward()
+        for i, (f, b) in enumerate(zip(fd, gref_p)):
+            assert _rel(f.grad.float(), b) < 1e-2, (f"pooler only, p{i + 2}", _rel(f.grad.float(), b))
 
 
 @pytest.mark.parametrize("dim,heads,shift,dtype", [(96, 3, 0, "bf16"), (96, 3, 3, "bf16"), (192, 6, 3, "bf16"), (96, 3, 3, "fp32")])

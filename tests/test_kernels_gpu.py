@@ -865,3 +865,92 @@ def test_roi_align_at_the_bench_shape_vs_oracle_on_sampled_rois(K):
     d2.roi_align_torch(fd, rois[pick].double(), (14, 14), 1 / 16.0, 0, True).backward(go[pick].double().permute(0, 3, 1, 2))
     gin = K.roi_align_bwd(dev(go), dev(rois), (n, h, w, c), 1 / 16.0)   # fp32 map: sums of exactly representable bf16 x fp32 weights
     torch.testing.assert_close(gin.permute(0, 3, 1, 2).cpu().double(), fd.grad, rtol=2e-4, atol=2e-4)
+
+
+# ------------------------------------------------------------------------------------------ round 4: launch-count reductions
+@pytest.mark.parametrize("co,ci,ks", [(512, 1024, 1), (2048, 512, 1), (512, 512, 3), (72, 40, 3), (1024, 2048, 1), (8, 8, 1)])
+def test_weight_dgrad_layout_one_launch_vs_torch(K, co, ci, ks):
+    """coin_weight_dgrad_layout: dst[ci][ks-1-ky][ks-1-kx][co] = src[co][ky][kx][ci] for a whole table in one launch (byte moves: exact),
+    against flip + permute of the same weights; ragged 64-tiles (72 x 40), and two entries of different size in one table."""
+    g = torch.Generator().manual_seed(co + ci + ks)
+    w_a = torch.randn(co, ci, ks, ks, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    w_b = torch.randn(64, 128, generator=g).to(torch.bfloat16).cuda()                       # a linear weight [N, K]
+    d_a = torch.full((ci, ks * ks * co), 7.0, dtype=torch.bfloat16, device="cuda")
+    d_b = torch.full((128, 64), 7.0, dtype=torch.bfloat16, device="cuda")
+    K.WdTable([(w_a, d_a, co, ci, ks), (w_b, d_b, 64, 128, 1)]).run()
+    assert torch.equal(d_a, w_a.flip(2, 3).permute(1, 2, 3, 0).contiguous().reshape(ci, ks * ks * co))
+    assert torch.equal(d_b, w_b.t().contiguous())
+
+
+def test_dgrad_weight_cache_follows_the_optimizer_and_foreign_writes(monkeypatch):
+    """layers.dgrad_weight: the persistent data-gradient layout of a conv weight is refreshed by ONE launch after `build_optimizer(...).step()`
+    (raw-pointer update of master + bf16 shadow), and recomputed when the master is written by anything else (version bump).  The input
+    gradient of the GEMM convolution must equal the one computed with a freshly re-laid weight after each kind of update."""
+    from coin_amd import layers as L
+
+    monkeypatch.setitem(L.CONV_GEMM, "enabled", True)
+    monkeypatch.setitem(L.CONV_GEMM, "min_rows", 0)
+    torch.manual_seed(5)
+    conv = torch.nn.Conv2d(256, 256, 3, padding=1, bias=False).cuda()
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    x0 = torch.randn(4, 256, 14, 14, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(4, 256, 14, 14, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def dx_now():
+        x = x0.clone().requires_grad_(True)
+        conv.weight.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y, _ = L.conv2d_gemm(x, conv)
+        y.backward(gy)
+        return x.grad.clone()
+
+    def dx_fresh():
+        wq = conv.weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        wd = wq.flip(2, 3).permute(1, 2, 3, 0).contiguous().reshape(256, 9 * 256)
+        out, _ = __import__("coin_amd.kernels", fromlist=["x"]).conv_gemm(gy.permute(0, 2, 3, 1).reshape(-1, 256), wd, spatial=(14, 14, 256))
+        return out.view(4, 14, 14, 256).permute(0, 3, 1, 2)
+
+    assert torch.equal(dx_now(), dx_fresh())                       # first use: computed with torch ops
+    assert len(L._DGRAD) >= 1
+    # (1) the product's optimizer: fused SGD writes master + shadow through raw pointers, `weights_updated` marks the layouts stale
+    from coin_amd.config import get_cfg
+    from coin_amd.solver import build_optimizer
+
+    cfg = get_cfg()
+    cfg.merge_from_list(["SOLVER.BASE_LR", 0.5, "SOLVER.MOMENTUM", 0.9, "SOLVER.WEIGHT_DECAY", 0.0])
+    opt = build_optimizer(cfg, conv)
+    dx_now()
+    before = conv.weight.detach().clone()
+    opt.step()
+    assert not torch.equal(before, conv.weight.detach())
+    assert L._DGRAD_STATE["dirty"]
+    assert torch.equal(dx_now(), dx_fresh()) and not L._DGRAD_STATE["dirty"]
+    # (2) a foreign in-place write (version bump): recomputed lazily
+    with torch.no_grad():
+        conv.weight.mul_(-1.5)
+    assert torch.equal(dx_now(), dx_fresh())
+
+
+def test_bn_counter_is_incremented_by_the_statistics_launch(monkeypatch):
+    """nn.BatchNorm2d.num_batches_tracked (utils.py:77-90 under train()): incremented by coin_bn_stats / coin_conv_gemm_stats_finalize
+    themselves -- once per training forward on either statistics path, not at all in eval mode."""
+    from coin_amd import layers as L
+
+    torch.manual_seed(6)
+    bn = torch.nn.BatchNorm2d(256).cuda().train()
+    x = torch.randn(4, 256, 14, 14, device="cuda").contiguous(memory_format=torch.channels_last)
+    for i in range(3):
+        L.bn_act(x, bn, True)
+        assert int(bn.num_batches_tracked) == i + 1
+    monkeypatch.setitem(L.CONV_GEMM, "enabled", True)
+    monkeypatch.setitem(L.CONV_GEMM, "min_rows", 0)
+    conv = torch.nn.Conv2d(256, 256, 1, bias=False).cuda()
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        L.conv_bn_act(x.to(torch.bfloat16), conv, bn, True)         # statistics from the GEMM epilogue -> the finalize kernel counts
+    assert int(bn.num_batches_tracked) == 4
+    rm = bn.running_mean.clone()
+    bn.eval()
+    with torch.no_grad():
+        L.bn_act(x, bn, True)
+    assert int(bn.num_batches_tracked) == 4 and torch.equal(rm, bn.running_mean)

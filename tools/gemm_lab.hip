@@ -163,8 +163,8 @@ static int check_case(const char* name, int M, int N, int K, int mode, int H, in
   if (stats_rows > 0) {
     float *m0, *r0, *m1, *r1;
     CK(hipMalloc(&m0, N * 4)); CK(hipMalloc(&r0, N * 4)); CK(hipMalloc(&m1, N * 4)); CK(hipMalloc(&r1, N * 4));
-    coin_conv_gemm_stats_finalize(S0, M, N, stats_rows, 1e-5f, 0.1f, m0, r0, nullptr, nullptr, nullptr);
-    coin_conv_gemm_stats_finalize(S1, M, N, stats_rows, 1e-5f, 0.1f, m1, r1, nullptr, nullptr, nullptr);
+    coin_conv_gemm_stats_finalize(S0, M, N, stats_rows, 1e-5f, 0.1f, m0, r0, nullptr, nullptr, nullptr, nullptr);
+    coin_conv_gemm_stats_finalize(S1, M, N, stats_rows, 1e-5f, 0.1f, m1, r1, nullptr, nullptr, nullptr, nullptr);
     CK(hipDeviceSynchronize());
     std::vector<float> a(N), b(N), c(N), d(N);
     CK(hipMemcpy(a.data(), m0, N * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), m1, N * 4, hipMemcpyDeviceToHost));
