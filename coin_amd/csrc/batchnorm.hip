@@ -281,15 +281,20 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_mean_kernel(const T* __re
 //           is recomputed from x (same expression as bn_apply_kernel) and y is never read.
 //   POOL 2: dy is [N,H/2,W/2,C]; mask recomputed from x.
 //   POOL 0: dy is [N,C] (global mean); `yout` carries the forward's RESIDUAL input (or NULL); mask recomputed.
-template <typename T, int POOL>
-__device__ __forceinline__ void upstream(const T* __restrict__ dy, const T* __restrict__ yout, const float (&xv)[Ld<T>::V],
+// MODE (compile time, so that the row loops are branch-free and the loads of several rows are issued together): bit 0 = ReLU,
+// bit 1 = `yout` is present (POOL 1: the saved output supplies the mask; POOL 0: the forward's residual input).
+template <typename T, int POOL, int MODE>
+__device__ __forceinline__ void upstream(const T* __restrict__ dy, const T* __restrict__ yout_, const float (&xv)[Ld<T>::V],
                                          const float (&sc)[Ld<T>::V], const float (&sh)[Ld<T>::V], int64_t r, int H, int W, int C,
-                                         size_t coff, int relu, float (&g)[Ld<T>::V]) {
+                                         size_t coff, float (&g)[Ld<T>::V]) {
   constexpr int V = Ld<T>::V;
+  constexpr bool relu = (MODE & 1) != 0;
+  constexpr bool HAS_Y = (MODE & 2) != 0;
+  const T* __restrict__ yout = yout_;
   if (POOL == 1) {
     const size_t off = (size_t)r * C + coff;
     Ld<T>::load(dy + off, g);
-    if (relu && yout) {
+    if (relu && HAS_Y) {
       float yv[V];
       Ld<T>::load(yout + off, yv);
 #pragma unroll
@@ -304,10 +309,10 @@ __device__ __forceinline__ void upstream(const T* __restrict__ dy, const T* __re
     Ld<T>::load(dy + (size_t)n * C + coff, g);
     const float inv = 1.0f / (float)hw;
     float rr[V];
-    if (yout) Ld<T>::load(yout + (size_t)r * C + coff, rr);
+    if (HAS_Y) Ld<T>::load(yout + (size_t)r * C + coff, rr);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-      const float pre = xv[i] * sc[i] + sh[i] + (yout ? rr[i] : 0.f);
+      const float pre = xv[i] * sc[i] + sh[i] + (HAS_Y ? rr[i] : 0.f);
       g[i] = (relu && !(pre > 0.f)) ? 0.f : g[i] * inv;
     }
   } else {
@@ -332,7 +337,7 @@ __device__ __forceinline__ void upstream(const T* __restrict__ dy, const T* __re
 
 // ------------------------------------------------------------------------------------------ backward reductions
 // dsums[0..C) = sum g (= dbeta), dsums[C..2C) = sum g * xhat (= dgamma)
-template <typename T, int POOL>
+template <typename T, int POOL, int MODE>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                     const T* __restrict__ yout, const float* __restrict__ mean,
                                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __re
       for (int64_t r = (int64_t)blockIdx.x * rpi + slot; r < M; r += (int64_t)gridDim.x * rpi) {
         float xv[V], g[V];
         Ld<T>::load(x + (size_t)r * C + coff, xv);
-        upstream<T, POOL>(dy, yout, xv, sc, sh, r, H, W, C, coff, relu, g);
+        upstream<T, POOL, MODE>(dy, yout, xv, sc, sh, r, H, W, C, coff, g);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
           db[i] += g[i];
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(float* __restrict
 }
 
 // dx = gamma * rstd * (g - dbeta/M - xhat * dgamma/M);  d_residual = g (forward had a residual)
-template <typename T, int POOL>
+template <typename T, int POOL, int MODE>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                 const T* __restrict__ yout, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const T* __restri
   for (int64_t r = rw.row0; r < M; r += rw.rstep) {
     float xv[V], g[V], o[V];
     Ld<T>::load(x + (size_t)r * C + coff, xv);
-    upstream<T, POOL>(dy, yout, xv, sc, sh, r, H, W, C, coff, relu, g);
+    upstream<T, POOL, MODE>(dy, yout, xv, sc, sh, r, H, W, C, coff, g);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       const float xhat = (xv[i] - mu[i]) * rs[i];
@@ -616,10 +621,21 @@ extern "C" int coin_bn_bwd(const void* x, const void* dy, const void* y, const f
   if (g > COIN_BN_MAX_PARTS) g = COIN_BN_MAX_PARTS;
   const size_t lds = sizeof(float) * BN_THREADS * 2 * v;
   const int wg = walk_grid(M, ncg);
-#define GO1(T, P)                                                                                                                  \
-  bn_bwd_reduce_kernel<T, P><<<(int)g, BN_THREADS, lds, st>>>((const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, beta, N, H, W, C, relu, dsums); \
+  const int mode = (relu ? 1 : 0) | (y ? 2 : 0);
+#define GO2(T, P, MD)                                                                                                              \
+  bn_bwd_reduce_kernel<T, P, MD><<<(int)g, BN_THREADS, lds, st>>>((const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, beta, N, H, W, C, relu, dsums); \
   bn_bwd_finalize_kernel<<<(2 * C + 63) / 64, 1024, 0, st>>>(dsums, (int)g, C);                                                      \
-  bn_bwd_dx_kernel<T, P><<<wg, BN_THREADS, 0, st>>>((const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, beta, dsums, N, H, W, C, relu, (T*)dx, (T*)d_residual)
+  bn_bwd_dx_kernel<T, P, MD><<<wg, BN_THREADS, 0, st>>>((const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, beta, dsums, N, H, W, C, relu, (T*)dx, (T*)d_residual)
+#define GO1(T, P)             \
+  if (mode == 0) {            \
+    GO2(T, P, 0);             \
+  } else if (mode == 1) {     \
+    GO2(T, P, 1);             \
+  } else if (mode == 2) {     \
+    GO2(T, P, 2);             \
+  } else {                    \
+    GO2(T, P, 3);             \
+  }
 #define GO(T)                 \
   if (pool == 1) {            \
     GO1(T, 1);                \
@@ -631,6 +647,7 @@ extern "C" int coin_bn_bwd(const void* x, const void* dy, const void* y, const f
   BN_DISPATCH(dtype, GO(float), GO(bf16_t));
 #undef GO
 #undef GO1
+#undef GO2
   return coin_launch_status();
 }
 

@@ -8,7 +8,7 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcb_$ctr
-  timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmcb_$ctr -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /tmp/pmcb_$ctr.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmcb_$ctr -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary > /tmp/pmcb_$ctr.log 2>&1
   f=$(find /tmp/pmcb_$ctr -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py "$f" "$out/pmc_bench_$ctr.csv" | grep -E "bn_bwd|roi_align|conv_gemm" ; else echo "no counter csv for $ctr"; tail -5 /tmp/pmcb_$ctr.log; fi
 done

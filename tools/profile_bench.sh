@@ -5,7 +5,7 @@
 set -u
 tag=${1:-r1}
 shift || true
-if [ $# -gt 0 ]; then prog=$1; shift; args="$*"; else prog=bench.py; args="--steps 10 --warmup 3 --no-cpu-baseline"; fi
+if [ $# -gt 0 ]; then prog=$1; shift; args="$*"; else prog=bench.py; args="--steps 10 --warmup 3 --no-cpu-baseline --no-secondary"; fi
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
