@@ -15,5 +15,6 @@ COIN_HIDDEN int coin_p8_tn_launch(const void* GY, const void* X, int mode, int H
                                   hipStream_t st);
 COIN_HIDDEN extern int coin_conv_gemm_force_impl;
 COIN_HIDDEN extern int coin_p8_debug;
+COIN_HIDDEN int coin_p8_read_stamps(long long* out, int n);
 COIN_HIDDEN extern int coin_p8_splitk;
 COIN_HIDDEN extern int coin_p8_stagger;

@@ -26,6 +26,9 @@
 #include "common.h"
 #include "conv_gemm_p8.h"
 
+// lab only (coin_p8_debug bit 6): per workgroup [sum of main-loop cycles, sum of epilogue cycles, tiles]
+__device__ long long coin_p8_stamp_buf[1024 * 4];
+
 namespace {
 
 constexpr int PM = 256, PN = 256, PK = 64;
@@ -363,6 +366,8 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(const P8Args p) {
   }
 
   int g = 0;  // K-tile sequence number of this workgroup (buffer g & 1)
+  long long st_main = 0, st_epi = 0, st_n = 0, st_t = 0;   // lab only (dbg bit 6): s_memtime split of a tile into main loop / epilogue
+  if (p.dbg & 64) st_t = __builtin_amdgcn_s_memtime();
   for (;;) {
     f32x4 acc[2][2][4][2];
 #pragma unroll
@@ -487,9 +492,21 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(const P8Args p) {
       P8_SCHED();
     }
     if (wr == 0) P8_BAR();  // both groups aligned again
+    if (p.dbg & 64) {
+      const long long t = __builtin_amdgcn_s_memtime();
+      st_main += t - st_t;
+      st_t = t;
+    }
 
     if (items.whole(item_idx)) {
       p8_epilogue<STATS>(p, acc, items.tile(item_idx), lds + P_IMG, lane, wave);
+      if (p.dbg & 64) {
+        if (p.dbg & 128) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // bit 7: the stores' drain is charged to the epilogue
+        const long long t = __builtin_amdgcn_s_memtime();
+        st_epi += t - st_t;
+        st_t = t;
+        ++st_n;
+      }
     } else {
       // split-K piece: fp32 accumulators in thread-private order (float4 index q * 512 + thread): coalesced 16-byte stores
       unsigned tid = threadIdx.x;
@@ -505,6 +522,11 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(const P8Args p) {
             for (int j = 0; j < 2; ++j) sl[(((x * 2 + y) * 4 + i) * 2 + j) * 512] = acc[x][y][i][j];
     }
     if (++item_idx >= items.n_items) break;
+  }
+  if ((p.dbg & 64) && threadIdx.x == 0 && blockIdx.x < 1024) {
+    coin_p8_stamp_buf[blockIdx.x * 4 + 0] = st_main;
+    coin_p8_stamp_buf[blockIdx.x * 4 + 1] = st_epi;
+    coin_p8_stamp_buf[blockIdx.x * 4 + 2] = st_n;
   }
 }
 
@@ -918,6 +940,7 @@ static int p8_grid(int ntiles) {
 }
 
 int coin_p8_debug = 0;  // lab hook, see TnArgs::dbg
+int coin_p8_read_stamps(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(coin_p8_stamp_buf), sizeof(long long) * 4 * (size_t)n); }
 int coin_p8_stagger = -1;  // lab hook: phases of the start-time stagger (-1: default, 0/1: off)
 int coin_p8_splitk = -1;  // lab hook: -1 = default policy, 0 = never split the tail round, 1 = split whenever it is possible
 

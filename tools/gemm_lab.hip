@@ -459,6 +459,30 @@ int main(int argc, char** argv) {
     for (const Shape& s : kShapes) bench_shape(s, iters, g_cold ? 2 : 5);
   }
   if (!strcmp(what, "dbg")) bench_debug(iters);
+  if (!strcmp(what, "stamps")) {
+    // in-kernel split of a tile's time: main loop vs epilogue (s_memtime, wave 0 lane 0 of every workgroup; coin_p8_debug bit 6;
+    // bit 7 additionally charges the drain of the tile's stores to the epilogue)
+    for (const Shape& sh : kShapes) {
+      if (getenv("LAB_SHAPES") && !strstr(getenv("LAB_SHAPES"), sh.name)) continue;
+      const int M = sh.nb * sh.h * sh.w, mode = sh.ks == 3 ? 1 : 0, K = sh.ks * sh.ks * sh.ci, N = sh.co;
+      void *A, *B, *C;
+      CK(hipMalloc(&A, (size_t)M * sh.ci * 2)); CK(hipMalloc(&B, (size_t)N * K * 2)); CK(hipMalloc(&C, (size_t)M * N * 2));
+      fill(A, (size_t)M * sh.ci, 0x1234u, 1.0f); fill(B, (size_t)N * K, 0x9876u, 0.05f);
+      for (int dbg : {64, 64 + 4, 64 + 128}) {
+        coin_p8_debug = dbg;
+        for (int i = 0; i < 3; ++i) run_gemm(1, A, sh.ci, mode, sh.h, sh.w, sh.ci, B, K, C, N, nullptr, 0, M, N, K, nullptr, 0);
+        CK(hipDeviceSynchronize());
+        std::vector<long long> st(256 * 4);
+        coin_p8_read_stamps(st.data(), 256);
+        coin_p8_debug = 0;
+        double mm = 0, ee = 0, nn = 0;
+        for (int b = 0; b < 256; ++b) { mm += st[b * 4]; ee += st[b * 4 + 1]; nn += st[b * 4 + 2]; }
+        printf("{\"shape\": \"%s\", \"dbg\": %d, \"tiles_per_wg\": %.2f, \"main_cycles_per_tile\": %.0f, \"epilogue_cycles_per_tile\": %.0f}\n", sh.name, dbg, nn / 256,
+               mm / (nn > 0 ? nn : 256), ee / (nn > 0 ? nn : 1));
+      }
+      hipFree(A); hipFree(B); hipFree(C);
+    }
+  }
   if (!strcmp(what, "wbench") || !strcmp(what, "all")) {
     for (const Shape& s : kShapes) bench_wgrad(s, iters, g_cold ? 2 : 5);
   }
