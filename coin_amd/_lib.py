@@ -86,7 +86,7 @@ SIGNATURES = {
     "coin_avgpool2_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "coin_avgpool2_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "coin_nms_batched": [_P, _P, _I, _I, _F, _I, _P, _P, _P, _P],
-    "coin_sgd_step": [_P, _I, _L, _F, _F, _F, _I, _P],
+    "coin_sgd_step": [_P, _I, _L, _F, _F, _F, _I, _P, _P],
     "coin_weight_dgrad_layout": [_P, _I, _I, _P],
     "coin_ema_update": [_P, _I, _L, _F, _P],
 }

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import functools
 import math
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -185,14 +185,35 @@ def _sizes_on_device(image_sizes, device):
 
 @torch.no_grad()
 def find_top_rpn_proposals(proposals: torch.Tensor, logits: torch.Tensor, image_sizes: List[Tuple[int, int]], nms_thresh: float,
-                           pre_nms_topk: int, post_nms_topk: int, min_box_size: float, training: bool, packed: bool = False):
-    """Single-level detectron2 find_top_rpn_proposals, batched: top-k -> clip -> drop empties -> NMS -> top-k.
-    proposals [N, A, 4], logits [N, A].  One host sync (the per-image keep counts)."""
+                           pre_nms_topk: int, post_nms_topk: int, min_box_size: float, training: bool, packed: bool = False,
+                           level_sizes: Optional[List[int]] = None):
+    """detectron2 find_top_rpn_proposals, batched: per-level top-k -> clip -> drop empties -> NMS inside each level -> top-k over all.
+    proposals [N, A, 4], logits [N, A]; `level_sizes` = anchors per feature level when A is the concatenation of several levels
+    (FPN extension): `pre_nms_topk` then applies to EVERY level and boxes of different levels never suppress each other (batched_nms
+    with the level as the group id -- the coordinate-offset form), as in detectron2's multi-level RPN.  One host sync (the keep counts)."""
     n, a = logits.shape
-    k = min(a, pre_nms_topk)
-    top_logits, idx = logits.float().sort(descending=True, dim=1)
-    top_logits, idx = top_logits[:, :k], idx[:, :k]
-    boxes = torch.gather(proposals.float(), 1, idx.unsqueeze(-1).expand(-1, -1, 4))
+    lvl = None
+    if level_sizes is not None and len(level_sizes) > 1:
+        assert sum(level_sizes) == a
+        bs, ls, ids, off = [], [], [], 0
+        for li, al in enumerate(level_sizes):
+            kl = min(al, pre_nms_topk)
+            tl, idx = logits[:, off:off + al].float().sort(descending=True, dim=1)
+            tl, idx = tl[:, :kl], idx[:, :kl]
+            bs.append(torch.gather(proposals[:, off:off + al].float(), 1, idx.unsqueeze(-1).expand(-1, -1, 4)))
+            ls.append(tl)
+            ids.append(torch.full((n, kl), li, dtype=torch.float32, device=logits.device))
+            off += al
+        # the candidates of all levels in ONE descending score order (ties: lower level first): the order NMS visits them in and the
+        # order the final top-k is taken in
+        top_logits, order = torch.cat(ls, dim=1).sort(descending=True, dim=1, stable=True)
+        boxes = torch.gather(torch.cat(bs, dim=1), 1, order.unsqueeze(-1).expand(-1, -1, 4))
+        lvl = torch.gather(torch.cat(ids, dim=1), 1, order)
+    else:
+        k = min(a, pre_nms_topk)
+        top_logits, idx = logits.float().sort(descending=True, dim=1)
+        top_logits, idx = top_logits[:, :k], idx[:, :k]
+        boxes = torch.gather(proposals.float(), 1, idx.unsqueeze(-1).expand(-1, -1, 4))
     if training and not packed and not bool(torch.isfinite(boxes).all() & torch.isfinite(top_logits).all()):
         raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")
     hw = _sizes_on_device(tuple(tuple(int(v) for v in sz) for sz in image_sizes), boxes.device)  # [N, 2] (h, w)
@@ -206,7 +227,11 @@ def find_top_rpn_proposals(proposals: torch.Tensor, logits: torch.Tensor, image_
     boxes = torch.gather(boxes, 1, order.unsqueeze(-1).expand(-1, -1, 4)).contiguous()
     top_logits = torch.gather(top_logits, 1, order)
     counts = valid.sum(dim=1).to(torch.int32)
-    keep, num = K.nms_batched(boxes, counts, nms_thresh, post_nms_topk)
+    if lvl is None:
+        keep, num = K.nms_batched(boxes, counts, nms_thresh, post_nms_topk)
+    else:   # level-wise NMS: boxes of level l are moved by l * (largest image extent + 1), so that levels cannot overlap
+        shift = torch.gather(lvl, 1, order) * (float(max(max(int(v) for v in sz) for sz in image_sizes)) + 1.0)
+        keep, num = K.nms_batched((boxes + shift.unsqueeze(-1)).contiguous(), counts, nms_thresh, post_nms_topk)
     if packed:
         # fixed-shape result, nothing read back: [N, post_nms_topk] rows + a validity mask
         p = min(post_nms_topk, keep.shape[1])

@@ -10,7 +10,8 @@
 namespace {
 
 __global__ __launch_bounds__(256) void sgd_kernel(const coin_sgd_tensor* __restrict__ table, float momentum,
-                                                  float inv_scale, float lr_scale, int first_step) {
+                                                  float inv_scale, float lr_scale, int first_step, const float* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0.f) return;   // device-side "skip this update" (data-parallel CKG step: no rank had merge terms)
   coin_sgd_tensor t = table[blockIdx.y];
   t.lr *= lr_scale;
   const int64_t n = t.numel;
@@ -99,7 +100,7 @@ extern "C" int coin_abi_version(void) { return COIN_ABI_VERSION; }
 extern "C" const char* coin_build_arch(void) { return "gfx950"; }
 
 extern "C" int coin_sgd_step(const coin_sgd_tensor* table, int num_tensors, int64_t max_numel, float momentum,
-                             float inv_loss_scale, float lr_scale, int first_step, void* stream) {
+                             float inv_loss_scale, float lr_scale, int first_step, const float* gate, void* stream) {
   if (num_tensors < 0 || max_numel < 0 || (num_tensors > 0 && !table)) return COIN_EINVAL;
   if (num_tensors == 0 || max_numel == 0) return COIN_OK;
   if (num_tensors > 65535) return COIN_ESHAPE;
@@ -107,7 +108,7 @@ extern "C" int coin_sgd_step(const coin_sgd_tensor* table, int num_tensors, int6
   if (gx > 512) gx = 512;
   if (gx < 1) gx = 1;
   dim3 grid((unsigned)gx, (unsigned)num_tensors);
-  sgd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(table, momentum, inv_loss_scale, lr_scale, first_step);
+  sgd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(table, momentum, inv_loss_scale, lr_scale, first_step, gate);
   return coin_launch_status();
 }
 

@@ -259,20 +259,22 @@ class CoinTrainer(BASE_Trainer):
         self.optimizer.zero_grad()
         self.optimizer_merge.zero_grad()
         has_merge = "loss_merge_a" in record
-        run_merge = has_merge
         if self.world_size > 1:
-            # The merge module is data-parallel too (trainer.py:70-72), so its gradient all-reduce must be entered by every rank
-            # or by none.  Whether a rank's batch contains B boxes is data dependent: the ranks agree on one flag per step, and
-            # a rank without merge terms contributes a zero gradient (the reference would dead-lock in that mixed case).
-            flag = torch.tensor([float(has_merge)], device=self.device)
-            dist.all_reduce(flag)
-            run_merge = bool(flag.item() > 0)
-        if run_merge:
-            # CKG update (trainer.py:192-197); gradients are formed for the merge parameters only
+            # The merge module is data-parallel too (trainer.py:70-72), so its gradient all-reduce must be entered by every rank or by
+            # none.  Whether a rank's batch contains B boxes is data dependent (the reference dead-locks when the ranks disagree).  Every
+            # rank therefore enters the merge slices every step -- a rank without merge terms contributes zeros -- and the number of ranks
+            # WITH merge terms rides in the same all-reduce (GradReducer.flag); the CKG optimizer reads it on the device and skips the
+            # update when it is 0 (coin_sgd_step's gate): no collective of its own, no `.item()` (round 3 agreed on a host flag per step).
+            self.reducer_merge.set_flag(1.0 if has_merge else 0.0)
             if has_merge:
                 record["loss_merge_grad"] = self.model.roi_heads.box_predictor.merge_grad_loss()
                 (record["loss_merge_grad"] + record["loss_merge_base"]).backward(inputs=list(self.merge.parameters()), retain_graph=True)
-            # a rank without merge terms has no gradient: its slices are flushed with zeros, every rank enters the same collectives
+            scale = self.reducer_merge.finalize()
+            self.optimizer_merge.step(inv_loss_scale=scale, gate=self.reducer_merge.flag)
+        elif has_merge:
+            # CKG update (trainer.py:192-197); gradients are formed for the merge parameters only
+            record["loss_merge_grad"] = self.model.roi_heads.box_predictor.merge_grad_loss()
+            (record["loss_merge_grad"] + record["loss_merge_base"]).backward(inputs=list(self.merge.parameters()), retain_graph=True)
             self.optimizer_merge.step(inv_loss_scale=self.reducer_merge.finalize() if self.reducer_merge is not None else 1.0)
         self.optimizer.zero_grad()
         self.optimizer_merge.zero_grad()

@@ -800,9 +800,14 @@ class SgdTable:
 
     def step(self, grads: Sequence[torch.Tensor], momentum: float, inv_loss_scale: float = 1.0,
              lrs: Optional[Sequence[float]] = None, lr_scale: float = 1.0,
-             shadows: Optional[Sequence[Optional[torch.Tensor]]] = None):
+             shadows: Optional[Sequence[Optional[torch.Tensor]]] = None, gate: Optional[torch.Tensor] = None):
         """`lrs` (re)defines the per-tensor base learning rates held in the device table (re-uploaded only when they or the
-        gradient pointers change); `lr_scale` is the per-step schedule factor passed as a kernel argument."""
+        gradient pointers change); `lr_scale` is the per-step schedule factor passed as a kernel argument; `gate` (one fp32 on the
+        device): the launch is a no-op when it holds 0."""
+        if gate is not None:
+            _dev(gate)
+            if gate.dtype != torch.float32 or gate.numel() != 1:
+                raise CoinHipError("sgd gate must be a one-element float32 device tensor")
         if shadows is not None:
             self.shadows = list(shadows)
         key = (tuple(g.data_ptr() if g is not None else 0 for g in grads), tuple(lrs) if lrs is not None else tuple(self.lrs),
@@ -813,7 +818,7 @@ class SgdTable:
             self._upload(grads)
             self._grads_key = key
         check(_lib.lib().coin_sgd_step(_p(self._dev), len(self.params), self.max_numel, float(momentum),
-                                       float(inv_loss_scale), float(lr_scale), int(self.first), _stream()), "coin_sgd_step")
+                                       float(inv_loss_scale), float(lr_scale), int(self.first), _p(gate), _stream()), "coin_sgd_step")
         self.first = False
 
 

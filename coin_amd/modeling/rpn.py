@@ -128,9 +128,12 @@ class DualTeacherRPN(nn.Module):
         # (N, A, H, W) -> (N, H*W*A) ; (N, A*4, H, W) -> (N, H*W*A, 4).  With channels-last activations both are views.
         logits = [s.permute(0, 2, 3, 1).flatten(1) for s in lg]
         deltas = [x.view(x.shape[0], -1, 4, x.shape[-2], x.shape[-1]).permute(0, 3, 4, 1, 2).flatten(1, -2) for x in dl]
+        self._level_sizes = None
         if len(logits) > 1:
-            # several feature levels (FPN extension): the levels' anchors are concatenated into ONE anchor set, so that labelling,
-            # losses, top-k and NMS below are the single-level code of the reference applied to the union
+            # several feature levels (FPN extension): the levels' anchors are concatenated into ONE anchor set, so that labelling and
+            # losses below are the single-level code of the reference applied to the union (as detectron2's multi-level RPN does);
+            # the proposal selection keeps the levels apart (per-level top-k, NMS inside a level: box_ops.find_top_rpn_proposals)
+            self._level_sizes = [int(l.shape[1]) for l in logits]
             anchors, logits, deltas = [Boxes.cat(anchors)], [torch.cat(logits, dim=1)], [torch.cat(deltas, dim=1)]
         losses = {}
         if self.training and branch != "test":
@@ -301,7 +304,8 @@ class DualTeacherRPN(nn.Module):
         d = deltas[0].detach().reshape(-1, 4)
         boxes = self.box2box_transform.apply_deltas(d, a.unsqueeze(0).expand(n, -1, -1).reshape(-1, 4)).view(n, -1, 4)
         return find_top_rpn_proposals(boxes, logits[0].detach(), image_sizes, self.nms_thresh, self.pre_nms_topk[self.training],
-                                      self.post_nms_topk[self.training], self.min_box_size, self.training, packed=packed)
+                                      self.post_nms_topk[self.training], self.min_box_size, self.training, packed=packed,
+                                      level_sizes=getattr(self, "_level_sizes", None))
 
 
 def build_proposal_generator(cfg, input_shape):

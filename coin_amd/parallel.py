@@ -56,6 +56,17 @@ class GradReducer:
             n += p.numel()
         if cur:
             self._close(cur)
+        # one extra fp32 behind the LAST slice's gradients: a per-step flag that is summed over the ranks by that slice's own all-reduce
+        # (`set_flag` / `flag`): "how many ranks had this kind of gradient" without a collective or a host round trip of its own
+        last = self.slices[-1]
+        flat = torch.zeros(last.flat.numel() + 1, dtype=torch.float32, device=last.flat.device)
+        off = 0
+        views = []
+        for p, v in zip(last.params, last.views):
+            views.append(flat[off:off + p.numel()].as_strided(v.shape, v.stride()))
+            off += p.numel()
+        last.flat, last.views = flat, views
+        self.flag = flat[-1:]
         self._next = 0          # next slice index to launch (collectives are issued in index order on every rank)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
@@ -126,6 +137,15 @@ class GradReducer:
             if self._pack_events is None:
                 self._pack_events = []
             self._pack_events.append(done)
+
+    def set_flag(self, value: float) -> None:
+        """This rank's contribution to `flag` (read it after `finalize()`: the sum over the ranks).  Call BEFORE the backward pass of the
+        step: the last slice may be launched by a hook, on whichever stream that backward node runs."""
+        self.flag.fill_(float(value))
+        if self.flag.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.flag.device))
+            self.slices[-1].events.append(ev)
 
     # ---- called by the trainer after backward
     def finalize(self) -> float:

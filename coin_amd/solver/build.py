@@ -79,7 +79,8 @@ class FusedSGD:
             torch._foreach_zero_(grads)
 
     @torch.no_grad()
-    def step(self, inv_loss_scale: float = 1.0):
+    def step(self, inv_loss_scale: float = 1.0, gate: Optional[torch.Tensor] = None):
+        """gate: one fp32 element on the parameters' device; the whole update is skipped ON THE DEVICE when it holds 0 (no host sync)."""
         params = self.params
         if self._table is None:
             self._table = K.SgdTable(params, [g["lr"] for g in self.param_groups], [g["weight_decay"] for g in self.param_groups])
@@ -103,9 +104,9 @@ class FusedSGD:
         shadows = [L.shadow_of(p) for p in params]
         if uniform:
             self._table.step(grads, self.momentum, inv_loss_scale, lrs=[g["base_lr"] for g in self.param_groups],
-                             lr_scale=1.0 if factor is None else factor, shadows=shadows)
+                             lr_scale=1.0 if factor is None else factor, shadows=shadows, gate=gate)
         else:  # groups were edited independently: fall back to uploading the absolute rates
-            self._table.step(grads, self.momentum, inv_loss_scale, lrs=[g["lr"] for g in self.param_groups], shadows=shadows)
+            self._table.step(grads, self.momentum, inv_loss_scale, lrs=[g["lr"] for g in self.param_groups], shadows=shadows, gate=gate)
         L.weights_updated()   # the persistent data-gradient layouts are re-derived by ONE launch at the next backward
 
     def load_momentum(self, bufs):

@@ -386,6 +386,9 @@ int coin_normalize_pad(const uint8_t* img, int h, int w, const float mean[3], co
  * (`lr_scale` = the schedule factor common to all groups, so the device table is uploaded once, not every step.)
  * `table` is a DEVICE array of coin_sgd_tensor descriptors; one launch updates all of them.
  * Optionally also refreshes a bf16 shadow copy of each parameter (shadow may be NULL).
+ * `gate` (DEVICE float, may be NULL): when *gate == 0 the launch changes nothing -- the data-parallel CKG update (trainer.py:192-197
+ * under DistributedDataParallel, :66-72) is taken by every rank or by none, and "did any rank see B boxes" is the all-reduced count
+ * that rides in the gradient arena: the decision never returns to the host.
  * ---------------------------------------------------------------------------------------- */
 typedef struct coin_sgd_tensor {
   float* param;
@@ -398,7 +401,7 @@ typedef struct coin_sgd_tensor {
 } coin_sgd_tensor;
 
 int coin_sgd_step(const coin_sgd_tensor* table, int num_tensors, int64_t max_numel, float momentum,
-                  float inv_loss_scale, float lr_scale, int first_step, void* stream);
+                  float inv_loss_scale, float lr_scale, int first_step, const float* gate, void* stream);
 
 /* Data-gradient layout of convolution / linear weights, all tensors of a DEVICE table in one launch (replaces the per-call
  * flip + permute + copy of the weight in the backward of the res5 / RPN / box-head layers, coin/modeling/utils.py:77-90 under autograd):

@@ -193,9 +193,12 @@ class _CpuSgdTable:
         self.bufs = [torch.zeros_like(p) for p in self.params]
         self.first = True
 
-    def step(self, grads, momentum, inv_loss_scale=1.0, lrs=None, lr_scale=1.0, shadows=None):
+    def step(self, grads, momentum, inv_loss_scale=1.0, lrs=None, lr_scale=1.0, shadows=None, gate=None):
         if lrs is not None:
             self.lrs = list(lrs)
+        if gate is not None and float(gate) == 0.0:   # coin_sgd_step's device-side gate
+            self.first = False
+            return
         for p, g, b, lr, wd in zip(self.params, grads, self.bufs, self.lrs, self.wds):
             if g is None:
                 continue

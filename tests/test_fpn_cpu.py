@@ -167,3 +167,40 @@ def test_oracle_torch_window_attention_equals_the_numpy_loops():
         a = O.window_attention_t(qkv, bias, m, 3, 32 ** -0.5).numpy()
         b = O.window_attention(qkv.numpy(), bias.numpy(), None if m is None else m.numpy(), 3, 32 ** -0.5)
         np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_multilevel_rpn_proposals_per_level_topk_and_levelwise_nms_vs_oracle(packed):
+    """box_ops.find_top_rpn_proposals with `level_sizes` (the FPN RPN) == the detectron2 multi-level algorithm as oracle/d2.py restates it:
+    top-k PER LEVEL, NMS inside each level only (batched_nms by level id), then the best `post_nms_topk` over all levels.  Round-3
+    ADVICE: a single top-k / NMS over the union lets the dense p2 anchors crowd out p5 / p6 and lets levels suppress each other."""
+    from coin_amd.box_ops import find_top_rpn_proposals
+    from oracle import d2
+
+    g = torch.Generator().manual_seed(31)
+    sizes = [(200, 320), (180, 300)]
+    level_sizes = [1200, 300, 80, 24, 8]
+    props, logits = [], []
+    for a in level_sizes:
+        xy = torch.rand(2, a, 2, generator=g) * torch.tensor([300.0, 180.0])
+        wh = torch.rand(2, a, 2, generator=g) * 120.0 + 2.0
+        props.append(torch.cat([xy - 5.0, xy + wh], dim=-1))             # some boxes start outside the image: clipping matters
+        logits.append(torch.randn(2, a, generator=g))
+    props[1][0, :40] = props[0][0, :40]                                    # identical boxes on two levels: must NOT suppress each other
+    logits[1][0, :40] = logits[0][0, :40] - 0.01
+    ref = d2.find_top_rpn_proposals(props, logits, sizes, 0.7, 100, 150, 0.0, False)
+    with cpu_kernels():
+        got = find_top_rpn_proposals(torch.cat(props, 1), torch.cat(logits, 1), sizes, 0.7, 100, 150, 0.0, False, packed=packed, level_sizes=level_sizes)
+    for i, r in enumerate(ref):
+        if packed:
+            ok = got.valid[i]
+            gb, gl = got.boxes[i][ok], got.logits[i][ok]
+        else:
+            gb, gl = got[i].proposal_boxes.tensor, got[i].objectness_logits
+        assert gb.shape == r.proposal_boxes.tensor.shape, (gb.shape, r.proposal_boxes.tensor.shape)
+        torch.testing.assert_close(gl, r.objectness_logits, rtol=0, atol=0)
+        torch.testing.assert_close(gb, r.proposal_boxes.tensor, rtol=0, atol=1e-5)
+    # and the union formulation differs on this input (the test would not notice a regression otherwise)
+    with cpu_kernels():
+        union = find_top_rpn_proposals(torch.cat(props, 1), torch.cat(logits, 1), sizes, 0.7, 100, 150, 0.0, False)
+    assert len(union[0]) != len(ref[0]) or not torch.equal(union[0].objectness_logits, ref[0].objectness_logits)

@@ -588,6 +588,37 @@ def test_sgd_table_matches_torch_sgd(K):
         assert torch.equal(s.cpu(), p.cpu().to(torch.bfloat16))
 
 
+def test_sgd_gate_skips_the_update_on_the_device(K):
+    """coin_sgd_step's gate (the data-parallel CKG update, trainer.py:192-197 under DDP): a zero in device memory turns the launch
+    into a no-op -- parameters, momentum buffers and shadows untouched -- without the host ever reading it; a non-zero count lets
+    it through.  The reducer's flag slot (parallel.GradReducer.flag) is what the trainer passes."""
+    from coin_amd.parallel import GradReducer
+
+    g = torch.Generator().manual_seed(15)
+    ps = [dev(torch.randn(s, generator=g)) for s in [(300, 17), (64,)]]
+    table = K.SgdTable(ps, [0.1, 0.1], [0.0, 0.0], [torch.empty_like(p, dtype=torch.bfloat16) for p in ps])
+    before = [p.clone() for p in ps]
+    grads = [torch.ones_like(p) for p in ps]
+    gate = torch.zeros(1, device="cuda")
+    table.step(grads, momentum=0.9, gate=gate)
+    assert all(torch.equal(a, b) for a, b in zip(ps, before)) and all(float(b.abs().max()) == 0.0 for b in table.bufs)
+    gate.fill_(3.0)
+    table.step(grads, momentum=0.9, gate=gate)
+    for a, b in zip(ps, before):
+        torch.testing.assert_close(a, b - 0.1, rtol=0, atol=1e-6)
+    # the reducer's flag slot: one fp32 behind the last slice, zero until set, usable as the gate as it stands
+    params = [torch.nn.Parameter(p.clone()) for p in ps]
+    red = GradReducer(params)
+    assert red.flag.numel() == 1 and red.flag.dtype == torch.float32 and float(red.flag) == 0.0
+    red.set_flag(1.0)
+    for p in params:
+        p.grad = None
+    (params[0].sum() * 2 + params[1].sum()).backward()
+    assert red.finalize() == 1.0 and float(red.flag) == 1.0
+    torch.testing.assert_close(params[0].grad, torch.full_like(params[0], 2.0))
+    red.remove()
+
+
 def test_ema_golden(K):
     z = load_golden("ema")
     keys = [k[3:] for k in z.files if k.startswith("t::") and z[k].dtype == np.float32]
