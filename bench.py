@@ -52,10 +52,10 @@ MFMA_ENTRIES = ("coin_gemm_nt", "coin_conv_gemm_bf16", "coin_conv_wgrad_bf16")  
 
 
 def pmc_traffic(entry: str, alg_bytes: float):
-    """HBM bytes per launch from the committed PMC passes (profiles/r3_pmc_traffic.json, else older rounds': FETCH_SIZE x2 on gfx950 +
+    """HBM bytes per launch from the committed PMC passes (profiles/r4_pmc_traffic.json, else older rounds': FETCH_SIZE x2 on gfx950 +
     WRITE_SIZE, KB units, MI355X_MICROARCH.md) -- only when that pass measured this entry point at this launch size (for the MFMA
     entry points: at this mean FLOP count per launch), else None."""
-    for name in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    for name in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 table = json.load(f)
