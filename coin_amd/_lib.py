@@ -81,8 +81,8 @@ SIGNATURES = {
     "coin_rpn_losses_fwd_bwd": [_P, _P, _P, _P, _P, _L, _L, _I, _P, _P, _P, _P, _P],
     "coin_normalize_pad": [_P, _I, _I, ctypes.POINTER(c_float), ctypes.POINTER(c_float), _P, _I, _I, _I, _I, _I, _P],
     "coin_bn_stats": [_P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P],
-    "coin_bn_apply_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "coin_bn_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P],
+    "coin_bn_apply_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "coin_bn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "coin_avgpool2_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "coin_avgpool2_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "coin_nms_batched": [_P, _P, _I, _I, _F, _I, _P, _P, _P, _P],

@@ -161,7 +161,8 @@ template <typename T, int POOL>
 __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, const T* __restrict__ residual,
-                                                               T* __restrict__ y, int N, int H, int W, int C, int relu) {
+                                                               T* __restrict__ y, int N, int H, int W, int C, int relu,
+                                                               uint8_t* __restrict__ mask) {
   constexpr int V = Ld<T>::V;
   const int ncg = C / V;
   const RowWalk rw = row_walk(ncg);
@@ -182,12 +183,15 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restric
         float v[V], rr[V], o[V];
         Ld<T>::load(x + (size_t)r * C + coff, v);
         Ld<T>::load(residual + (size_t)r * C + coff, rr);
+        unsigned m = 0;
 #pragma unroll
         for (int i = 0; i < V; ++i) {
           o[i] = v[i] * sc[i] + sh[i] + rr[i];
+          m |= (o[i] > 0.f ? 1u : 0u) << i;
           if (relu) o[i] = fmaxf(o[i], 0.f);
         }
         Ld<T>::store(y + (size_t)r * C + coff, o);
+        if (mask) mask[(size_t)r * ncg + rw.cg] = (uint8_t)m;   // bit i: channel i of this 16-byte group passed the ReLU
       }
     } else {
 #pragma unroll 4
@@ -239,7 +243,8 @@ template <typename T>
 __global__ __launch_bounds__(BN_THREADS) void bn_apply_mean_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, const T* __restrict__ residual,
-                                                                    T* __restrict__ y, int N, int HW, int C, int relu) {
+                                                                    T* __restrict__ y, int N, int HW, int C, int relu,
+                                                                    uint8_t* __restrict__ mask) {
   constexpr int V = Ld<T>::V;
   const int ncg = C / V;
   const int cg = blockIdx.x * BN_THREADS + threadIdx.x;
@@ -267,8 +272,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_mean_kernel(const T* __re
 #pragma unroll
       for (int i = 0; i < V; ++i) v[i] = v[i] * sc[i] + sh[i];
     }
+    unsigned m = 0;
 #pragma unroll
-    for (int i = 0; i < V; ++i) acc[i] += relu ? fmaxf(v[i], 0.f) : v[i];
+    for (int i = 0; i < V; ++i) {
+      m |= (v[i] > 0.f ? 1u : 0u) << i;
+      acc[i] += relu ? fmaxf(v[i], 0.f) : v[i];
+    }
+    if (mask) mask[((size_t)n * HW + r) * ncg + cg] = (uint8_t)m;
   }
   const float inv = 1.0f / (float)HW;
 #pragma unroll
@@ -282,15 +292,33 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_mean_kernel(const T* __re
 //   POOL 2: dy is [N,H/2,W/2,C]; mask recomputed from x.
 //   POOL 0: dy is [N,C] (global mean); `yout` carries the forward's RESIDUAL input (or NULL); mask recomputed.
 // MODE (compile time, so that the row loops are branch-free and the loads of several rows are issued together): bit 0 = ReLU,
-// bit 1 = `yout` is present (POOL 1: the saved output supplies the mask; POOL 0: the forward's residual input).
+// bit 1 = `yout` is present (POOL 1: the saved output supplies the mask; POOL 0: the forward's residual input),
+// bit 2 = the forward's ReLU bit mask is present (one byte per 16-byte channel group and row; replaces `yout` in both roles: a
+// residual block's backward then reads 1/16 of the bytes it read from the saved output, twice).
 template <typename T, int POOL, int MODE>
 __device__ __forceinline__ void upstream(const T* __restrict__ dy, const T* __restrict__ yout_, const float (&xv)[Ld<T>::V],
                                          const float (&sc)[Ld<T>::V], const float (&sh)[Ld<T>::V], int64_t r, int H, int W, int C,
-                                         size_t coff, float (&g)[Ld<T>::V]) {
+                                         size_t coff, float (&g)[Ld<T>::V], const uint8_t* __restrict__ mask = nullptr) {
   constexpr int V = Ld<T>::V;
   constexpr bool relu = (MODE & 1) != 0;
   constexpr bool HAS_Y = (MODE & 2) != 0;
+  constexpr bool HAS_M = (MODE & 4) != 0;
   const T* __restrict__ yout = yout_;
+  if (HAS_M && (POOL == 1 || POOL == 0)) {
+    const unsigned m = mask[(size_t)r * (C / V) + coff / V];
+    if (POOL == 1) {
+      Ld<T>::load(dy + (size_t)r * C + coff, g);
+#pragma unroll
+      for (int i = 0; i < V; ++i) g[i] = (!relu || ((m >> i) & 1u)) ? g[i] : 0.f;
+    } else {
+      const int hw = H * W;
+      Ld<T>::load(dy + (size_t)(r / hw) * C + coff, g);
+      const float inv = 1.0f / (float)hw;
+#pragma unroll
+      for (int i = 0; i < V; ++i) g[i] = (!relu || ((m >> i) & 1u)) ? g[i] * inv : 0.f;
+    }
+    return;
+  }
   if (POOL == 1) {
     const size_t off = (size_t)r * C + coff;
     Ld<T>::load(dy + off, g);
@@ -342,7 +370,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __re
                                                                     const T* __restrict__ yout, const float* __restrict__ mean,
                                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, int N, int H, int W, int C,
-                                                                    int relu, float* __restrict__ dsums) {
+                                                                    int relu, float* __restrict__ dsums, const uint8_t* __restrict__ mask) {
   constexpr int V = Ld<T>::V;
   extern __shared__ float red[];
   const int ncg = C / V;
@@ -368,7 +396,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __re
       for (int64_t r = (int64_t)blockIdx.x * rpi + slot; r < M; r += (int64_t)gridDim.x * rpi) {
         float xv[V], g[V];
         Ld<T>::load(x + (size_t)r * C + coff, xv);
-        upstream<T, POOL, MODE>(dy, yout, xv, sc, sh, r, H, W, C, coff, g);
+        upstream<T, POOL, MODE>(dy, yout, xv, sc, sh, r, H, W, C, coff, g, mask);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
           db[i] += g[i];
@@ -428,7 +456,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const T* __restri
                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, const float* __restrict__ dsums,
                                                                 int N, int H, int W, int C, int relu, T* __restrict__ dx,
-                                                                T* __restrict__ dres) {
+                                                                T* __restrict__ dres, const uint8_t* __restrict__ mask) {
   constexpr int V = Ld<T>::V;
   const int ncg = C / V;
   const RowWalk rw = row_walk(ncg);
@@ -450,7 +478,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(const T* __restri
   for (int64_t r = rw.row0; r < M; r += rw.rstep) {
     float xv[V], g[V], o[V];
     Ld<T>::load(x + (size_t)r * C + coff, xv);
-    upstream<T, POOL, MODE>(dy, yout, xv, sc, sh, r, H, W, C, coff, g);
+    upstream<T, POOL, MODE>(dy, yout, xv, sc, sh, r, H, W, C, coff, g, mask);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       const float xhat = (xv[i] - mu[i]) * rs[i];
@@ -576,7 +604,7 @@ extern "C" int coin_bn_stats(const void* x, int N, int H, int W, int C, float ep
 }
 
 extern "C" int coin_bn_apply_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                 const void* residual, void* y, int N, int H, int W, int C, int relu, int pool, int dtype,
+                                 const void* residual, void* y, uint8_t* relu_mask, int N, int H, int W, int C, int relu, int pool, int dtype,
                                  void* stream) {
   int rc = bn_check(x, N, H, W, C, pool, dtype);
   if (rc) return rc;
@@ -588,7 +616,7 @@ extern "C" int coin_bn_apply_fwd(const void* x, const float* mean, const float* 
   if (pool == 0) {
     if (N > 65535) return COIN_ESHAPE;
     dim3 grid((C / v + BN_THREADS - 1) / BN_THREADS, N);
-#define GO(T) bn_apply_mean_kernel<T><<<grid, BN_THREADS, 0, st>>>((const T*)x, mean, rstd, gamma, beta, (const T*)residual, (T*)y, N, H * W, C, relu)
+#define GO(T) bn_apply_mean_kernel<T><<<grid, BN_THREADS, 0, st>>>((const T*)x, mean, rstd, gamma, beta, (const T*)residual, (T*)y, N, H * W, C, relu, relu_mask)
     BN_DISPATCH(dtype, GO(float), GO(bf16_t));
 #undef GO
     return coin_launch_status();
@@ -596,22 +624,23 @@ extern "C" int coin_bn_apply_fwd(const void* x, const float* mean, const float* 
   const int grid = walk_grid((int64_t)N * (H / pool) * (W / pool), C / v);
 #define GO(T)                                                                                                                     \
   if (pool == 1)                                                                                                                  \
-    bn_apply_kernel<T, 1><<<grid, BN_THREADS, 0, st>>>((const T*)x, mean, rstd, gamma, beta, (const T*)residual, (T*)y, N, H, W, C, relu); \
+    bn_apply_kernel<T, 1><<<grid, BN_THREADS, 0, st>>>((const T*)x, mean, rstd, gamma, beta, (const T*)residual, (T*)y, N, H, W, C, relu, residual ? relu_mask : nullptr); \
   else                                                                                                                            \
-    bn_apply_kernel<T, 2><<<grid, BN_THREADS, 0, st>>>((const T*)x, mean, rstd, gamma, beta, (const T*)residual, (T*)y, N, H, W, C, relu)
+    bn_apply_kernel<T, 2><<<grid, BN_THREADS, 0, st>>>((const T*)x, mean, rstd, gamma, beta, (const T*)residual, (T*)y, N, H, W, C, relu, nullptr)
   BN_DISPATCH(dtype, GO(float), GO(bf16_t));
 #undef GO
   return coin_launch_status();
 }
 
-extern "C" int coin_bn_bwd(const void* x, const void* dy, const void* y, const float* mean, const float* rstd, const float* gamma,
-                           const float* beta, int N, int H, int W, int C, int relu, int pool, float* dsums /* [2C]: dbeta, dgamma */,
-                           void* dx, void* d_residual, int dtype, void* stream) {
+extern "C" int coin_bn_bwd(const void* x, const void* dy, const void* y, const uint8_t* relu_mask, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, int N, int H, int W, int C, int relu, int pool,
+                           float* dsums /* [2C]: dbeta, dgamma */, void* dx, void* d_residual, int dtype, void* stream) {
   int rc = bn_check(x, N, H, W, C, pool, dtype);
   if (rc) return rc;
   if (!dy || !mean || !rstd || !gamma || !beta || !dsums || !dx) return COIN_EINVAL;
-  if (relu && pool == 1 && d_residual && !y) return COIN_EINVAL;  // with a residual the ReLU mask is only in the saved output
-  if (pool == 0 && d_residual && !y) return COIN_EINVAL;          // pool == 0: `y` is the forward's residual input
+  if (relu_mask && pool == 2) return COIN_ESHAPE;
+  if (relu && pool == 1 && d_residual && !y && !relu_mask) return COIN_EINVAL;  // with a residual the ReLU mask is only in the saved output / bit mask
+  if (pool == 0 && d_residual && !y && !relu_mask) return COIN_EINVAL;          // pool == 0: `y` is the forward's residual input
   if (pool == 2 && d_residual) return COIN_ESHAPE;
   hipStream_t st = (hipStream_t)stream;
   const int v = dtype == COIN_F32 ? 4 : 8;
@@ -621,11 +650,11 @@ extern "C" int coin_bn_bwd(const void* x, const void* dy, const void* y, const f
   if (g > COIN_BN_MAX_PARTS) g = COIN_BN_MAX_PARTS;
   const size_t lds = sizeof(float) * BN_THREADS * 2 * v;
   const int wg = walk_grid(M, ncg);
-  const int mode = (relu ? 1 : 0) | (y ? 2 : 0);
+  const int mode = relu_mask ? ((relu ? 1 : 0) | 4) : ((relu ? 1 : 0) | (y ? 2 : 0));
 #define GO2(T, P, MD)                                                                                                              \
-  bn_bwd_reduce_kernel<T, P, MD><<<(int)g, BN_THREADS, lds, st>>>((const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, beta, N, H, W, C, relu, dsums); \
+  bn_bwd_reduce_kernel<T, P, MD><<<(int)g, BN_THREADS, lds, st>>>((const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, beta, N, H, W, C, relu, dsums, relu_mask); \
   bn_bwd_finalize_kernel<<<(2 * C + 63) / 64, 1024, 0, st>>>(dsums, (int)g, C);                                                      \
-  bn_bwd_dx_kernel<T, P, MD><<<wg, BN_THREADS, 0, st>>>((const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, beta, dsums, N, H, W, C, relu, (T*)dx, (T*)d_residual)
+  bn_bwd_dx_kernel<T, P, MD><<<wg, BN_THREADS, 0, st>>>((const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, beta, dsums, N, H, W, C, relu, (T*)dx, (T*)d_residual, relu_mask)
 #define GO1(T, P)             \
   if (mode == 0) {            \
     GO2(T, P, 0);             \
@@ -633,8 +662,12 @@ extern "C" int coin_bn_bwd(const void* x, const void* dy, const void* y, const f
     GO2(T, P, 1);             \
   } else if (mode == 2) {     \
     GO2(T, P, 2);             \
-  } else {                    \
+  } else if (mode == 3) {     \
     GO2(T, P, 3);             \
+  } else if (mode == 4) {     \
+    GO2(T, P, 4);             \
+  } else {                    \
+    GO2(T, P, 5);             \
   }
 #define GO(T)                 \
   if (pool == 1) {            \

@@ -570,26 +570,36 @@ def bn_stats(x: torch.Tensor, eps: float, momentum: float, running_mean: Optiona
     return mean, rstd
 
 
-def bn_apply_fwd(x: torch.Tensor, mean, rstd, gamma, beta, residual: Optional[torch.Tensor], relu: bool, pool: int) -> torch.Tensor:
+def bn_apply_fwd(x: torch.Tensor, mean, rstd, gamma, beta, residual: Optional[torch.Tensor], relu: bool, pool: int, want_mask: bool = False):
+    """want_mask (pool 1 with a residual, pool 0): also return the ReLU bit mask [N*H*W, C/8] (uint8; C/4 groups for float32) that
+    `bn_bwd` takes instead of the saved output / the residual input -> (y, mask)."""
     _dev(x, mean, rstd, gamma, beta, residual)
     n, h, w, c = _nhwc(x, "x")
+    mask = None
+    if want_mask:
+        if pool == 2 or (pool == 1 and residual is None):
+            raise CoinHipError("the ReLU bit mask exists for pool 1 with a residual and for pool 0")
+        mask = torch.empty((n * h * w, c // (8 if x.dtype == torch.bfloat16 else 4)), dtype=torch.uint8, device=x.device)
     # pool: 1 = none, 2 = 2x2 average pool, 0 = global spatial mean (y is [N,1,1,C]; the full activation is never written)
     y = torch.empty((n, 1, 1, c) if pool == 0 else (n, h // pool, w // pool, c), dtype=x.dtype, device=x.device)
     if residual is not None and (residual.shape != x.shape or pool == 2 or residual.dtype != x.dtype or not residual.is_contiguous()):
         raise CoinHipError("residual must match the pre-pool activation (contiguous NHWC, same dtype)")
-    with _timed("coin_bn_apply_fwd", _nbytes(x) + _nbytes(residual) + _nbytes(y)):
+    with _timed("coin_bn_apply_fwd", _nbytes(x) + _nbytes(residual) + _nbytes(y) + _nbytes(mask)):
         check(_lib.lib().coin_bn_apply_fwd(_p(x), _p(_f32c(mean, "mean")), _p(_f32c(rstd, "rstd")), _p(_f32c(gamma, "gamma")),
-                                           _p(_f32c(beta, "beta")), _p(residual), _p(y), n, h, w, c, int(relu), int(pool), _dt(x), _stream()),
+                                           _p(_f32c(beta, "beta")), _p(residual), _p(y), _p(mask), n, h, w, c, int(relu), int(pool), _dt(x), _stream()),
               "coin_bn_apply_fwd")
-    return y
+    return (y, mask) if want_mask else y
 
 
 def bn_bwd(x: torch.Tensor, dy: torch.Tensor, y: Optional[torch.Tensor], mean, rstd, gamma, beta, relu: bool, pool: int,
-           want_dres: bool):
+           want_dres: bool, mask: Optional[torch.Tensor] = None):
     """-> dx [N,H,W,C], dgamma [C], dbeta [C], d_residual (or None).
     `y`: the saved forward output (pool 1, only needed when the forward added a residual) or, for pool 0 (global mean), the
-    forward's residual INPUT (the activation was never stored; the ReLU mask is recomputed)."""
-    _dev(x, dy, y)
+    forward's residual INPUT (the activation was never stored; the ReLU mask is recomputed).  `mask`: the forward's ReLU bit mask
+    (`bn_apply_fwd(..., want_mask=True)`) -- replaces `y` in either role."""
+    _dev(x, dy, y, mask)
+    if mask is not None and (mask.dtype != torch.uint8 or not mask.is_contiguous()):
+        raise CoinHipError("mask must be the contiguous uint8 tensor bn_apply_fwd returned")
     n, h, w, c = _nhwc(x, "x")
     if not dy.is_contiguous() or dy.dtype != x.dtype:
         raise CoinHipError("dy must be contiguous NHWC of x's dtype")
@@ -598,9 +608,9 @@ def bn_bwd(x: torch.Tensor, dy: torch.Tensor, y: Optional[torch.Tensor], mean, r
     dres = torch.empty_like(x) if want_dres else None
     # algorithmic bytes of the two-pass backward: the channel sums must be complete before any dx can be formed and the
     # tensors are far larger than the caches, so every input is streamed twice; outputs once
-    alg = 2 * (_nbytes(x) + _nbytes(dy) + _nbytes(y)) + _nbytes(dx) + _nbytes(dres)
+    alg = 2 * (_nbytes(x) + _nbytes(dy) + (_nbytes(mask) if mask is not None else _nbytes(y))) + _nbytes(dx) + _nbytes(dres)
     with _timed("coin_bn_bwd", alg):
-        check(_lib.lib().coin_bn_bwd(_p(x), _p(dy), _p(y), _p(mean), _p(rstd), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")), n, h, w, c,
+        check(_lib.lib().coin_bn_bwd(_p(x), _p(dy), _p(y if mask is None else None), _p(mask), _p(mean), _p(rstd), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")), n, h, w, c,
                                      int(relu), int(pool), _p(dsums), _p(dx), _p(dres), _dt(x), _stream()), "coin_bn_bwd")
     return dx, dsums[c:2 * c], dsums[:c], dres
 

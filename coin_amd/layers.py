@@ -487,31 +487,35 @@ class _BNAct(Function):
             mean, rstd = K.conv_stats_finalize(part, xn.shape[0] * xn.shape[1] * xn.shape[2], xn.shape[3], rows, eps, momentum, running_mean, running_var, nbt)
         else:
             mean, rstd = K.bn_stats(xn if nv is None else xn[:nv], eps, momentum, running_mean, running_var, nbt)
-        y = K.bn_apply_fwd(xn, mean, rstd, g, b, rn, relu, pool)
-        ctx.relu, ctx.pool, ctx.has_res, ctx.nv = relu, pool, residual is not None, nv
-        # pool 1: the saved output is only needed for the ReLU mask when a residual was added (otherwise coin_bn_bwd recomputes
-        # it from x).  pool 0 (global mean): the activation does not exist; the residual input is kept instead.
-        if pool == 0:
-            keep = rn
+        # The backward needs the ReLU decisions of a block that added a residual (pool 1: they were only in the saved output; pool 0:
+        # in x + the residual input).  They are kept as ONE BIT per element, written by the apply pass: both backward passes then
+        # read 1/16 of the bytes (the [2048, 7, 7, 2048] outputs of res5: 26 MB instead of 411 MB, twice per block).
+        want_mask = bool(relu) and residual is not None and pool in (0, 1) and xn.is_cuda
+        if want_mask:
+            y, mask = K.bn_apply_fwd(xn, mean, rstd, g, b, rn, relu, pool, want_mask=True)
         else:
-            keep = y if (relu and pool == 1 and residual is not None) else None
-        ctx.save_for_backward(xn, keep, mean, rstd, g, b)
+            y, mask = K.bn_apply_fwd(xn, mean, rstd, g, b, rn, relu, pool), None
+        ctx.relu, ctx.pool, ctx.has_res, ctx.nv = relu, pool, residual is not None, nv
+        # without a residual coin_bn_bwd recomputes the mask from x; pool 0 without ReLU still needs nothing but x
+        keep = None if mask is not None else (rn if pool == 0 else (y if (relu and pool == 1 and residual is not None) else None))
+        ctx.save_for_backward(xn, keep, mean, rstd, g, b, mask)
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        xn, y, mean, rstd, g, b = ctx.saved_tensors
+        xn, y, mean, rstd, g, b, mask = ctx.saved_tensors
         dyn = _as_nhwc(dy)
         if dyn.dtype != xn.dtype:
             dyn = dyn.to(xn.dtype)
         want_dres = ctx.has_res and ctx.needs_input_grad[3]
         nv = ctx.nv
         if nv is None:
-            dx, dgamma, dbeta, dres = K.bn_bwd(xn, dyn, y, mean, rstd, g, b, ctx.relu, ctx.pool, want_dres)
+            dx, dgamma, dbeta, dres = K.bn_bwd(xn, dyn, y, mean, rstd, g, b, ctx.relu, ctx.pool, want_dres, mask=mask)
         else:  # sums and dx over the real rows (leading, contiguous); the filler rows get zero gradient
+            hw = xn.shape[1] * xn.shape[2]
             dxv, dgamma, dbeta, dresv = K.bn_bwd(xn[:nv], dyn[:nv], y[:nv] if y is not None else None, mean, rstd, g, b, ctx.relu, ctx.pool,
-                                                 want_dres)
+                                                 want_dres, mask=mask[:nv * hw] if mask is not None else None)
             dx = torch.zeros_like(xn)
             dx[:nv] = dxv
             dres = None

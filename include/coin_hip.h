@@ -136,6 +136,9 @@ int coin_bias_act_bwd(const void* dC, const void* C, void* dZ, int ld, int M, in
  *                     coin/modeling/roi_heads/clip_roi_heads.py:207-208): the activation itself is never stored.
  *                     num_batches_tracked (may be NULL): the module's int64 counter, incremented by the same launch that
  *                     updates the running statistics (nn.BatchNorm2d does `num_batches_tracked += 1` as a launch of its own).
+ *                     relu_mask (may be NULL; pool 1 with a residual, pool 0): [N*H*W][C/8] bytes (C/4 for float32), bit i = channel i of
+ *                     the 16-byte channel group passed the ReLU.  Given to coin_bn_bwd it replaces `y` (the saved output / the
+ *                     residual input): the backward of a residual block then reads 1/16 of those bytes, in both of its passes.
  * coin_bn_bwd       : given dy (shape of y) computes dsums[0..C) = dbeta, dsums[C..2C) = dgamma (dsums must hold
  *                     (COIN_BN_MAX_PARTS+1)*2*C floats: the result followed by the partial sums), dx (shape of x)
  *                     and, if d_residual != NULL, d_residual = dy * relu'  (shape of y, pool == 1).
@@ -150,11 +153,11 @@ int coin_bn_stats(const void* x, int N, int H, int W, int C, float eps, float mo
                   float* mean, float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, int dtype,
                   void* stream);
 int coin_bn_apply_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                      const void* residual, void* y, int N, int H, int W, int C, int relu, int pool, int dtype,
+                      const void* residual, void* y, uint8_t* relu_mask, int N, int H, int W, int C, int relu, int pool, int dtype,
                       void* stream);
-int coin_bn_bwd(const void* x, const void* dy, const void* y, const float* mean, const float* rstd,
-                const float* gamma, const float* beta, int N, int H, int W, int C, int relu, int pool,
-                float* dsums, void* dx, void* d_residual, int dtype, void* stream);
+int coin_bn_bwd(const void* x, const void* dy, const void* y, const uint8_t* relu_mask, const float* mean, const float* rstd,
+                const float* gamma, const float* beta, int N, int H, int W, int C, int relu, int pool, float* dsums, void* dx,
+                void* d_residual, int dtype, void* stream);
 
 /* nn.AvgPool2d(2) forward / backward on channels-last tensors (the anti-aliased shortcut of utils.py:71-75). */
 int coin_avgpool2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);

@@ -985,3 +985,38 @@ def test_bn_counter_is_incremented_by_the_statistics_launch(monkeypatch):
     with torch.no_grad():
         L.bn_act(x, bn, True)
     assert int(bn.num_batches_tracked) == 4 and torch.equal(rm, bn.running_mean)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("pool", [1, 0])
+def test_bn_relu_bit_mask_gives_the_backward_of_the_saved_output(K, dtype, pool):
+    """coin_bn_apply_fwd's ReLU bit mask (one bit per element, written by the apply pass) given to coin_bn_bwd in place of the saved
+    output (pool 1) / the residual input (pool 0): every gradient is BIT-identical, and the mask is the sign of the output."""
+    n, h, w, c = 37, 7, 7, 256
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn((n, h, w, c), generator=g, device="cuda").to(dtype)
+    r = torch.randn((n, h, w, c), generator=g, device="cuda").to(dtype)
+    gam, bet = torch.rand(c, generator=g, device="cuda") + 0.5, torch.randn(c, generator=g, device="cuda")
+    mean, rstd = K.bn_stats(x, 1e-5, 0.1)
+    y0 = K.bn_apply_fwd(x, mean, rstd, gam, bet, r, True, pool)
+    y1, mask = K.bn_apply_fwd(x, mean, rstd, gam, bet, r, True, pool, want_mask=True)
+    assert torch.equal(y0, y1)
+    v = 8 if dtype == torch.bfloat16 else 4
+    assert mask.shape == (n * h * w, c // v) and mask.dtype == torch.uint8
+    bits = ((mask.view(n, h, w, c // v, 1).int() >> torch.arange(v, device="cuda").view(1, 1, 1, 1, v)) & 1).bool().view(n, h, w, c)
+    if pool == 1:
+        assert torch.equal(bits, y1 > 0)
+    else:
+        pre = (x.float() - mean) * (rstd * gam) + bet + r.float()
+        assert float((bits != (pre > 0)).float().mean()) < 1e-4   # fp32 evaluation order at |pre| ~ 1e-7
+    dy = torch.randn(y0.shape, generator=g, device="cuda").to(dtype)
+    a = K.bn_bwd(x, dy, y0 if pool == 1 else r, mean, rstd, gam, bet, True, pool, True)
+    b = K.bn_bwd(x, dy, None, mean, rstd, gam, bet, True, pool, True, mask=mask)
+    if pool == 1:
+        for u, t in zip(a, b):
+            assert torch.equal(u, t)
+    else:  # pool 0: the reference path recomputes the pre-activation (same expression as the forward), so it is also exact
+        for u, t in zip(a, b):
+            assert torch.equal(u, t)
+    with pytest.raises(K.CoinHipError):
+        K.bn_apply_fwd(x, mean, rstd, gam, bet, None, True, 1, want_mask=True)

@@ -29,6 +29,11 @@ for name, shape, pool, resid in [("c512_14", (2048, 14, 14, 512), 1, False), ("c
     y = K.bn_apply_fwd(x, mean, rstd, gam, bet, r, True, pool)
     dy = torch.randn_like(y)
     t_bwd = timeit(lambda: K.bn_bwd(x, dy, y if pool == 1 else None, mean, rstd, gam, bet, True, pool, resid))
+    t_apply_m = t_bwd_m = None
+    if resid:  # the ReLU bit mask instead of the saved output
+        t_apply_m = timeit(lambda: K.bn_apply_fwd(x, mean, rstd, gam, bet, r, True, pool, want_mask=True))
+        _, mk = K.bn_apply_fwd(x, mean, rstd, gam, bet, r, True, pool, want_mask=True)
+        t_bwd_m = timeit(lambda: K.bn_bwd(x, dy, None, mean, rstd, gam, bet, True, pool, resid, mask=mk))
     # torch reference
     xt = x.permute(0, 3, 1, 2).detach().requires_grad_(True)
     bn = torch.nn.BatchNorm2d(c).cuda()
@@ -40,6 +45,6 @@ for name, shape, pool, resid in [("c512_14", (2048, 14, 14, 512), 1, False), ("c
     def tb():
         o = tf(); o.backward(go)
     t_tfb = timeit(tb)
-    res[name] = {"x_GB": gb, "stats_ms": t_stats, "stats_GBps": gb / t_stats * 1e3, "apply_ms": t_apply, "bwd_ms": t_bwd,
+    res[name] = {"x_GB": gb, "stats_ms": t_stats, "stats_GBps": gb / t_stats * 1e3, "apply_ms": t_apply, "bwd_ms": t_bwd, "apply_mask_ms": t_apply_m, "bwd_mask_ms": t_bwd_m,
                  "ours_fwd_ms": t_stats + t_apply, "ours_fwdbwd_ms": t_stats + t_apply + t_bwd, "torch_fwd_ms": t_tf, "torch_fwdbwd_ms": t_tfb}
 print(json.dumps(res, indent=1))
