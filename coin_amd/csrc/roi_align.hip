@@ -77,6 +77,20 @@ __device__ __forceinline__ void vec_fma(float (&acc)[Vec16<T>::N], const typenam
   for (int i = 0; i < Vec16<T>::N; ++i) acc[i] += w * (float)v[i];
 }
 
+// summed bilinear weight that the samples of bin `b` put on map coordinate `k` (one axis); same ops as axis_taps
+__device__ __forceinline__ float bin_weight(float start, float binsz, int grid, int b, int k, int size) {
+  float wsum = 0.f;
+  for (int i = 0; i < grid; ++i) {
+    const float v = start + (float)b * binsz + ((float)i + 0.5f) * binsz / (float)grid;
+    int lo, hi;
+    float wl, wh;
+    if (!axis_taps(v, size, lo, hi, wl, wh)) continue;
+    if (lo == k) wsum += wl;
+    if (hi == k) wsum += wh;
+  }
+  return wsum;
+}
+
 // ------------------------------------------------------------------------------------------
 // forward, NHWC
 // ------------------------------------------------------------------------------------------
@@ -163,20 +177,133 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_kernel(
   }
 }
 
-// summed bilinear weight that the samples of bin `b` put on map coordinate `k` (one axis); same ops as axis_taps
-__device__ __forceinline__ float bin_weight(float start, float binsz, int grid, int b, int k, int size) {
-  float wsum = 0.f;
-  for (int i = 0; i < grid; ++i) {
-    const float v = start + (float)b * binsz + ((float)i + 0.5f) * binsz / (float)grid;
-    int lo, hi;
-    float wl, wh;
-    if (!axis_taps(v, size, lo, hi, wl, wh)) continue;
-    if (lo == k) wsum += wl;
-    if (hi == k) wsum += wh;
-  }
-  return wsum;
-}
 
+
+// Column-walk forward (channels-last, pw in {7, 14}: the kernel the detector's poolers run).  RoIAlign is separable:
+//   out[py][px][c] = inv_count * sum_x Wx[px][x] * ( sum_y Wy[py][y] * feat[y][x][c] ),
+// Wy[py][y] / Wx[px][x] = the summed bilinear weights that the samples of bin row py / bin column px put on map row y / column x
+// (bin_weight: the same tap rule, sample by sample).  One WAVE owns (RoI, py, 7 bins, 64 channel groups of 16 bytes) and keeps its 7
+// output pixels as accumulators in registers (128 VGPRs: 4 waves per SIMD); it walks the DISTINCT map columns of its bins' footprint
+// once, reading the (<= grid + 1) rows that bin row py touches -- the next column's rows are requested before the current one is
+// folded in -- instead of 4 taps per sample per output pixel: a 14 x 14 pooling of a box of 8 x 8 map cells reads 18 rows of
+// 16 bytes per lane and output row instead of 56; 20 x 20 cells: 63 instead of 224.  Weights are wave-uniform (lane p computes the
+// column weights of bin p, v_readlane / v_readfirstlane turn them into scalars, zero weights are skipped by scalar branches).
+// No LDS, no barrier.  Measured (tools/roibench.py, [4,50,83,1024] bf16, 2048 boxes, 14 x 14): boxes of 32-400 px 0.357 ms against
+// 0.431 ms of the per-sample kernel, 300-800 px 0.95 against 1.32, 16-96 px 0.245 against 0.255; without its stores 0.31 / 0.92 /
+// 0.17 ms, without its loads 0.145 ms (the 822 MB write stream at 5.7 TB/s) -- the gather phase is bound by instruction issue
+// (8-byte lanes = twice the instructions: 0.57 ms; pinning channel slabs to XCDs so that a map slab fits one L2: 0.405 ms, no gain),
+// not by L2 / Infinity Cache bandwidth.
+template <typename T, bool ML>
+__global__ __launch_bounds__(256) void roi_align_fwd_cols_kernel(
+    const T* __restrict__ feat, const float* __restrict__ rois, T* __restrict__ out, int C, int H, int W, int R,
+    int ph, int pw, float scale, int sampling_ratio, int aligned, const RoiLevelTable lv, const int* __restrict__ roi_level, int nlevels,
+    int wpr /* waves per (RoI, py, 7-bin group): ceil(C / VEC / 64) */, int bpr /* blocks per RoI */, int variant /* lab: bit 2 no loads, bit 3 no stores */) {
+  constexpr int VEC = Vec16<T>::N;
+  constexpr int PG = 7;                     // bins per wave: 7 accumulators x VEC channels in registers (pw = 7 or 14)
+  typedef typename Vec16<T>::type vec_t;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, s = bid >> 3;
+  const int ngrp = pw / PG;
+  const int roi = xcd + 8 * (s / bpr);      // every block of one RoI runs on one XCD
+  const int unit = (s % bpr) * 4 + (threadIdx.x >> 6);
+  if (roi >= R || unit >= ph * ngrp * wpr) return;
+  const int slab = unit % wpr, grp = (unit / wpr) % ngrp, py = unit / (wpr * ngrp);
+  const int px0 = grp * PG;
+  const int lane = threadIdx.x & 63;
+  if (ML) {
+    int l = roi_level[roi];
+    l = l < 0 ? 0 : (l >= nlevels ? nlevels - 1 : l);
+    feat = (const T*)lv.feat[0];
+    H = lv.H[0];
+    W = lv.W[0];
+    scale = lv.scale[0];
+#pragma unroll
+    for (int k = 1; k < COIN_ROI_MAX_LEVELS; ++k)
+      if (l == k) {
+        feat = (const T*)lv.feat[k];
+        H = lv.H[k];
+        W = lv.W[k];
+        scale = lv.scale[k];
+      }
+  }
+  const RoiGeom g = roi_geom(rois + (size_t)roi * 5, ph, pw, scale, sampling_ratio, aligned);
+  const int ncg = C / VEC;
+  const int cg = slab * 64 + lane;
+  const int cgl = cg < ncg ? cg : ncg - 1;       // lanes past the last channel group repeat it (loads stay in bounds); not stored
+  float acc[PG][VEC];
+#pragma unroll
+  for (int p = 0; p < PG; ++p)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[p][i] = 0.f;
+  if (g.gh > 0 && g.gw > 0 && !(variant & 4)) {
+    // footprint of this output row (rows) and of this wave's 7 bins (columns); a superset is harmless (weights of untouched lines are 0)
+    const float ya = g.y0 + (float)py * g.bh + 0.5f * g.bh / (float)g.gh, yb = g.y0 + (float)py * g.bh + ((float)g.gh - 0.5f) * g.bh / (float)g.gh;
+    const float xa = g.x0 + (float)px0 * g.bw + 0.5f * g.bw / (float)g.gw;
+    const float xb = g.x0 + (float)(px0 + PG - 1) * g.bw + ((float)g.gw - 0.5f) * g.bw / (float)g.gw;
+    const float ylo = fminf(ya, yb), yhi = fmaxf(ya, yb), xlo = fminf(xa, xb), xhi = fmaxf(xa, xb);
+    if (!(yhi < -1.0f || ylo > (float)H || xhi < -1.0f || xlo > (float)W)) {
+      const int ymin = (int)fminf(fmaxf(floorf(ylo), 0.f), (float)(H - 1)), ymax = (int)fminf(fmaxf(floorf(yhi) + 1.f, 0.f), (float)(H - 1));
+      const int xmin = (int)fminf(fmaxf(floorf(xlo), 0.f), (float)(W - 1)), xmax = (int)fminf(fmaxf(floorf(xhi) + 1.f, 0.f), (float)(W - 1));
+      const T* __restrict__ fmap = feat + (size_t)g.n * H * W * C + (size_t)cgl * VEC;
+      const int pxl = px0 + (lane < PG ? lane : PG - 1);
+      for (int y0 = ymin; y0 <= ymax; y0 += 4) {            // four map rows per sweep (a bin row touches grid + 1 rows: <= 4 up to 42-cell boxes)
+        float wk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          // (every lane computes the same value: wave-uniform by construction; readfirstlane makes it a scalar for the branches)
+          const float w = (y0 + u <= ymax) ? bin_weight(g.y0, g.bh, g.gh, py, y0 + u, H) : 0.f;
+          wk[u] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w)));
+        }
+        if (wk[0] == 0.f && wk[1] == 0.f && wk[2] == 0.f && wk[3] == 0.f) continue;
+        const T* __restrict__ fy = fmap + (size_t)y0 * W * C;
+        const size_t rs = (size_t)W * C;
+        vec_t vn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (wk[u] != 0.f) vn[u] = *reinterpret_cast<const vec_t*>(fy + u * rs + (size_t)xmin * C);
+        for (int x = xmin; x <= xmax; ++x) {
+          vec_t v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = vn[u];
+          if (x < xmax) {                                    // the next column's rows are in flight while this one is folded in
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (wk[u] != 0.f) vn[u] = *reinterpret_cast<const vec_t*>(fy + u * rs + (size_t)(x + 1) * C);
+          }
+          const float wxv = bin_weight(g.x0, g.bw, g.gw, pxl, x, W);
+          if (__ballot(wxv != 0.f) == 0ull) continue;
+          float col[VEC];
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) col[i] = 0.f;
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (wk[u] != 0.f) {
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) col[i] += wk[u] * (float)v[u][i];
+            }
+#pragma unroll
+          for (int p = 0; p < PG; ++p) {
+            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wxv), p));
+            if (w != 0.f) {
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) acc[p][i] += w * col[i];
+            }
+          }
+        }
+      }
+    }
+  }
+  if (cg < ncg && !((variant & 8) && acc[0][0] != 12345.f)) {
+    T* __restrict__ orow = out + (((size_t)roi * ph + py) * pw + px0) * C + (size_t)cg * VEC;
+#pragma unroll
+    for (int p = 0; p < PG; ++p) {
+      vec_t o;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o[i] = (T)(acc[p][i] * g.inv_count);
+      *reinterpret_cast<vec_t*>(orow + (size_t)p * C) = o;   // (non-temporal stores: 0.41 against 0.36 ms at the benchmark's box sizes)
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------------
 // backward, NHWC, bins larger than 16 x 16 only (the tile-gather kernel below serves the detector's 14 x 14 / 7 x 7 bins): separable gather
@@ -303,12 +430,13 @@ constexpr int LIST_CAP = 4096;  // RoIs per tile list (ordered compaction)
 // ------------------------------------------------------------------------------------------
 constexpr int BT_ROWS = 4, BT_COLS = 8, BT_LC = 32;
 
-template <typename T>
+// VEC = channels per lane (4: 16-byte f32 / 8-byte bf16 loads; a wave covers 256 channels).  With 8 bf16 channels per lane the 1024-channel
+// res4 gradient gave 1 144 workgroups whose longest (the central tiles, touched by ~40 % of an image's boxes) bounded the launch.
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
     const T* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gfeat, int C, int H, int W, int R, int ph, int pw,
     float scale, int sampling_ratio, int aligned, int tiles_x, int tiles_y, int ntiles, int nparts, const int* __restrict__ roi_level, int level) {
-  constexpr int VEC = Vec16<T>::N;
-  typedef typename Vec16<T>::type vec_t;
+  typedef T vec_t __attribute__((ext_vector_type(VEC)));
   __shared__ unsigned short list[LIST_CAP];
   __shared__ int wave_cnt[4];
   __shared__ int list_n;
@@ -443,16 +571,22 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
         const int roi = base + (int)list[lb + li];
         const T* __restrict__ go = gout + (size_t)roi * ph * pw * C + (c_ok ? c0 : 0);
         while (ym) {
-          const int py = __builtin_ctz(ym);
+          // two bin rows per round: up to 8 gradient bins (one wave-instruction each) in flight
+          const int py0 = __builtin_ctz(ym);
           ym &= ym - 1;
-          const float a = wyt[li][py][wave];
-          const T* __restrict__ grow = go + (size_t)py * pw * C;
+          const int py1 = ym ? __builtin_ctz(ym) : -1;
+          if (py1 >= 0) ym &= ym - 1;
+          const float a0 = wyt[li][py0][wave];
+          const float a1 = py1 >= 0 ? wyt[li][py1][wave] : 0.f;
+          const T* __restrict__ grow0 = go + (size_t)py0 * pw * C;
+          const T* __restrict__ grow1 = go + (size_t)(py1 >= 0 ? py1 : py0) * pw * C;
           for (int px = pa; px < pe; px += 4) {
-            vec_t v[4];
+            vec_t v[8];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int pp = px + j < pe ? px + j : pe - 1;
-              v[j] = *reinterpret_cast<const vec_t*>(grow + (size_t)pp * C);
+              v[j] = *reinterpret_cast<const vec_t*>(grow0 + (size_t)pp * C);
+              if (py1 >= 0) v[4 + j] = *reinterpret_cast<const vec_t*>(grow1 + (size_t)pp * C);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -461,14 +595,19 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
               if (mk == 0) continue;
               const f32x4 w0 = *reinterpret_cast<const f32x4*>(&wxt[li][px + j][0]);
               const f32x4 w1 = *reinterpret_cast<const f32x4*>(&wxt[li][px + j][4]);
+              // the two rows are combined first (fixed order), then fanned out to the tile columns
               float vf[VEC];
 #pragma unroll
-              for (int i = 0; i < VEC; ++i) vf[i] = (float)v[j][i];
+              for (int i = 0; i < VEC; ++i) vf[i] = a0 * (float)v[j][i];
+              if (py1 >= 0) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) vf[i] += a1 * (float)v[4 + j][i];
+              }
 #pragma unroll
               for (int t = 0; t < BT_COLS; ++t) {
                 if (mk & (1u << t)) {
                   asm volatile("; col taken");  // a real wave-uniform branch (see the forward kernel)
-                  const float wt = a * (t < 4 ? w0[t & 3] : w1[t & 3]);
+                  const float wt = t < 4 ? w0[t & 3] : w1[t & 3];
 #pragma unroll
                   for (int i = 0; i < VEC; ++i) acc[t][i] += wt * vf[i];
                 }
@@ -579,6 +718,30 @@ int check_common(const void* a, const void* rois, const void* b, int N, int C, i
 
 }  // namespace
 
+// launch of the column-walk forward (pw in {7, 14}); returns false if the shape is not served by it
+int g_roi_fwd_variant = 0;   // lab hook (tools/roibench.py): bit 0 = per-sample kernel for every shape; bits 2 / 3 = column-walk kernel without its loads / stores
+
+template <bool ML>
+static bool launch_fwd_cols(const void* feat, const float* rois, void* out, int C, int H, int W, int R, int ph, int pw, float scale,
+                            int sampling_ratio, int aligned, const RoiLevelTable& lv, const int* roi_level, int nlevels, int dtype, hipStream_t st) {
+  if ((pw != 7 && pw != 14) || (g_roi_fwd_variant & 1)) return false;
+  const int vec = dtype == COIN_F32 ? 4 : 8;
+  const int wpr = (C / vec + 63) / 64;
+  const int bpr = (ph * (pw / 7) * wpr + 3) / 4;
+  const long long nblk = (long long)((R + 7) / 8) * 8 * bpr;
+  if (nblk > 0x7fffffffLL) return false;
+  const int grid = (int)nblk;
+#define GO(T) roi_align_fwd_cols_kernel<T, ML><<<grid, 256, 0, st>>>((const T*)feat, rois, (T*)out, C, H, W, R, ph, pw, scale, sampling_ratio, aligned, lv, roi_level, nlevels, wpr, bpr, g_roi_fwd_variant)
+  if (dtype == COIN_F32)
+    GO(float);
+  else
+    GO(bf16_t);
+#undef GO
+  return true;
+}
+
+extern "C" void coin_roi_align_lab_variant(int v) { g_roi_fwd_variant = v; }
+
 extern "C" int coin_roi_align_fwd(const void* feat, int N, int C, int H, int W, int layout, const float* rois,
                                   int R, int ph, int pw, float spatial_scale, int sampling_ratio, int aligned,
                                   void* out, int dtype, void* stream) {
@@ -586,11 +749,11 @@ extern "C" int coin_roi_align_fwd(const void* feat, int N, int C, int H, int W, 
   if (rc) return rc;
   if (R == 0) return COIN_OK;
   hipStream_t st = (hipStream_t)stream;
-  // (A separable forward -- row pass into LDS, then a column pass -- was built and measured in round 2: 0.46 ms against 0.40 ms of this
-  // kernel at the benchmark shape; each output needs 4-16 taps out of L2 and the kernel is bound by those gathers, so it was removed.)
   if (layout == COIN_NHWC) {
     const int grid = ((R + 7) / 8) * 8 * ph;
     const RoiLevelTable none = {};
+    if (launch_fwd_cols<false>(feat, rois, out, C, H, W, R, ph, pw, spatial_scale, sampling_ratio, aligned, none, nullptr, 0, dtype, st))
+      return coin_launch_status();
     if (dtype == COIN_F32)
       roi_align_fwd_nhwc_kernel<float, false><<<grid, 256, 0, st>>>((const float*)feat, rois, (float*)out, C, H, W, R, ph,
                                                                       pw, spatial_scale, sampling_ratio, aligned, none, nullptr, 0);
@@ -627,11 +790,11 @@ static int roi_align_bwd_impl(const void* grad_out, int N, int C, int H, int W, 
     const int ntiles = tiles_x * tiles_y * N;
     if (dtype == COIN_F32) {
       const int nparts = (C + 64 * 4 - 1) / (64 * 4);
-      roi_align_bwd_gather_kernel<float><<<ntiles * nparts, 256, 0, st>>>((const float*)grad_out, rois, grad_feat, C, H, W, R, ph, pw, spatial_scale,
+      roi_align_bwd_gather_kernel<float, 4><<<ntiles * nparts, 256, 0, st>>>((const float*)grad_out, rois, grad_feat, C, H, W, R, ph, pw, spatial_scale,
                                                                           sampling_ratio, aligned, tiles_x, tiles_y, ntiles, nparts, roi_level, level);
     } else {
-      const int nparts = (C + 64 * 8 - 1) / (64 * 8);
-      roi_align_bwd_gather_kernel<bf16_t><<<ntiles * nparts, 256, 0, st>>>((const bf16_t*)grad_out, rois, grad_feat, C, H, W, R, ph, pw, spatial_scale,
+      const int nparts = (C + 64 * 4 - 1) / (64 * 4);
+      roi_align_bwd_gather_kernel<bf16_t, 4><<<ntiles * nparts, 256, 0, st>>>((const bf16_t*)grad_out, rois, grad_feat, C, H, W, R, ph, pw, spatial_scale,
                                                                            sampling_ratio, aligned, tiles_x, tiles_y, ntiles, nparts, roi_level, level);
     }
   } else if (roi_level != nullptr) {
@@ -690,6 +853,8 @@ extern "C" int coin_roi_align_fwd_levels(const coin_roi_level* levels, int nleve
   }
   if (R == 0) return COIN_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (launch_fwd_cols<true>(nullptr, rois, out, C, 0, 0, R, ph, pw, 0.f, sampling_ratio, aligned, t, roi_level, nlevels, dtype, st))
+    return coin_launch_status();
   const int grid = ((R + 7) / 8) * 8 * ph;
   if (dtype == COIN_F32)
     roi_align_fwd_nhwc_kernel<float, true><<<grid, 256, 0, st>>>(nullptr, rois, (float*)out, C, 0, 0, R, ph, pw, 0.f, sampling_ratio, aligned, t, roi_level, nlevels);
