@@ -179,6 +179,95 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_kernel(
 
 
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// 16 bytes of channels as pairs of floats (the arithmetic of the column walk runs on v_pk_mul_f32 / v_pk_fma_f32: the kernel is
+// bound by vector-ALU issue -- a wave64 instruction occupies its 16-lane SIMD for 4 cycles -- and packed fp32 halves the count)
+__device__ __forceinline__ void to_pairs(const bf16x8& v, f32x2 (&o)[4]) {
+  const uint4 u = __builtin_bit_cast(uint4, v);
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    o[k].x = __builtin_bit_cast(float, w[k] << 16);
+    o[k].y = __builtin_bit_cast(float, w[k] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void to_pairs(const f32x4& v, f32x2 (&o)[2]) {
+  o[0].x = v[0];
+  o[0].y = v[1];
+  o[1].x = v[2];
+  o[1].y = v[3];
+}
+
+// bin_weight with the per-sample step (bin size / grid) and the bin's start precomputed: no division in the loop.  The sample
+// coordinate may differ from bin_weight's by one rounding (the interpolation is continuous in it).
+__device__ __forceinline__ float bin_weight_step(float bin_start, float step, int grid, int k, int size) {
+  float wsum = 0.f;
+  for (int i = 0; i < grid; ++i) {
+    const float v = bin_start + ((float)i + 0.5f) * step;
+    int lo, hi;
+    float wl, wh;
+    if (!axis_taps(v, size, lo, hi, wl, wh)) continue;
+    if (lo == k) wsum += wl;
+    if (hi == k) wsum += wh;
+  }
+  return wsum;
+}
+
+// one sweep of the column-walk forward: NR consecutive map rows (weights wk, wave-uniform) x the columns [xmin, xmax]
+template <typename T, int NR, int PG>
+__device__ __forceinline__ void cols_sweep(const T* __restrict__ fy, size_t rs, int C, int xmin, int xmax, const float (&wk)[4],
+                                           float bin_start, float step, int gw, int W, f32x2 (&acc)[PG][Vec16<T>::N / 2]) {
+  constexpr int VP = Vec16<T>::N / 2;
+  typedef typename Vec16<T>::type vec_t;
+  // fold one column (its NR rows are in `v`) into the bins that have weight on it
+  auto fold = [&](const vec_t (&v)[NR], int x) {
+    const float wxv = bin_weight_step(bin_start, step, gw, x, W);
+    if (__ballot(wxv != 0.f) == 0ull) return;
+    f32x2 col[VP];
+    {
+      f32x2 f[VP];
+      to_pairs(v[0], f);
+      const f32x2 w0 = {wk[0], wk[0]};
+#pragma unroll
+      for (int k = 0; k < VP; ++k) col[k] = w0 * f[k];
+    }
+#pragma unroll
+    for (int u = 1; u < NR; ++u) {
+      f32x2 f[VP];
+      to_pairs(v[u], f);
+      const f32x2 wu = {wk[u], wk[u]};
+#pragma unroll
+      for (int k = 0; k < VP; ++k) col[k] = __builtin_elementwise_fma(wu, f[k], col[k]);
+    }
+#pragma unroll
+    for (int p = 0; p < PG; ++p) {
+      const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wxv), p));
+      if (w != 0.f) {
+        const f32x2 ww = {w, w};
+#pragma unroll
+        for (int k = 0; k < VP; ++k) acc[p][k] = __builtin_elementwise_fma(ww, col[k], acc[p][k]);
+      }
+    }
+  };
+  // two register sets, used alternately: the rows of column x + 1 are requested before column x is folded in, and no register
+  // of a pending load is copied (a `v = vn` rotation made the compiler wait for the prefetch at the top of every iteration)
+  vec_t va[NR], vb[NR];
+#pragma unroll
+  for (int u = 0; u < NR; ++u) va[u] = *reinterpret_cast<const vec_t*>(fy + u * rs + (size_t)xmin * C);
+#pragma nounroll
+  for (int x = xmin; x <= xmax; x += 2) {
+    const int x1 = x + 1 <= xmax ? x + 1 : xmax;        // (past the end the last column is requested again: an L2 hit instead of a branch)
+#pragma unroll
+    for (int u = 0; u < NR; ++u) vb[u] = *reinterpret_cast<const vec_t*>(fy + u * rs + (size_t)x1 * C);
+    fold(va, x);
+    const int x2 = x + 2 <= xmax ? x + 2 : xmax;
+#pragma unroll
+    for (int u = 0; u < NR; ++u) va[u] = *reinterpret_cast<const vec_t*>(fy + u * rs + (size_t)x2 * C);
+    if (x + 1 <= xmax) fold(vb, x + 1);
+  }
+}
+
 // Column-walk forward (channels-last, pw in {7, 14}: the kernel the detector's poolers run).  RoIAlign is separable:
 //   out[py][px][c] = inv_count * sum_x Wx[px][x] * ( sum_y Wy[py][y] * feat[y][x][c] ),
 // Wy[py][y] / Wx[px][x] = the summed bilinear weights that the samples of bin row py / bin column px put on map row y / column x
@@ -188,12 +277,14 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_kernel(
 // folded in -- instead of 4 taps per sample per output pixel: a 14 x 14 pooling of a box of 8 x 8 map cells reads 18 rows of
 // 16 bytes per lane and output row instead of 56; 20 x 20 cells: 63 instead of 224.  Weights are wave-uniform (lane p computes the
 // column weights of bin p, v_readlane / v_readfirstlane turn them into scalars, zero weights are skipped by scalar branches).
-// No LDS, no barrier.  Measured (tools/roibench.py, [4,50,83,1024] bf16, 2048 boxes, 14 x 14): boxes of 32-400 px 0.357 ms against
-// 0.431 ms of the per-sample kernel, 300-800 px 0.95 against 1.32, 16-96 px 0.245 against 0.255; without its stores 0.31 / 0.92 /
-// 0.17 ms, without its loads 0.145 ms (the 822 MB write stream at 5.7 TB/s) -- the gather phase is bound by instruction issue
-// (8-byte lanes = twice the instructions: 0.57 ms; pinning channel slabs to XCDs so that a map slab fits one L2: 0.405 ms, no gain),
-// not by L2 / Infinity Cache bandwidth.
-template <typename T, bool ML>
+// No LDS, no barrier.  Measured (tools/roibench.py, [4,50,83,1024] bf16, 2048 boxes, 14 x 14): boxes of 32-400 px 0.358 ms against
+// 0.44-0.45 ms of the per-sample kernel, 300-800 px 0.87 against 1.34, 16-96 px 0.241 against 0.28; without its stores 0.25 / 0.85 /
+// 0.14 ms, without its loads 0.14 ms (the 822 MB write stream at 5.9 TB/s).  The gather phase is bound by vector-ALU issue, not by
+// L2 / Infinity Cache bandwidth or latency (SQ counters, profiles/r4_roi_pmc_sq.csv: 193 M wave-instructions x 4 cycles on 1 024
+// SIMDs = 0.31 ms for the first version): packed fp32 arithmetic and division-free bin weights took it from 0.31 to 0.25 ms; 8-byte
+// lanes (twice the instructions) 0.57 ms; pinning channel slabs to XCDs so that a map slab fits one L2 0.405 ms; a real prefetch
+// (two register sets, counted `vmcnt`) instead of one the compiler had to wait for: no change.
+template <typename T, bool ML, int SW /* map rows per sweep */>
 __global__ __launch_bounds__(256) void roi_align_fwd_cols_kernel(
     const T* __restrict__ feat, const float* __restrict__ rois, T* __restrict__ out, int C, int H, int W, int R,
     int ph, int pw, float scale, int sampling_ratio, int aligned, const RoiLevelTable lv, const int* __restrict__ roi_level, int nlevels,
@@ -226,15 +317,26 @@ __global__ __launch_bounds__(256) void roi_align_fwd_cols_kernel(
         scale = lv.scale[k];
       }
   }
-  const RoiGeom g = roi_geom(rois + (size_t)roi * 5, ph, pw, scale, sampling_ratio, aligned);
+  RoiGeom g = roi_geom(rois + (size_t)roi * 5, ph, pw, scale, sampling_ratio, aligned);
+  {  // the geometry is wave-uniform: keep it in scalar registers (the float arithmetic above ran on the vector unit)
+    auto uf = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    g.n = __builtin_amdgcn_readfirstlane(g.n);
+    g.gw = __builtin_amdgcn_readfirstlane(g.gw);
+    g.gh = __builtin_amdgcn_readfirstlane(g.gh);
+    g.x0 = uf(g.x0);
+    g.y0 = uf(g.y0);
+    g.bw = uf(g.bw);
+    g.bh = uf(g.bh);
+    g.inv_count = uf(g.inv_count);
+  }
   const int ncg = C / VEC;
   const int cg = slab * 64 + lane;
   const int cgl = cg < ncg ? cg : ncg - 1;       // lanes past the last channel group repeat it (loads stay in bounds); not stored
-  float acc[PG][VEC];
+  f32x2 acc[PG][VEC / 2];
 #pragma unroll
   for (int p = 0; p < PG; ++p)
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) acc[p][i] = 0.f;
+    for (int k = 0; k < VEC / 2; ++k) acc[p][k] = f32x2{0.f, 0.f};
   if (g.gh > 0 && g.gw > 0 && !(variant & 4)) {
     // footprint of this output row (rows) and of this wave's 7 bins (columns); a superset is harmless (weights of untouched lines are 0)
     const float ya = g.y0 + (float)py * g.bh + 0.5f * g.bh / (float)g.gh, yb = g.y0 + (float)py * g.bh + ((float)g.gh - 0.5f) * g.bh / (float)g.gh;
@@ -246,60 +348,45 @@ __global__ __launch_bounds__(256) void roi_align_fwd_cols_kernel(
       const int xmin = (int)fminf(fmaxf(floorf(xlo), 0.f), (float)(W - 1)), xmax = (int)fminf(fmaxf(floorf(xhi) + 1.f, 0.f), (float)(W - 1));
       const T* __restrict__ fmap = feat + (size_t)g.n * H * W * C + (size_t)cgl * VEC;
       const int pxl = px0 + (lane < PG ? lane : PG - 1);
-      for (int y0 = ymin; y0 <= ymax; y0 += 4) {            // four map rows per sweep (a bin row touches grid + 1 rows: <= 4 up to 42-cell boxes)
-        float wk[4];
+      const float xstep = g.bw / (float)g.gw, ystep = g.bh / (float)g.gh;
+      const float xbin = g.x0 + (float)pxl * g.bw, ybin = g.y0 + (float)py * g.bh;   // start of this lane's bin column / this wave's bin row
+      for (int y0 = ymin; y0 <= ymax; y0 += SW) {           // SW map rows per sweep (a bin row touches grid + 1 rows)
+        const int nr = (ymax - y0 + 1) < SW ? (ymax - y0 + 1) : SW;
+        float wk[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          // (every lane computes the same value: wave-uniform by construction; readfirstlane makes it a scalar for the branches)
-          const float w = (y0 + u <= ymax) ? bin_weight(g.y0, g.bh, g.gh, py, y0 + u, H) : 0.f;
+        for (int u = 0; u < SW; ++u) {
+          // (every lane computes the same value: wave-uniform by construction; readfirstlane makes it a scalar)
+          const float w = u < nr ? bin_weight_step(ybin, ystep, g.gh, y0 + u, H) : 0.f;
           wk[u] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w)));
         }
         if (wk[0] == 0.f && wk[1] == 0.f && wk[2] == 0.f && wk[3] == 0.f) continue;
         const T* __restrict__ fy = fmap + (size_t)y0 * W * C;
         const size_t rs = (size_t)W * C;
-        vec_t vn[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (wk[u] != 0.f) vn[u] = *reinterpret_cast<const vec_t*>(fy + u * rs + (size_t)xmin * C);
-        for (int x = xmin; x <= xmax; ++x) {
-          vec_t v[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) v[u] = vn[u];
-          if (x < xmax) {                                    // the next column's rows are in flight while this one is folded in
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-              if (wk[u] != 0.f) vn[u] = *reinterpret_cast<const vec_t*>(fy + u * rs + (size_t)(x + 1) * C);
-          }
-          const float wxv = bin_weight(g.x0, g.bw, g.gw, pxl, x, W);
-          if (__ballot(wxv != 0.f) == 0ull) continue;
-          float col[VEC];
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) col[i] = 0.f;
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (wk[u] != 0.f) {
-#pragma unroll
-              for (int i = 0; i < VEC; ++i) col[i] += wk[u] * (float)v[u][i];
-            }
-#pragma unroll
-          for (int p = 0; p < PG; ++p) {
-            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wxv), p));
-            if (w != 0.f) {
-#pragma unroll
-              for (int i = 0; i < VEC; ++i) acc[p][i] += w * col[i];
-            }
-          }
-        }
+        // One instantiation per row count: the loads of a sweep are UNCONDITIONAL inside it, so that the compiler can count them
+        // (`s_waitcnt vmcnt(NR)`: the next column's rows stay in flight while the current column is folded in).  With the loads
+        // under `if (weight != 0)` it had to wait for vmcnt(0) before every use and the prefetch bought nothing.
+        if (nr == 1)
+          cols_sweep<T, 1, PG>(fy, rs, C, xmin, xmax, wk, xbin, xstep, g.gw, W, acc);
+        else if (SW == 2 || nr == 2)
+          cols_sweep<T, 2, PG>(fy, rs, C, xmin, xmax, wk, xbin, xstep, g.gw, W, acc);
+        else if (SW == 3 || nr == 3)
+          cols_sweep<T, (SW >= 3 ? 3 : 2), PG>(fy, rs, C, xmin, xmax, wk, xbin, xstep, g.gw, W, acc);
+        else
+          cols_sweep<T, (SW >= 4 ? 4 : 2), PG>(fy, rs, C, xmin, xmax, wk, xbin, xstep, g.gw, W, acc);
       }
     }
   }
-  if (cg < ncg && !((variant & 8) && acc[0][0] != 12345.f)) {
+  if (cg < ncg && !((variant & 8) && acc[0][0].x != 12345.f)) {
     T* __restrict__ orow = out + (((size_t)roi * ph + py) * pw + px0) * C + (size_t)cg * VEC;
 #pragma unroll
     for (int p = 0; p < PG; ++p) {
       vec_t o;
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) o[i] = (T)(acc[p][i] * g.inv_count);
+      for (int k = 0; k < VEC / 2; ++k) {
+        const f32x2 r = acc[p][k] * f32x2{g.inv_count, g.inv_count};
+        o[2 * k] = (T)r.x;
+        o[2 * k + 1] = (T)r.y;
+      }
       *reinterpret_cast<vec_t*>(orow + (size_t)p * C) = o;   // (non-temporal stores: 0.41 against 0.36 ms at the benchmark's box sizes)
     }
   }
@@ -719,6 +806,9 @@ int check_common(const void* a, const void* rois, const void* b, int N, int C, i
 }  // namespace
 
 // launch of the column-walk forward (pw in {7, 14}); returns false if the shape is not served by it
+#ifndef BF16_SW
+#define BF16_SW 3
+#endif
 int g_roi_fwd_variant = 0;   // lab hook (tools/roibench.py): bit 0 = per-sample kernel for every shape; bits 2 / 3 = column-walk kernel without its loads / stores
 
 template <bool ML>
@@ -731,11 +821,11 @@ static bool launch_fwd_cols(const void* feat, const float* rois, void* out, int 
   const long long nblk = (long long)((R + 7) / 8) * 8 * bpr;
   if (nblk > 0x7fffffffLL) return false;
   const int grid = (int)nblk;
-#define GO(T) roi_align_fwd_cols_kernel<T, ML><<<grid, 256, 0, st>>>((const T*)feat, rois, (T*)out, C, H, W, R, ph, pw, scale, sampling_ratio, aligned, lv, roi_level, nlevels, wpr, bpr, g_roi_fwd_variant)
+#define GO(T, SW) roi_align_fwd_cols_kernel<T, ML, SW><<<grid, 256, 0, st>>>((const T*)feat, rois, (T*)out, C, H, W, R, ph, pw, scale, sampling_ratio, aligned, lv, roi_level, nlevels, wpr, bpr, g_roi_fwd_variant)
   if (dtype == COIN_F32)
-    GO(float);
+    GO(float, 3);
   else
-    GO(bf16_t);
+    GO(bf16_t, BF16_SW);
 #undef GO
   return true;
 }
