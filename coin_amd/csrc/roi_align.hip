@@ -339,16 +339,16 @@ __global__ __launch_bounds__(256) void roi_align_fwd_cols_kernel(
     for (int k = 0; k < VEC / 2; ++k) acc[p][k] = f32x2{0.f, 0.f};
   if (g.gh > 0 && g.gw > 0 && !(variant & 4)) {
     // footprint of this output row (rows) and of this wave's 7 bins (columns); a superset is harmless (weights of untouched lines are 0)
-    const float ya = g.y0 + (float)py * g.bh + 0.5f * g.bh / (float)g.gh, yb = g.y0 + (float)py * g.bh + ((float)g.gh - 0.5f) * g.bh / (float)g.gh;
-    const float xa = g.x0 + (float)px0 * g.bw + 0.5f * g.bw / (float)g.gw;
-    const float xb = g.x0 + (float)(px0 + PG - 1) * g.bw + ((float)g.gw - 0.5f) * g.bw / (float)g.gw;
+    const float xstep = g.bw / (float)g.gw, ystep = g.bh / (float)g.gh;
+    const float ya = g.y0 + (float)py * g.bh + 0.5f * ystep, yb = g.y0 + (float)py * g.bh + ((float)g.gh - 0.5f) * ystep;
+    const float xa = g.x0 + (float)px0 * g.bw + 0.5f * xstep;
+    const float xb = g.x0 + (float)(px0 + PG - 1) * g.bw + ((float)g.gw - 0.5f) * xstep;
     const float ylo = fminf(ya, yb), yhi = fmaxf(ya, yb), xlo = fminf(xa, xb), xhi = fmaxf(xa, xb);
     if (!(yhi < -1.0f || ylo > (float)H || xhi < -1.0f || xlo > (float)W)) {
       const int ymin = (int)fminf(fmaxf(floorf(ylo), 0.f), (float)(H - 1)), ymax = (int)fminf(fmaxf(floorf(yhi) + 1.f, 0.f), (float)(H - 1));
       const int xmin = (int)fminf(fmaxf(floorf(xlo), 0.f), (float)(W - 1)), xmax = (int)fminf(fmaxf(floorf(xhi) + 1.f, 0.f), (float)(W - 1));
       const T* __restrict__ fmap = feat + (size_t)g.n * H * W * C + (size_t)cgl * VEC;
       const int pxl = px0 + (lane < PG ? lane : PG - 1);
-      const float xstep = g.bw / (float)g.gw, ystep = g.bh / (float)g.gh;
       const float xbin = g.x0 + (float)pxl * g.bw, ybin = g.y0 + (float)py * g.bh;   // start of this lane's bin column / this wave's bin row
       for (int y0 = ymin; y0 <= ymax; y0 += SW) {           // SW map rows per sweep (a bin row touches grid + 1 rows)
         const int nr = (ymax - y0 + 1) < SW ? (ymax - y0 + 1) : SW;
