@@ -187,6 +187,39 @@ __device__ __forceinline__ void nt_stage(const NtCursor<GATHER3>& c, const P8Arg
   }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// 8 bf16 -> 4 pairs of floats (element 2k in .x, 2k + 1 in .y): one shift / one mask per element, exact
+__device__ __forceinline__ void p8_pairs(const bf16x8& v, f32x2 (&o)[4]) {
+  const uint4 u = __builtin_bit_cast(uint4, v);
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    o[k].x = __builtin_bit_cast(float, w[k] << 16);
+    o[k].y = __builtin_bit_cast(float, w[k] & 0xffff0000u);
+  }
+}
+
+// t[i] <- sum of t[i] over lanes l, l ^ 16, l ^ 32, l ^ 48 (the four 16-lane rows of the wave), in every lane.
+// v_permlane32_swap vdst, src: lanes 32-63 of vdst <-> lanes 0-31 of src;  v_permlane16_swap: odd rows of vdst <-> even rows of src.
+// With vdst = src = x the two results add up to the pair sums.  (`s_nop 1`: a vector-ALU write of a swap operand needs two wait
+// states before the swap reads it; inline asm is not covered by the compiler's hazard recogniser.)
+__device__ __forceinline__ void p8_rows_sum(float (&t)[8]) {
+  float u[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) u[i] = t[i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(t[i]), "+v"(u[i]));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    t[i] += u[i];
+    u[i] = t[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(t[i]), "+v"(u[i]));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] += u[i];
+}
+
 // Epilogue of one output tile: four 128 x 128 quadrants through the 32 KiB image -> whole 256-byte rows (+ residual, + statistics of
 // the stored values).  Workgroup-wide (all 512 threads, aligned); `img` = 32 KiB of LDS.
 template <bool STATS>
@@ -198,7 +231,9 @@ __device__ __forceinline__ void p8_epilogue(const P8Args& p, f32x4 (&acc)[2][2][
   if (p.dbg & 4) return;  // lab only: main loop without the epilogue
 #pragma unroll
   for (int bh = 0; bh < 2; ++bh) {
-    float s1[8], s2[8], piv[8];
+    // statistics in pairs of channels: v_pk_add_f32 / v_pk_fma_f32 (a wave64 vector instruction holds its SIMD for 4 cycles; the
+    // unpacked form spent ~4 000 SIMD cycles per tile here: 7-15 % of a 1x1 convolution's tile)
+    f32x2 s1[4], s2[4], piv[4];
 #pragma unroll
     for (int ah = 0; ah < 2; ++ah) {
       // (the previous pass's readers are past their barrier below)
@@ -218,11 +253,9 @@ __device__ __forceinline__ void p8_epilogue(const P8Args& p, f32x4 (&acc)[2][2][
       const int gcol = n0 + bh * 128 + chunk * 8;
       if (STATS && ah == 0) {
         const bf16x8 pv = *reinterpret_cast<const bf16x8*>(img + (chunk << 4));  // row 0 of the tile: every thread's pivot
+        p8_pairs(pv, piv);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          piv[i] = (float)pv[i];
-          s1[i] = s2[i] = 0.f;
-        }
+        for (int i = 0; i < 4; ++i) s1[i] = s2[i] = f32x2{0.f, 0.f};
       }
       // the four rows of this thread: R rows requested first (they queue behind nothing but the previous pass's stores), then the four
       // image reads back to back, then add / store / statistics -- one LDS latency and one memory latency per pass instead of four
@@ -243,9 +276,17 @@ __device__ __forceinline__ void p8_epilogue(const P8Args& p, f32x4 (&acc)[2][2][
       }
       if (has_r) {  // C = bf16(bf16(A.B^T) + R): what two separate launches would store
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q) {
+          f32x2 a[4], b[4];
+          p8_pairs(v[q], a);
+          p8_pairs(rr[q], b);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v[q][i] = (bf16_t)((float)v[q][i] + (float)rr[q][i]);
+          for (int i = 0; i < 4; ++i) {
+            const f32x2 t = a[i] + b[i];
+            v[q][2 * i] = (bf16_t)t.x;
+            v[q][2 * i + 1] = (bf16_t)t.y;
+          }
+        }
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -254,46 +295,60 @@ __device__ __forceinline__ void p8_epilogue(const P8Args& p, f32x4 (&acc)[2][2][
           if (p.dbg & 16) __builtin_nontemporal_store(v[q], reinterpret_cast<bf16x8*>(p.C + (size_t)grow * p.ldc + gcol));
           else *reinterpret_cast<bf16x8*>(p.C + (size_t)grow * p.ldc + gcol) = v[q];
         }
-        if (STATS && (long long)grow < p.stats_rows) {
+        if (STATS && (long long)grow < p.stats_rows && !(p.dbg & 256)) {
+          f32x2 f[4];
+          p8_pairs(v[q], f);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float d = (float)v[q][i] - piv[i];
+          for (int i = 0; i < 4; ++i) {
+            const f32x2 d = f[i] - piv[i];
             s1[i] += d;
-            s2[i] += d * d;
+            s2[i] = __builtin_elementwise_fma(d, d, s2[i]);
           }
         }
       }
       P8_LDS_SYNC();
     }
-    if (STATS) {
+    if (STATS && !(p.dbg & 512)) {
       // threads with equal `chunk`: lanes l, l ^ 16, l ^ 32 of a wave, then the 8 waves through the (free) image, fixed order
+      // lanes l, l ^ 32, then l ^ 16, with v_permlane32_swap / v_permlane16_swap (vector ALU).  As 64 `ds_bpermute`s per wave and
+      // tile these sums cost ~4 000 cycles of the CU's LDS crossbar per tile (lab stamps: statistics epilogue 14 800 cycles against
+      // 7 000 without; 9 200 with this reduction switched off).
+      float t1[8], t2[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        s1[i] += __shfl_xor(s1[i], 16, 64);
-        s2[i] += __shfl_xor(s2[i], 16, 64);
-        s1[i] += __shfl_xor(s1[i], 32, 64);
-        s2[i] += __shfl_xor(s2[i], 32, 64);
+        t1[i] = (i & 1) ? s1[i >> 1].y : s1[i >> 1].x;
+        t2[i] = (i & 1) ? s2[i >> 1].y : s2[i >> 1].x;
       }
+      p8_rows_sum(t1);
+      p8_rows_sum(t2);
       float* red = reinterpret_cast<float*>(img);  // [8 waves][16 chunks][16]
       if (lane < 16) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          red[(wave * 16 + lane) * 16 + i] = s1[i];
-          red[(wave * 16 + lane) * 16 + 8 + i] = s2[i];
+          red[(wave * 16 + lane) * 16 + i] = t1[i];
+          red[(wave * 16 + lane) * 16 + 8 + i] = t2[i];
         }
         if (wave == 0) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) red[8 * 16 * 16 + lane * 8 + i] = piv[i];
+          for (int i = 0; i < 8; ++i) red[8 * 16 * 16 + lane * 8 + i] = (i & 1) ? piv[i >> 1].y : piv[i >> 1].x;
         }
       }
       P8_LDS_SYNC();
       if (threadIdx.x < 128) {
         const int c = threadIdx.x, ch = c >> 3, ci = c & 7;
+        // all 16 reads first, then the sums in wave order (interleaved, every add waited for its own LDS round trip: 8 in a row)
+        float r1[8], r2[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          r1[w] = red[(w * 16 + ch) * 16 + ci];
+          r2[w] = red[(w * 16 + ch) * 16 + 8 + ci];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         float a1 = 0.f, a2 = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) {
-          a1 += red[(w * 16 + ch) * 16 + ci];
-          a2 += red[(w * 16 + ch) * 16 + 8 + ci];
+          a1 += r1[w];
+          a2 += r2[w];
         }
         float* __restrict__ part = p.stats + (size_t)tm * 3 * p.N + n0 + bh * 128 + c;
         part[0] = red[8 * 16 * 16 + c];

@@ -468,9 +468,12 @@ int main(int argc, char** argv) {
       void *A, *B, *C;
       CK(hipMalloc(&A, (size_t)M * sh.ci * 2)); CK(hipMalloc(&B, (size_t)N * K * 2)); CK(hipMalloc(&C, (size_t)M * N * 2));
       fill(A, (size_t)M * sh.ci, 0x1234u, 1.0f); fill(B, (size_t)N * K, 0x9876u, 0.05f);
-      for (int dbg : {64, 64 + 4, 64 + 128}) {
-        coin_p8_debug = dbg;
-        for (int i = 0; i < 3; ++i) run_gemm(1, A, sh.ci, mode, sh.h, sh.w, sh.ci, B, K, C, N, nullptr, 0, M, N, K, nullptr, 0);
+      float* stats;
+      CK(hipMalloc(&stats, (size_t)((M + 255) / 256) * 3 * N * 4));
+      for (int dbg : {64, 64 + 4, 64 + 128, 64 + 1024, 64 + 1024 + 256, 64 + 1024 + 512, 64 + 1024 + 256 + 512}) {   // + 1024 (lab only, not a kernel bit): with the statistics epilogue
+        const bool st_on = dbg & 1024;
+        coin_p8_debug = dbg & 1023;
+        for (int i = 0; i < 3; ++i) run_gemm(1, A, sh.ci, mode, sh.h, sh.w, sh.ci, B, K, C, N, nullptr, 0, M, N, K, st_on ? stats : nullptr, st_on ? M : 0);
         CK(hipDeviceSynchronize());
         std::vector<long long> st(256 * 4);
         coin_p8_read_stamps(st.data(), 256);
@@ -480,7 +483,7 @@ int main(int argc, char** argv) {
         printf("{\"shape\": \"%s\", \"dbg\": %d, \"tiles_per_wg\": %.2f, \"main_cycles_per_tile\": %.0f, \"epilogue_cycles_per_tile\": %.0f}\n", sh.name, dbg, nn / 256,
                mm / (nn > 0 ? nn : 256), ee / (nn > 0 ? nn : 1));
       }
-      hipFree(A); hipFree(B); hipFree(C);
+      hipFree(A); hipFree(B); hipFree(C); hipFree(stats);
     }
   }
   if (!strcmp(what, "wbench") || !strcmp(what, "all")) {
