@@ -396,9 +396,22 @@ def main():
             out["secondary"] = run_secondary_targetdet(args.secondary_steps)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = run_cpu_baseline(args.cpu_timeout)
-        print(json.dumps(out), flush=True)
+    else:
+        out = None
+    # The JSON line must be the LAST line on stdout: RCCL writes its version banner through C stdio, which is fully buffered on a pipe
+    # and would otherwise be flushed when a rank exits, after the line.  Every rank flushes, all meet, then rank 0 prints.
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
     if dist.is_initialized():
         dist.barrier()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
