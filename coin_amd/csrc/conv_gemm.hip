@@ -602,21 +602,31 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // Block = 16 channels x 64 tile lanes (thread = channel c16 + 16 * tile lane): a thread folds tiles lane, lane + 64, ... (a serial
 // chain of ~tiles/64 dependent updates; the [401 408, 512] res5 outputs have 1568 tiles), then one thread per channel folds the 64
 // partial results in lane order.  N/16 workgroups (32..128) instead of N/64: the launch was latency-bound at 8 workgroups.
+// CPB = channels per workgroup (16 or 4), 1024 / CPB tile lanes; SF_U tiles per round.
+template <int CPB, int SF_U>
 __global__ __launch_bounds__(1024) void conv_stats_finalize_kernel(const float* __restrict__ part, int tiles_m, int N, int64_t rows,
                                                                     float eps, float momentum, float* __restrict__ mean,
                                                                     float* __restrict__ rstd, float* __restrict__ running_mean,
                                                                     float* __restrict__ running_var, int64_t* __restrict__ nbt) {
-  __shared__ float red[64][3][16];
+  constexpr int TL = 1024 / CPB;
+  __shared__ float red[TL][3][CPB];
   if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;   // nn.BatchNorm2d's counter rides along (it was a launch of its own)
-  const int c16 = threadIdx.x & 15, tl = threadIdx.x >> 4;  // tile lane 0..63
-  const int c = blockIdx.x * 16 + c16;
+  const int cl = threadIdx.x % CPB, tl = threadIdx.x / CPB;  // tile lane 0..TL-1
+  const int c = blockIdx.x * CPB + cl;
   float n_a = 0.f, mu_a = 0.f, m2_a = 0.f;
+  auto fold = [&](float n_b, float mu_b, float m2_b) {
+    if (n_b == 0.f) return;
+    const float n = n_a + n_b, d = mu_b - mu_a;
+    mu_a += d * (n_b / n);
+    m2_a += m2_b + d * d * (n_a * n_b / n);
+    n_a = n;
+  };
   if (c < N) {
-    for (int t0 = tl; t0 < tiles_m; t0 += 64 * 4) {  // 4 tiles per round: their 12 loads are in flight together (the chain is latency-bound)
-      float pv[4], s1[4], s2[4], nb[4];
+    for (int t0 = tl; t0 < tiles_m; t0 += TL * SF_U) {  // SF_U tiles per round: their loads are in flight together (the chain is latency-bound)
+      float pv[SF_U], s1[SF_U], s2[SF_U], nb[SF_U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int t = t0 + 64 * u;
+      for (int u = 0; u < SF_U; ++u) {
+        const int t = t0 + TL * u;
         const int64_t left = rows - (int64_t)t * GM;
         nb[u] = t < tiles_m ? (float)(left <= 0 ? 0 : (left < GM ? left : GM)) : 0.f;
         const float* __restrict__ p = part + (size_t)(t < tiles_m ? t : 0) * 3 * N + c;
@@ -625,32 +635,34 @@ __global__ __launch_bounds__(1024) void conv_stats_finalize_kernel(const float* 
         s2[u] = p[2 * (size_t)N];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SF_U; ++u) {
         const float n_b = nb[u];
         if (n_b == 0.f) continue;
-        const float mu_b = pv[u] + s1[u] / n_b;
-        const float m2_b = fmaxf(s2[u] - s1[u] * s1[u] / n_b, 0.f);
-        const float n = n_a + n_b, d = mu_b - mu_a;
-        mu_a += d * (n_b / n);
-        m2_a += m2_b + d * d * (n_a * n_b / n);
-        n_a = n;
+        fold(n_b, pv[u] + s1[u] / n_b, fmaxf(s2[u] - s1[u] * s1[u] / n_b, 0.f));
       }
     }
   }
-  red[tl][0][c16] = n_a;
-  red[tl][1][c16] = mu_a;
-  red[tl][2][c16] = m2_a;
+  red[tl][0][cl] = n_a;
+  red[tl][1][cl] = mu_a;
+  red[tl][2][cl] = m2_a;
   __syncthreads();
+  // the TL partial results of a channel in lane order, 16 at a time (two levels when TL > 64)
+  if (TL > 64) {
+    if (tl < TL / 16) {
+      n_a = mu_a = m2_a = 0.f;
+      for (int w = tl * 16; w < tl * 16 + 16; ++w) fold(red[w][0][cl], red[w][1][cl], red[w][2][cl]);
+    }
+    __syncthreads();
+    if (tl < TL / 16) {
+      red[tl][0][cl] = n_a;
+      red[tl][1][cl] = mu_a;
+      red[tl][2][cl] = m2_a;
+    }
+    __syncthreads();
+  }
   if (tl != 0 || c >= N) return;
   n_a = mu_a = m2_a = 0.f;
-  for (int w = 0; w < 64; ++w) {
-    const float n_b = red[w][0][c16];
-    if (n_b == 0.f) continue;
-    const float n = n_a + n_b, d = red[w][1][c16] - mu_a;
-    mu_a += d * (n_b / n);
-    m2_a += red[w][2][c16] + d * d * (n_a * n_b / n);
-    n_a = n;
-  }
+  for (int w = 0; w < (TL > 64 ? TL / 16 : TL); ++w) fold(red[w][0][cl], red[w][1][cl], red[w][2][cl]);
   const float var = n_a > 0.f ? m2_a / n_a : 0.f;
   mean[c] = mu_a;
   rstd[c] = 1.0f / sqrtf(var + eps);
@@ -752,8 +764,17 @@ extern "C" int coin_conv_gemm_stats_finalize(const float* partials, int M, int N
                                              float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream) {
   if (!partials || !mean || !rstd || M <= 0 || N <= 0 || rows <= 0 || rows > M) return COIN_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return COIN_EINVAL;
-  conv_stats_finalize_kernel<<<(N + 15) / 16, 1024, 0, (hipStream_t)stream>>>(partials, (M + GM - 1) / GM, N, rows, eps, momentum, mean, rstd,
-                                                                             running_mean, running_var, num_batches_tracked);
+  static const int lab = [] { const char* e = getenv("COIN_STATS_FIN"); return e ? atoi(e) : 0; }();   // measurements only: 1 = 16 channels per workgroup, 2 = 4
+  const int tiles = (M + GM - 1) / GM;
+  // 4 channels x 256 tile lanes per workgroup up to N = 1024 (tools/statsfin_bench.py: 8.3 against 14.5 us at [100352, 512], 20.4 / 24.7 at
+  // [401408, 512], 8.0 / 11.9 at [16700, 1024]); 16 x 64 for N = 2048 (15.1 against 20.9 us)
+  const bool narrow = lab ? lab == 2 : N <= 1024;
+  if (narrow)
+    conv_stats_finalize_kernel<4, 8><<<(N + 3) / 4, 1024, 0, (hipStream_t)stream>>>(partials, tiles, N, rows, eps, momentum, mean, rstd, running_mean,
+                                                                                   running_var, num_batches_tracked);
+  else
+    conv_stats_finalize_kernel<16, 4><<<(N + 15) / 16, 1024, 0, (hipStream_t)stream>>>(partials, tiles, N, rows, eps, momentum, mean, rstd, running_mean,
+                                                                                     running_var, num_batches_tracked);
   return coin_launch_status();
 }
 
