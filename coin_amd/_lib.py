@@ -60,6 +60,7 @@ SIGNATURES = {
     "coin_gemm_nt": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _F, _I, _I, _P],
     "coin_conv_gemm_bf16": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P],
     "coin_conv_gemm_bf16_ws": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P, _Z, _P],
+    "coin_conv_gemm_bf16_rpool": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P],
     "coin_conv_gemm_stats_finalize": [_P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P, _P],
     "coin_conv_wgrad_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "coin_window_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],

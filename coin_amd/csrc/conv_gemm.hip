@@ -689,6 +689,30 @@ extern "C" int coin_conv_gemm_bf16(const void* A, int lda, int mode, int H, int 
   return coin_conv_gemm_bf16_ws(A, lda, mode, H, W, Cin, B, ldb, C, ldc, R, ldr, M, N, K, stats, stats_rows, nullptr, 0, stream);
 }
 
+// C = bf16(bf16(A.B^T) + 0.25 * R[pooled pixel]): R is the gradient of a 2x2 / stride-2 average pool of the OUTPUT pixel grid [*, out_h, out_w]
+// (rows of R = pixels of [*, out_h / 2, out_w / 2], floor).  The data gradient of a Bottleneck's conv1 takes the downsample branch's
+// gradient this way: the avg-pool backward (an [M, N] tensor written and read back) disappears into the epilogue's residual add.
+// Served by the persistent 8-phase kernel only: COIN_ESHAPE where that kernel does not fit (the caller materialises the pool gradient).
+extern "C" int coin_conv_gemm_bf16_rpool(const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb, void* C, int ldc,
+                                         const void* R, int ldr, int out_h, int out_w, int M, int N, int K, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  if (!A || !B || !C || !R) return COIN_EINVAL;
+  if (M <= 0 || N <= 0 || K <= 0 || ldb < K || ldc < N || ldr < N || (mode != 0 && mode != 1)) return COIN_EINVAL;
+  if (out_h < 2 || out_w < 2 || M % (out_h * out_w)) return COIN_EINVAL;
+  if (K % GK || ldb % 8 || ldc % 8 || N % 8 || ldr % 8) return COIN_ESHAPE;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15) || ((uintptr_t)R & 15)) return COIN_EALIGN;
+  if (mode == 0) {
+    if (lda < K) return COIN_EINVAL;
+    if (lda % 8) return COIN_ESHAPE;
+  } else {
+    if (H <= 0 || W <= 0 || Cin <= 0 || M % (H * W)) return COIN_EINVAL;
+    if (Cin % GK || K != 9 * Cin) return COIN_ESHAPE;
+  }
+  if (coin_conv_gemm_force_impl > 1 || !coin_p8_nt_ok(M, N, K, mode, Cin, lda, ldb)) return COIN_ESHAPE;
+  return coin_p8_nt_launch(A, lda, mode, H, W, Cin, B, ldb, C, ldc, R, ldr, M, N, K, nullptr, 0, ((uintptr_t)workspace & 15) ? nullptr : workspace,
+                           workspace_bytes, (hipStream_t)stream, out_h, out_w);
+}
+
 extern "C" int coin_conv_gemm_bf16_ws(const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb, void* C, int ldc,
                                       const void* R, int ldr, int M, int N, int K, float* stats, int64_t stats_rows, void* workspace,
                                       size_t workspace_bytes, void* stream) {

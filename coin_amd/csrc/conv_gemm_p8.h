@@ -8,7 +8,7 @@ COIN_HIDDEN bool coin_p8_nt_ok(int M, int N, int K, int mode, int Cin, int lda, 
 COIN_HIDDEN size_t coin_p8_nt_workspace_bytes(int M, int N, int K);
 COIN_HIDDEN int coin_p8_nt_launch(const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb, void* C, int ldc, const void* R,
                                   int ldr, int M, int N, int K, float* stats, long long stats_rows, void* workspace, size_t workspace_bytes,
-                                  hipStream_t st);
+                                  hipStream_t st, int rp_h = 0, int rp_w = 0);
 COIN_HIDDEN bool coin_p8_tn_ok(int M, int Cout, int Cin, int Ktot, int mode);
 COIN_HIDDEN size_t coin_p8_tn_workspace_bytes(int M, int Cout, int Ktot);
 COIN_HIDDEN int coin_p8_tn_launch(const void* GY, const void* X, int mode, int H, int W, int Cin, int M, int Cout, int Ktot, float* dW, void* workspace,

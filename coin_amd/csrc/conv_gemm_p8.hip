@@ -76,6 +76,9 @@ struct P8Args {
   const bf16_t* B; int ldb;
   bf16_t* C; int ldc;
   const bf16_t* R; int ldr;
+  // rp_w > 0: R is the gradient of a 2x2 average pool of the OUTPUT grid (rows = pixels of a [*, rp_h, rp_w] map): output pixel (n, h, w)
+  // adds 0.25 * R[n][h / 2][w / 2] (nothing where h / 2 or w / 2 falls off the floor-pooled map) -- avg-pool backward folded into the add
+  int rp_h, rp_w; unsigned rp_magic_hw, rp_magic_w;
   int M, N, K, H, W, Cin;
   float* stats; long long stats_rows;
   int tiles_m, tiles_n;
@@ -261,12 +264,22 @@ __device__ __forceinline__ void p8_epilogue(const P8Args& p, f32x4 (&acc)[2][2][
       // image reads back to back, then add / store / statistics -- one LDS latency and one memory latency per pass instead of four
       bf16x8 v[4], rr[4];
       const bool has_r = p.R != nullptr;
+      float rscale[4] = {1.f, 1.f, 1.f, 1.f};
       if (has_r) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           int grow = m0 + ah * 128 + q * 32 + rsub;
           grow = grow < p.M ? grow : p.M - 1;
-          rr[q] = *reinterpret_cast<const bf16x8*>(p.R + (size_t)grow * p.ldr + gcol);
+          size_t rrow = (size_t)grow;
+          if (p.rp_w) {   // wave-uniform: pooled residual
+            const int n = (int)__umulhi((unsigned)grow, p.rp_magic_hw);
+            const int rem = grow - n * (p.rp_h * p.rp_w);
+            const int h = (int)__umulhi((unsigned)rem, p.rp_magic_w), w = rem - h * p.rp_w;
+            const int oh = h >> 1, ow = w >> 1, OH = p.rp_h >> 1, OW = p.rp_w >> 1;
+            rscale[q] = (oh < OH && ow < OW) ? 0.25f : 0.f;
+            rrow = ((size_t)n * OH + (oh < OH ? oh : OH - 1)) * OW + (ow < OW ? ow : OW - 1);
+          }
+          rr[q] = *reinterpret_cast<const bf16x8*>(p.R + rrow * p.ldr + gcol);
         }
       }
 #pragma unroll
@@ -280,9 +293,10 @@ __device__ __forceinline__ void p8_epilogue(const P8Args& p, f32x4 (&acc)[2][2][
           f32x2 a[4], b[4];
           p8_pairs(v[q], a);
           p8_pairs(rr[q], b);
+          const f32x2 sc = {rscale[q], rscale[q]};   // 1 (plain), 0.25 / 0 (pooled): exact scalings, so bf16(0.25 r) need not be formed first
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const f32x2 t = a[i] + b[i];
+            const f32x2 t = __builtin_elementwise_fma(sc, b[i], a[i]);
             v[q][2 * i] = (bf16_t)t.x;
             v[q][2 * i + 1] = (bf16_t)t.y;
           }
@@ -1029,12 +1043,15 @@ size_t coin_p8_nt_workspace_bytes(int M, int N, int K) {
 }
 
 int coin_p8_nt_launch(const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb, void* C, int ldc, const void* R, int ldr,
-                      int M, int N, int K, float* stats, long long stats_rows, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                      int M, int N, int K, float* stats, long long stats_rows, void* workspace, size_t workspace_bytes, hipStream_t st, int rp_h, int rp_w) {
   P8Args a;
   a.A = (const bf16_t*)A; a.lda = lda;
   a.B = (const bf16_t*)B; a.ldb = ldb;
   a.C = (bf16_t*)C; a.ldc = ldc;
   a.R = (const bf16_t*)R; a.ldr = ldr;
+  a.rp_h = R ? rp_h : 0; a.rp_w = R ? rp_w : 0;
+  a.rp_magic_hw = a.rp_w ? (unsigned)((0x100000000ull + (unsigned)(rp_h * rp_w) - 1) / (unsigned)(rp_h * rp_w)) : 0;
+  a.rp_magic_w = a.rp_w ? (unsigned)((0x100000000ull + (unsigned)rp_w - 1) / (unsigned)rp_w) : 0;
   a.M = M; a.N = N; a.K = K; a.H = H; a.W = W; a.Cin = Cin;
   a.stats = stats; a.stats_rows = stats_rows;
   a.tiles_m = (M + PM - 1) / PM; a.tiles_n = N / PN;

@@ -192,13 +192,16 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
 
 
 def conv_gemm(a: torch.Tensor, w: torch.Tensor, spatial: Optional[Tuple[int, int, int]] = None, stats_rows: Optional[int] = None,
-              out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None):
+              out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, residual_pool: Optional[Tuple[int, int]] = None):
     """bf16 GEMM / implicit-GEMM convolution (coin_conv_gemm_bf16).
     a: [M, K] row-major (1x1 convolution on NHWC rows, nn.Linear) or, with ``spatial=(H, W, Cin)``, the NHWC activation flattened
     to [M, Cin] for the implicit 3x3 / pad 1 convolution (M = NB*H*W);  w: [N, K] with K = Cin or 9*Cin (ky, kx, ci).
     -> C [M, N] bf16, and -- when ``stats_rows`` is given -- the per-row-tile statistics partials of the stored outputs over the
     first ``stats_rows`` rows (input of `conv_stats_finalize`).  ``residual`` [M, N] bf16 is added to the (bf16-rounded) product in
-    the epilogue."""
+    the epilogue.  ``residual_pool=(out_h, out_w)``: `residual` is instead the gradient of a 2x2 average pool of the output grid
+    ([M / (out_h out_w) * (out_h // 2) * (out_w // 2), N]) and every output pixel adds a quarter of its pooled pixel
+    (coin_conv_gemm_bf16_rpool) -> (C, None), or None when the persistent kernel does not serve the shape (the caller materialises
+    the pool gradient instead)."""
     _dev(a, w, out, residual)
     if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or a.dim() != 2 or w.dim() != 2 or a.stride(1) != 1 or w.stride(1) != 1:
         raise CoinHipError("conv_gemm needs 2-D K-contiguous bf16 operands")
@@ -216,7 +219,13 @@ def conv_gemm(a: torch.Tensor, w: torch.Tensor, spatial: Optional[Tuple[int, int
         out = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
     elif out.shape != (m, n) or out.stride(1) != 1 or out.dtype != torch.bfloat16:
         raise CoinHipError("conv_gemm: bad `out`")
-    if residual is not None and (residual.shape != (m, n) or residual.stride(1) != 1 or residual.dtype != torch.bfloat16):
+    if residual_pool is not None:
+        oh, ow = residual_pool
+        if residual is None or stats_rows is not None or oh < 2 or ow < 2 or m % (oh * ow):
+            raise CoinHipError("conv_gemm: residual_pool needs a residual, no statistics and M a multiple of out_h * out_w")
+        if residual.shape != (m // (oh * ow) * (oh // 2) * (ow // 2), n) or residual.stride(1) != 1 or residual.dtype != torch.bfloat16:
+            raise CoinHipError("conv_gemm: the pooled `residual` must be a bf16 [M / (h w) * (h // 2) * (w // 2), N] matrix")
+    elif residual is not None and (residual.shape != (m, n) or residual.stride(1) != 1 or residual.dtype != torch.bfloat16):
         raise CoinHipError("conv_gemm: `residual` must be a bf16 [M, N] matrix with contiguous rows")
     part = None
     if stats_rows is not None:
@@ -230,6 +239,19 @@ def conv_gemm(a: torch.Tensor, w: torch.Tensor, spatial: Optional[Tuple[int, int
         ws = _GEMM_WS.get(key)
         if ws is None or ws.numel() < wsb:
             ws = _GEMM_WS[key] = torch.empty(wsb, dtype=torch.uint8, device=a.device)
+    if residual_pool is not None:
+        shape_key = (m, n, k, mode, a.stride(0), w.stride(0))
+        if shape_key in _RPOOL_UNSERVED:
+            return None
+        with _timed("coin_conv_gemm_bf16", 2 * m * n * k):
+            rc = _lib.lib().coin_conv_gemm_bf16_rpool(_p(a), a.stride(0), mode, h, wd, cin, _p(w), w.stride(0), _p(out), out.stride(0), _p(residual),
+                                                      residual.stride(0), int(residual_pool[0]), int(residual_pool[1]), m, n, k, _p(ws),
+                                                      wsb if ws is not None else 0, _stream())
+        if rc == -2:   # COIN_ESHAPE: not a shape of the persistent kernel (remembered: the failed call launched nothing)
+            _RPOOL_UNSERVED.add(shape_key)
+            return None
+        check(rc, "coin_conv_gemm_bf16_rpool")
+        return out, None
     with _timed("coin_conv_gemm_bf16", 2 * m * n * k):  # "bytes" slot carries FLOPs for the MFMA entry point
         check(_lib.lib().coin_conv_gemm_bf16_ws(_p(a), a.stride(0), mode, h, wd, cin, _p(w), w.stride(0), _p(out), out.stride(0),
                                                 _p(residual), residual.stride(0) if residual is not None else 0, m, n, k,
@@ -238,6 +260,7 @@ def conv_gemm(a: torch.Tensor, w: torch.Tensor, spatial: Optional[Tuple[int, int
 
 
 _GEMM_WS: dict = {}
+_RPOOL_UNSERVED: set = set()
 
 
 _WGRAD_WS: dict = {}

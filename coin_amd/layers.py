@@ -231,12 +231,18 @@ class _ConvGemm(Function):
         ctx.save_for_backward(x, wq)
         ctx.ks = ks
         ctx.param = weakref.ref(weight)
+        ctx.pool_tap = fork == "pool"
         if part is None:
             part = out.new_zeros(0, dtype=torch.float32)
         ctx.mark_non_differentiable(part)
         y = out.view(n, h, w, co).permute(0, 3, 1, 2)
         # fork: also hand the input back as the tap of the block's OTHER consumer (identity / downsample branch), so that this
-        # node receives both gradients of x and forms their sum in the dgrad epilogue instead of autograd's separate add pass
+        # node receives both gradients of x and forms their sum in the dgrad epilogue instead of autograd's separate add pass.
+        # fork == "pool": the other consumer starts with AvgPool2d(2) (the stride-2 Bottleneck's downsample branch, utils.py:60-75):
+        # the tap is the POOLED input, and its gradient is folded into the same epilogue at quarter weight -- the avg-pool backward
+        # (a full-size tensor written, then read as the residual) is never materialised.
+        if fork == "pool":
+            return y, part, K.avgpool2_fwd(xn).permute(0, 3, 1, 2)
         return (y, part, x.view_as(x)) if fork else (y, part)
 
     @staticmethod
@@ -246,11 +252,12 @@ class _ConvGemm(Function):
         gyn = _as_nhwc(gy)
         if gyn.dtype != torch.bfloat16:
             gyn = gyn.to(torch.bfloat16)
-        dx, dw = _conv_gemm_grads(x, wq, gyn, ctx.ks, ctx.needs_input_grad[0], ctx.needs_input_grad[1], g_tap, param=ctx.param())
+        dx, dw = _conv_gemm_grads(x, wq, gyn, ctx.ks, ctx.needs_input_grad[0], ctx.needs_input_grad[1], g_tap, param=ctx.param(),
+                                  tap_pooled=ctx.pool_tap)
         return dx, dw, None, None, None
 
 
-def _conv_gemm_grads(x, wq, gyn, ks, need_dx, need_dw, g_tap=None, param=None):
+def _conv_gemm_grads(x, wq, gyn, ks, need_dx, need_dw, g_tap=None, param=None, tap_pooled=False):
     """(dx, dw) of the GEMM convolutions; gyn: bf16 NHWC gradient of the output, x: the saved (logical NCHW) input, wq: bf16 weight,
     param: the fp32 master of wq (key of the persistent data-gradient layout)."""
     pad = ks // 2
@@ -261,10 +268,21 @@ def _conv_gemm_grads(x, wq, gyn, ks, need_dx, need_dw, g_tap=None, param=None):
         # dgrad = the same contraction over (flipped tap, Cout): weight re-laid [Cin][ky'][kx'][Cout] (persistent copy, see dgrad_weight)
         wd = dgrad_weight(param, wq, ks)
         res = None
+        gx = None
         if g_tap is not None:
             res = _as_nhwc(g_tap)
-            res = (res if res.dtype == torch.bfloat16 else res.to(torch.bfloat16)).reshape(n * h * w, ci)
-        gx, _ = K.conv_gemm(gyn.reshape(n * h * w, co), wd, spatial=(h, w, co) if ks == 3 else None, residual=res)
+            res = res if res.dtype == torch.bfloat16 else res.to(torch.bfloat16)
+            if tap_pooled:   # gradient of avg_pool2(x): [n, h // 2, w // 2, ci]
+                done = K.conv_gemm(gyn.reshape(n * h * w, co), wd, spatial=(h, w, co) if ks == 3 else None,
+                                   residual=res.reshape(n * (h // 2) * (w // 2), ci), residual_pool=(h, w))
+                if done is not None:
+                    gx = done[0]
+                else:        # a shape the persistent kernel does not serve: materialise the pool's backward
+                    res = K.avgpool2_bwd(res.contiguous(), (n, h, w, ci))
+            if gx is None:
+                res = res.reshape(n * h * w, ci)
+        if gx is None:
+            gx, _ = K.conv_gemm(gyn.reshape(n * h * w, co), wd, spatial=(h, w, co) if ks == 3 else None, residual=res)
         dx = gx.view(n, h, w, ci).permute(0, 3, 1, 2)
     if need_dw:
         if CONV_GEMM["wgrad"] and K.conv_wgrad_ok(co, ci):
@@ -342,7 +360,7 @@ def conv2d_gemm(x: torch.Tensor, conv: torch.nn.Conv2d, stats_rows: Optional[int
         x = x.to(torch.bfloat16)
     wq = _shadow_entry(conv.weight, torch.bfloat16).tensor
     if fork:
-        y, part, tap = _ConvGemm.apply(x, conv.weight, wq, stats_rows, True)
+        y, part, tap = _ConvGemm.apply(x, conv.weight, wq, stats_rows, fork)
         return y, (part if stats_rows is not None else None), tap
     y, part = _ConvGemm.apply(x, conv.weight, wq, stats_rows)
     return y, (part if stats_rows is not None else None)
@@ -354,9 +372,10 @@ def conv_bn_act(x: torch.Tensor, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d
     the convolution's epilogue (no statistics pass over the activation).
     fork=True -> (result, tap): `tap` is x for the block's other consumer (identity / downsample branch); when the convolution runs
     on the hand-written GEMM and x needs a gradient, the two gradients of x are summed in the dgrad epilogue (coin_conv_gemm_bf16's
-    R operand) instead of by a separate elementwise pass."""
+    R operand) instead of by a separate elementwise pass.  fork="pool" -> `tap` is avg_pool2(x) (the stride-2 block's downsample
+    branch starts with AvgPool2d(2)); on the GEMM path the pool's backward is folded into that epilogue too."""
     if _conv_gemm_ok(x, conv):
-        do_fork = fork and torch.is_grad_enabled() and x.requires_grad
+        do_fork = fork if (fork and torch.is_grad_enabled() and x.requires_grad) else False
         if bn.training and bn.momentum is not None:
             nv = _VALID_ROWS[0]
             rows = (x.shape[0] if nv is None or nv >= x.shape[0] else int(nv)) * x.shape[2] * x.shape[3]
@@ -365,9 +384,13 @@ def conv_bn_act(x: torch.Tensor, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d
         else:
             y, _, *tap = conv2d_gemm(x, conv, fork=do_fork)
             out = bn_act(y, bn, relu, residual, pool)
-        return (out, tap[0] if tap else x) if fork else out
+        if not fork:
+            return out
+        return out, (tap[0] if tap else (avg_pool2(x) if fork == "pool" else x))
     out = bn_act(conv2d(x, conv), bn, relu, residual, pool)
-    return (out, x) if fork else out
+    if not fork:
+        return out
+    return out, (avg_pool2(x) if fork == "pool" else x)
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -137,11 +137,12 @@ class Bottleneck(nn.Module):
         # trainable stage: every BatchNorm + elementwise tail is a fused HIP stream (coin_amd.layers.bn_act)
         pool = 2 if self.stride > 1 else 1
         assert self.stride in (1, 2)
-        y, x = L.conv_bn_act(x, self.conv1, self.bn1, relu=True, fork=True)            # x: the identity branch's tap (gradient fan-in fused)
+        # x: the identity branch's tap (gradient fan-in fused); for the stride-2 block the tap comes back already average-pooled
+        fork = "pool" if (self.downsample is not None and pool == 2) else True
+        y, x = L.conv_bn_act(x, self.conv1, self.bn1, relu=True, fork=fork)
         y = L.conv_bn_act(y, self.conv2, self.bn2, relu=True, pool=pool)               # ReLU and the anti-aliasing avg-pool fused in
         if self.downsample is not None:
-            sx = L.avg_pool2(x) if pool == 2 else x
-            sx = L.conv_bn_act(sx, self.downsample[1], self.downsample[2], relu=False)
+            sx = L.conv_bn_act(x, self.downsample[1], self.downsample[2], relu=False)
         else:
             sx = x
         return L.conv_bn_act(y, self.conv3, self.bn3, relu=True, residual=sx, pool=0 if mean_pool else 1)  # bn3 + identity + ReLU

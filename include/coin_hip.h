@@ -206,6 +206,15 @@ size_t coin_conv_gemm_workspace_bytes(int M, int N, int K);
 int coin_conv_gemm_bf16_ws(const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb,
                            void* C, int ldc, const void* R, int ldr, int M, int N, int K, float* stats, int64_t stats_rows,
                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* coin_conv_gemm_bf16_rpool: as coin_conv_gemm_bf16_ws without statistics, with C = bf16(bf16(A.B^T) + 0.25 * R[n][h / 2][w / 2]) for the
+ * output pixel (n, h, w) of the grid [M / (out_h * out_w), out_h, out_w]; R: [M / (out_h * out_w) * (out_h / 2) * (out_w / 2), N] bf16 (floor
+ * pooling: pixels whose h / 2 or w / 2 falls off the pooled map add nothing).  R = the gradient of `AvgPool2d(2)` applied to the tensor whose
+ * data gradient this GEMM produces: the downsample branch of the CLIP Bottleneck (coin/modeling/utils.py:60-75, 84-88: `avgpool` +
+ * `downsample`) -- the pool's backward pass folded into the residual add.  COIN_ESHAPE when the persistent kernel does not serve the shape
+ * (N % 256, K % 64 ...): the caller then materialises the pool gradient (coin_avgpool2_bwd) and passes it as a plain residual. */
+int coin_conv_gemm_bf16_rpool(const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb, void* C, int ldc, const void* R,
+                              int ldr, int out_h, int out_w, int M, int N, int K, void* workspace, size_t workspace_bytes, void* stream);
 int coin_conv_gemm_stats_finalize(const float* partials, int M, int N, int64_t rows, float eps, float momentum,
                                   float* mean, float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                   void* stream);

@@ -284,11 +284,12 @@ def test_conv_wgrad_vs_fp64(K, nb, h, w, cin, cout, ks):
     assert torch.equal(dw, K.conv_wgrad(ga, xa, spatial=(h, w, cin) if ks == 3 else None))
 
 
-@pytest.mark.parametrize("inplanes,planes,stride", [(256, 64, 1), (128, 64, 2)])
+@pytest.mark.parametrize("inplanes,planes,stride", [(256, 64, 1), (128, 64, 2), (256, 64, 2), (512, 256, 2)])
 def test_bottleneck_gradient_fan_in_fused_in_dgrad_epilogue(monkeypatch, inplanes, planes, stride):
     """Trainable CLIP Bottleneck (coin/modeling/utils.py:60-90) in the bf16 mode: the block input's two gradients (conv1's dgrad and
     the identity / downsample branch) are summed in conv1's dgrad epilogue.  Same bits as autograd's separate add, and one
-    elementwise launch fewer."""
+    elementwise launch fewer.  Stride 2: the downsample branch's AvgPool2d backward is folded into the same epilogue
+    (coin_conv_gemm_bf16_rpool; an odd map size exercises the floor-pooled border) -- same bits as the separate pool-backward kernel."""
     import sys
 
     sys.path.insert(0, __import__("os").path.dirname(__file__))
@@ -299,13 +300,15 @@ def test_bottleneck_gradient_fan_in_fused_in_dgrad_epilogue(monkeypatch, inplane
     monkeypatch.setitem(L.CONV_GEMM, "enabled", True)
     monkeypatch.setitem(L.CONV_GEMM, "min_rows", 0)
     blk = seeded.fill_module(Bottleneck(inplanes, planes, stride), 77).cuda().train()
-    x0 = seeded.randn((4, inplanes, 14, 14), 78).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    hw = 15 if (stride == 2 and inplanes == 256) else 14   # 15: floor pooling leaves the last row / column without a pool gradient
+    x0 = seeded.randn((4, inplanes, hw, hw), 78).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     gy = None
     res = []
     for fork in (True, False):
         if not fork:
             real = L.conv_bn_act
-            monkeypatch.setattr(L, "conv_bn_act", lambda *a, fork=False, **k: ((real(*a, **k), a[0]) if fork else real(*a, **k)))
+            # the un-fused reference: a plain tap (average-pooled by the separate kernel pair for the stride-2 block's fork="pool")
+            monkeypatch.setattr(L, "conv_bn_act", lambda *a, fork=False, **k: ((real(*a, **k), L.avg_pool2(a[0]) if fork == "pool" else a[0]) if fork else real(*a, **k)))
         x = (x0 * 1).requires_grad_(True)   # non-leaf copy: its gradient is what the previous block would receive
         x.retain_grad()
         blk.zero_grad()
