@@ -47,7 +47,7 @@ ENTRY_KERNELS = {
     "coin_conv_wgrad_bf16": ["conv_wgrad_p8_kernel", "tn_reduce_kernel"],
     "coin_conv_gemm_stats_finalize": ["conv_stats_finalize_kernel"],
 }
-KERNEL_TIMING_STEPS = 4    # the first steps of the timed region carry HIP events around every timed launch (`kernels` / `roofline` blocks)
+KERNEL_TIMING_STEPS = 2    # the first steps of the timed region carry HIP events around every timed launch (`kernels` / `roofline` blocks)
 MFMA_ENTRIES = ("coin_gemm_nt", "coin_conv_gemm_bf16", "coin_conv_wgrad_bf16")   # their `units` slot carries FLOPs, not bytes
 
 
@@ -276,8 +276,8 @@ def run_secondary_targetdet(steps: int = 24, warmup: int = 8, images: int = 3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
