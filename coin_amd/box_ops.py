@@ -99,17 +99,29 @@ class Box2BoxTransform:
         return torch.stack((wx * (tx - sx) / sw, wy * (ty - sy) / sh, ww * torch.log(tw / sw), wh * torch.log(th / sh)), dim=1)
 
     def apply_deltas(self, deltas: torch.Tensor, boxes: torch.Tensor) -> torch.Tensor:
+        """detectron2 Box2BoxTransform.apply_deltas on (x, y) / (w, h) pairs: the same arithmetic per element as the column-by-column
+        form (every multiplication by 0.5 is exact, the products and sums are separate roundings as before), a third of the launches."""
         deltas = deltas.float()
         boxes = boxes.to(deltas.dtype)
-        w, h = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
-        cx, cy = boxes[:, 0] + 0.5 * w, boxes[:, 1] + 0.5 * h
-        wx, wy, ww, wh = self.weights
-        dx, dy = deltas[:, 0::4] / wx, deltas[:, 1::4] / wy
-        dw = torch.clamp(deltas[:, 2::4] / ww, max=self.scale_clamp)
-        dh = torch.clamp(deltas[:, 3::4] / wh, max=self.scale_clamp)
-        pcx, pcy = dx * w[:, None] + cx[:, None], dy * h[:, None] + cy[:, None]
-        pw, ph = torch.exp(dw) * w[:, None], torch.exp(dh) * h[:, None]
-        return torch.stack((pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph), dim=-1).reshape(deltas.shape)
+        wh = boxes[:, 2:] - boxes[:, :2]                                   # [R, 2] (w, h)
+        ctr = torch.add(boxes[:, :2], wh, alpha=0.5)                       # (cx, cy)
+        d = deltas.reshape(deltas.shape[0], -1, 4) / self._weights_on(deltas.device)   # [R, k, 4] / (wx, wy, ww, wh)
+        dwh = torch.clamp(d[..., 2:], max=self.scale_clamp)
+        pc = d[..., :2] * wh[:, None, :]
+        pc = pc + ctr[:, None, :]
+        pwh = torch.exp(dwh) * wh[:, None, :]
+        return torch.cat((torch.add(pc, pwh, alpha=-0.5), torch.add(pc, pwh, alpha=0.5)), dim=-1).reshape(deltas.shape)
+
+    _wdev = None
+
+    def _weights_on(self, device):
+        """(wx, wy, ww, wh) as a device tensor, built once per device from a pinned staging tensor (no blocking pageable copy per call)."""
+        if self._wdev is None:
+            self._wdev = {}
+        t = self._wdev.get(device)
+        if t is None:
+            t = self._wdev[device] = torch.tensor(self.weights, dtype=torch.float32).to(device)
+        return t
 
 
 def cell_anchors(sizes: Sequence[float], aspect_ratios: Sequence[float]) -> torch.Tensor:
@@ -183,6 +195,11 @@ def _sizes_on_device(image_sizes, device):
     return torch.tensor(image_sizes, dtype=torch.float32, device=device)
 
 
+@functools.lru_cache(maxsize=64)
+def _clip_limits(image_sizes, device):
+    return torch.tensor([[w, h, w, h] for h, w in image_sizes], dtype=torch.float32, device=device).view(len(image_sizes), 1, 4)
+
+
 @torch.no_grad()
 def find_top_rpn_proposals(proposals: torch.Tensor, logits: torch.Tensor, image_sizes: List[Tuple[int, int]], nms_thresh: float,
                            pre_nms_topk: int, post_nms_topk: int, min_box_size: float, training: bool, packed: bool = False,
@@ -217,10 +234,9 @@ def find_top_rpn_proposals(proposals: torch.Tensor, logits: torch.Tensor, image_
     if training and not packed and not bool(torch.isfinite(boxes).all() & torch.isfinite(top_logits).all()):
         raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")
     hw = _sizes_on_device(tuple(tuple(int(v) for v in sz) for sz in image_sizes), boxes.device)  # [N, 2] (h, w)
-    wmax, hmax = hw[:, 1].view(n, 1), hw[:, 0].view(n, 1)
-    boxes = torch.stack((torch.minimum(boxes[..., 0].clamp(min=0), wmax), torch.minimum(boxes[..., 1].clamp(min=0), hmax),
-                         torch.minimum(boxes[..., 2].clamp(min=0), wmax), torch.minimum(boxes[..., 3].clamp(min=0), hmax)), dim=-1)
-    valid = ((boxes[..., 2] - boxes[..., 0]) > min_box_size) & ((boxes[..., 3] - boxes[..., 1]) > min_box_size)
+    lim = _clip_limits(tuple(tuple(int(v) for v in sz) for sz in image_sizes), boxes.device)   # [N, 1, 4]: (w, h, w, h) per image
+    boxes = torch.minimum(boxes.clamp(min=0), lim)                         # clip: the same two operations per coordinate as before
+    valid = ((boxes[..., 2:] - boxes[..., :2]) > min_box_size).all(dim=-1)
     valid &= torch.isfinite(boxes).all(dim=-1) & torch.isfinite(top_logits)
     # stable partition: valid boxes first, still in descending score order
     order = torch.argsort((~valid).to(torch.int8), dim=1, stable=True)

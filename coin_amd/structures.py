@@ -42,8 +42,9 @@ class Boxes:
         return ((b[:, 2] - b[:, 0]) > threshold) & ((b[:, 3] - b[:, 1]) > threshold)
 
     def scale(self, sx: float, sy: float):
-        self.tensor[:, 0::2] *= sx
-        self.tensor[:, 1::2] *= sy
+        # (in-place on the strided views: `t[:, 0::2] *= sx` is getitem + mul_ + a setitem copy of the view onto itself -- two launches)
+        self.tensor[:, 0::2].mul_(sx)
+        self.tensor[:, 1::2].mul_(sy)
 
     def __getitem__(self, item):
         if isinstance(item, int):
