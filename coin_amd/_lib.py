@@ -65,7 +65,7 @@ SIGNATURES = {
     "coin_conv_wgrad_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "coin_window_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "coin_window_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
-    "coin_anchor_match": [_P, _P, _I, _P, _I, _F, _F, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "coin_anchor_match": [_P, _P, _I, _P, _I, _I, _F, _F, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "coin_sample_labels": [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P],
     "coin_aug_resize_bilinear_u8": [_P, _I, _I, _P, _I, _I, _I, _P, _P],
     "coin_aug_point_op_u8": [_P, _P, _I, _I, _I, _F, _I, _P, _I, _P],

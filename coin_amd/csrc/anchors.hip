@@ -41,7 +41,7 @@ __device__ __forceinline__ float iou_rn(float4 a, float area_a, float4 b, float 
 
 // pass 1: per anchor the best ground-truth box (value, lowest index), the band label, and the per-box maximum over the anchors
 __global__ __launch_bounds__(AM_THREADS) void anchor_match_kernel(const float4* __restrict__ gt, AmOffsets off, const float4* __restrict__ anchors,
-                                                                  int A, float lo, float hi, int label_lo, int label_mid, int label_hi,
+                                                                  size_t astride /* 0: one shared box set; A: a set per image */, int A, float lo, float hi, int label_lo, int label_mid, int label_hi,
                                                                   int empty_label, int64_t* __restrict__ matched, int8_t* __restrict__ labels,
                                                                   float4* __restrict__ matched_boxes, unsigned* __restrict__ gt_best) {
   __shared__ float4 sbox[AM_MAX_GT];
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(AM_THREADS) void anchor_match_kernel(const float4* 
       labels[o] = (int8_t)empty_label;
       if (matched_boxes) matched_boxes[o] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
-      const float4 b = anchors[a];
+      const float4 b = anchors[(size_t)img * astride + a];
       const float area_b = box_area(b);
       float best = -1.f;
       int arg = 0;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(AM_THREADS) void anchor_match_kernel(const float4* 
 
 // pass 2 (allow_low_quality_matches): label 1 where the anchor's IoU with some box equals that box's maximum over all anchors
 __global__ __launch_bounds__(AM_THREADS) void anchor_low_quality_kernel(const float4* __restrict__ gt, AmOffsets off, const float4* __restrict__ anchors,
-                                                                        int A, const unsigned* __restrict__ gt_best, int8_t* __restrict__ labels) {
+                                                                        size_t astride, int A, const unsigned* __restrict__ gt_best, int8_t* __restrict__ labels) {
   __shared__ float4 sbox[AM_MAX_GT];
   __shared__ float sarea[AM_MAX_GT];
   __shared__ float sbest[AM_MAX_GT];
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(AM_THREADS) void anchor_low_quality_kernel(const fl
   __syncthreads();
   const int a = blockIdx.x * AM_THREADS + threadIdx.x;
   if (a >= A) return;
-  const float4 b = anchors[a];
+  const float4 b = anchors[(size_t)img * astride + a];
   const float area_b = box_area(b);
   bool hit = false;
   for (int g = 0; g < G; ++g) hit |= iou_rn(sbox[g], sarea[g], b, area_b) == sbest[g];
@@ -288,9 +288,9 @@ __global__ __launch_bounds__(SS_THREADS) void sample_labels_kernel(const CLS* __
 
 }  // namespace
 
-extern "C" int coin_anchor_match(const float* gt_boxes, const int* gt_offsets_host, int num_images, const float* anchors, int A, float lo,
-                                 float hi, int label_lo, int label_mid, int label_hi, int empty_label, int allow_low_quality,
-                                 int64_t* matched, int8_t* labels, float* matched_boxes, void* workspace, void* stream) {
+extern "C" int coin_anchor_match(const float* gt_boxes, const int* gt_offsets_host, int num_images, const float* anchors, int A,
+                                 int anchors_per_image, float lo, float hi, int label_lo, int label_mid, int label_hi, int empty_label,
+                                 int allow_low_quality, int64_t* matched, int8_t* labels, float* matched_boxes, void* workspace, void* stream) {
   if (!gt_offsets_host || !anchors || !matched || !labels || num_images < 0 || A < 0) return COIN_EINVAL;
   if (num_images > AM_MAX_IMAGES) return COIN_ESHAPE;
   if (num_images == 0 || A == 0) return COIN_OK;
@@ -309,10 +309,11 @@ extern "C" int coin_anchor_match(const float* gt_boxes, const int* gt_offsets_ho
     if (e != hipSuccess) return (int)e;
   }
   dim3 grid((A + AM_THREADS - 1) / AM_THREADS, num_images);
-  anchor_match_kernel<<<grid, AM_THREADS, 0, st>>>((const float4*)gt_boxes, off, (const float4*)anchors, A, lo, hi, label_lo, label_mid, label_hi,
+  const size_t astride = anchors_per_image ? (size_t)A : 0;
+  anchor_match_kernel<<<grid, AM_THREADS, 0, st>>>((const float4*)gt_boxes, off, (const float4*)anchors, astride, A, lo, hi, label_lo, label_mid, label_hi,
                                                    empty_label, matched, labels, (float4*)matched_boxes, best);
   if (best && total > 0)
-    anchor_low_quality_kernel<<<grid, AM_THREADS, 0, st>>>((const float4*)gt_boxes, off, (const float4*)anchors, A, best, labels);
+    anchor_low_quality_kernel<<<grid, AM_THREADS, 0, st>>>((const float4*)gt_boxes, off, (const float4*)anchors, astride, A, best, labels);
   return coin_launch_status();
 }
 

@@ -678,11 +678,16 @@ def nms_batched(boxes: torch.Tensor, counts: torch.Tensor, iou_threshold: float,
 def anchor_match(gt_boxes: Sequence[torch.Tensor], anchors: torch.Tensor, lo: float, hi: float, labels: Tuple[int, int, int],
                  empty_label: int, allow_low_quality: bool, want_boxes: bool = True):
     """detectron2 Matcher(thresholds [lo, hi], labels) over pairwise_iou(gt_i, anchors) for a batch of images in one launch
-    sequence (coin_anchor_match).  gt_boxes: per image a [G_i, 4] float32 tensor (G_i may be 0); anchors [A, 4].
+    sequence (coin_anchor_match).  gt_boxes: per image a [G_i, 4] float32 tensor (G_i may be 0); anchors [A, 4] shared by the images,
+    or [N, A, 4]: a candidate set per image.
     -> matched gt index [N, A] int64, label [N, A] int8, matched gt box [N, A, 4] (or None)."""
     anchors = _f32c(anchors, "anchors")
     _dev(anchors, *gt_boxes)
-    n, a = len(gt_boxes), anchors.shape[0]
+    per_image = anchors.dim() == 3       # [N, A, 4]: every image has its own candidate set
+    n = len(gt_boxes)
+    if per_image and anchors.shape[0] != n:
+        raise CoinHipError("anchor_match: a [N, A, 4] box set needs one row block per image")
+    a = anchors.shape[1] if per_image else anchors.shape[0]
     offs = [0]
     for g in gt_boxes:
         offs.append(offs[-1] + int(g.shape[0]))
@@ -697,8 +702,8 @@ def anchor_match(gt_boxes: Sequence[torch.Tensor], anchors: torch.Tensor, lo: fl
     mb = torch.empty((n, a, 4), dtype=torch.float32, device=anchors.device) if want_boxes else None
     ws = torch.empty(max(total, 1), dtype=torch.int32, device=anchors.device) if allow_low_quality else None
     c_offs = (ctypes.c_int * (n + 1))(*offs)
-    check(_lib.lib().coin_anchor_match(_p(cat), c_offs, n, _p(anchors), a, float(lo), float(hi), int(labels[0]), int(labels[1]), int(labels[2]),
-                                       int(empty_label), int(bool(allow_low_quality)), _p(matched), _p(lab), _p(mb), _p(ws), _stream()),
+    check(_lib.lib().coin_anchor_match(_p(cat), c_offs, n, _p(anchors), a, int(per_image), float(lo), float(hi), int(labels[0]), int(labels[1]),
+                                       int(labels[2]), int(empty_label), int(bool(allow_low_quality)), _p(matched), _p(lab), _p(mb), _p(ws), _stream()),
           "coin_anchor_match")
     return matched, lab, mb
 

@@ -200,34 +200,51 @@ class OpenVocabularyRes5ROIHeads(nn.Module):
         candidates = RPN proposals (+ validity) ++ teacher boxes, same Matcher, `sample_masks` instead of randperm."""
         k, r = self.num_classes, self.batch_size_per_image
         dev = proposals.boxes.device
-        gmax = max(len(t) for t in targets)
-        cand_b, cand_cls, cand_gt, cand_pr = [], [], [], []
-        for i, t in enumerate(targets):
-            g = len(t)
-            pb, pv = proposals.boxes[i], proposals.valid[i]
-            if self.proposal_append_gt:
-                pb = torch.cat([pb, t.gt_boxes.tensor])
-                pv = torch.cat([pv, torch.ones(g, dtype=torch.bool, device=dev)])
-            pad = gmax - g if self.proposal_append_gt else 0
-            if pad:
-                pb = torch.cat([pb, pb.new_zeros(pad, 4)])
-                pv = torch.cat([pv, torch.zeros(pad, dtype=torch.bool, device=dev)])
-            if g > 0:
-                # IoU + arg-max + threshold band in one launch (coin_anchor_match; bit-identical to Matcher(pairwise_iou(...)))
-                idx, lab, _ = self.proposal_matcher.match_boxes([t.gt_boxes.tensor], pb, want_boxes=False)
-                idx, lab = idx[0], lab[0]
-                cls = torch.where(lab == 1, t.gt_classes_offline[idx], torch.full_like(idx, k))
-                gtb = torch.where((lab == 1).unsqueeze(1), t.gt_boxes.tensor[idx], pb)
-                pr = t.gt_probs_offline[idx]
+        n = len(targets)
+        counts = [len(t) for t in targets]
+        gmax = max(counts)
+        # Batched over the images (round 4: ~15 launches instead of ~20 per image): the teacher boxes / classes / probabilities as
+        # zero-padded [N, gmax, ...] blocks, ONE matcher launch sequence with a candidate set per image (coin_anchor_match,
+        # anchors_per_image), gathers instead of per-image indexing.  Row for row the values of the per-image form.
+        def padded(get, tail, dtype):
+            rows = [get(t) for t in targets]
+            if all(c == gmax for c in counts):
+                return torch.stack(rows) if gmax else torch.zeros((n, 0) + tail, dtype=dtype, device=dev)
+            out = torch.zeros((n, gmax) + tail, dtype=dtype, device=dev)
+            for i, (row, c) in enumerate(zip(rows, counts)):
+                if c:
+                    out[i, :c] = row
+            return out
+
+        gt_b = padded(lambda t: t.gt_boxes.tensor, (4,), proposals.boxes.dtype)
+        pb, pv = proposals.boxes, proposals.valid
+        if self.proposal_append_gt and gmax:
+            if all(c == gmax for c in counts):
+                gv = torch.ones((n, gmax), dtype=torch.bool, device=dev)
             else:
-                cls = torch.full((pb.shape[0],), k, dtype=torch.int64, device=dev)
-                gtb, pr = pb, pb.new_zeros(pb.shape[0], k + 1)
-            cand_cls.append(torch.where(pv, cls, torch.full_like(cls, -1)))
-            cand_b.append(pb)
-            cand_gt.append(gtb)
-            cand_pr.append(pr)
-        cls = torch.stack(cand_cls)                                   # [N, M]
-        boxes, gtb, prs = torch.stack(cand_b), torch.stack(cand_gt), torch.stack(cand_pr)
+                gv = torch.zeros((n, gmax), dtype=torch.bool, device=dev)
+                for i, c in enumerate(counts):
+                    if c:
+                        gv[i, :c] = True
+            pb = torch.cat([pb, gt_b], dim=1)       # padding rows are zero boxes, marked invalid
+            pv = torch.cat([pv, gv], dim=1)
+        pb = pb.contiguous()
+        m = pb.shape[1]
+        if gmax:
+            # IoU + arg-max + threshold band in one launch sequence for the batch (bit-identical to Matcher(pairwise_iou(...)) per image);
+            # an image without teacher boxes gets index 0 and the background band
+            idx, lab, _ = self.proposal_matcher.match_boxes([t.gt_boxes.tensor for t in targets], pb, want_boxes=False)
+            fgm = lab == 1
+            gt_c = padded(lambda t: t.gt_classes_offline, (), torch.int64)
+            gt_p = padded(lambda t: t.gt_probs_offline, (k + 1,), gt_b.dtype if gt_b.is_floating_point() else torch.float32)
+            cls = torch.where(fgm, gt_c.gather(1, idx), torch.full_like(idx, k))
+            gtb = torch.where(fgm.unsqueeze(-1), gt_b.gather(1, idx.unsqueeze(-1).expand(-1, -1, 4)), pb)
+            prs = gt_p.gather(1, idx.unsqueeze(-1).expand(-1, -1, k + 1))
+        else:
+            cls = torch.full((n, m), k, dtype=torch.int64, device=dev)
+            gtb, prs = pb, pb.new_zeros(n, m, k + 1)
+        cls = torch.where(pv, cls, torch.full_like(cls, -1))             # [N, M]
+        boxes = pb
         fg, bg = sample_masks(cls, r, self.positive_fraction, k)
         # exactly r rows per image: chosen fg first, then chosen bg, then (only if short) unchosen fillers marked invalid
         prio = torch.where(fg, 0, torch.where(bg, 1, 2))

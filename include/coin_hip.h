@@ -338,7 +338,8 @@ int coin_nms_batched(const float* boxes, const int* counts, int B, int n_max, fl
  *   composed torch ops.  An image without boxes gets matched = 0, labels = empty_label, matched_boxes = 0.
  * gt_boxes        : [sum G_i, 4] float32 xyxy (device), the images' boxes concatenated;
  * gt_offsets_host : HOST array of num_images + 1 ints, image i owns rows [off[i], off[i+1]); G_i <= 512, num_images <= 64
- * anchors         : [A, 4] float32 (device), shared by the images
+ * anchors         : [A, 4] float32 (device), shared by the images -- or, with anchors_per_image != 0, [num_images, A, 4]: image i is
+ *                   matched against its own set (the RoI samplers: every image's proposals ++ its teacher boxes, one launch per batch)
  * matched         : [num_images, A] int64;  labels: [num_images, A] int8;  matched_boxes (optional): [num_images, A, 4]
  * workspace       : 4 * sum G_i bytes of device memory when allow_low_quality (contents undefined), else may be NULL.
  *
@@ -348,7 +349,7 @@ int coin_nms_batched(const float* boxes, const int* counts, int B, int n_max, fl
  *   keys [num_images, M] float32 >= 0;  out [num_images, M] int8 = 1 (chosen positive) / 0 (chosen negative) / -1.
  * ---------------------------------------------------------------------------------------- */
 int coin_anchor_match(const float* gt_boxes, const int* gt_offsets_host, int num_images, const float* anchors, int A,
-                      float lo, float hi, int label_lo, int label_mid, int label_hi, int empty_label,
+                      int anchors_per_image, float lo, float hi, int label_lo, int label_mid, int label_hi, int empty_label,
                       int allow_low_quality, int64_t* matched, int8_t* labels, float* matched_boxes, void* workspace,
                       void* stream);
 int coin_sample_labels(const void* cls, int cls_is_int64, const float* keys, int num_images, int M, int bg_label,

@@ -133,14 +133,15 @@ def _anchor_match(gt_boxes, anchors, lo, hi, labels, empty_label, allow_low_qual
     else:
         m = d2.Matcher([lo, hi], list(labels), allow_low_quality_matches=allow_low_quality)
     idxs, labs, mbs = [], [], []
-    for g in gt_boxes:
+    for i, g in enumerate(gt_boxes):
         g = g.reshape(-1, 4).float()
+        anc = anchors[i] if anchors.dim() == 3 else anchors      # [N, A, 4]: a candidate set per image
         if g.shape[0] == 0:
-            idxs.append(torch.zeros(anchors.shape[0], dtype=torch.int64))
-            labs.append(torch.full((anchors.shape[0],), empty_label, dtype=torch.int8))
-            mbs.append(torch.zeros_like(anchors))
+            idxs.append(torch.zeros(anc.shape[0], dtype=torch.int64))
+            labs.append(torch.full((anc.shape[0],), empty_label, dtype=torch.int8))
+            mbs.append(torch.zeros_like(anc))
             continue
-        idx, lab = m(d2.pairwise_iou(d2.Boxes(g), d2.Boxes(anchors)))
+        idx, lab = m(d2.pairwise_iou(d2.Boxes(g), d2.Boxes(anc)))
         idxs.append(idx)
         labs.append(lab.to(torch.int8))
         mbs.append(g[idx])

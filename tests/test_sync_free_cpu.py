@@ -191,3 +191,49 @@ def test_sync_free_step_detector_forward_counting_rules_and_finite_losses():
                 assert torch.equal(ps.gt_classes_offline[sl][role == 1], b.gt_classes_offline[j])
             allt = Boxes.cat([a.gt_boxes, b.gt_boxes, c.gt_boxes])
             assert bool((pairwise_iou(allt, boxes).max(0).values[role == 2] < 0.5).all())  # background overlaps no target at all
+
+
+def test_sample_packed_batched_over_images_equals_the_per_image_rules_with_ragged_and_empty_targets():
+    """`sample_packed` (batched over the images: padded teacher blocks, one matcher call with a candidate set per image) on targets of
+    different sizes, one of them EMPTY: every chosen row carries what the per-image composition (Matcher(pairwise_iou) -> class /
+    box / probabilities of the matched teacher box) gives for that box; padding rows are never chosen."""
+    from coin_amd.box_ops import PackedProposals
+    from coin_amd.structures import Boxes, Instances, pairwise_iou
+
+    g = torch.Generator().manual_seed(3)
+    with cpu_kernels():
+        heads = tiny_product_detector().roi_heads
+        k, r = heads.num_classes, heads.batch_size_per_image
+        n, p = 3, 40
+        xy = torch.rand(n, p, 2, generator=g) * 80
+        wh = torch.rand(n, p, 2, generator=g) * 40 + 4
+        boxes = torch.cat([xy, xy + wh], dim=-1)
+        valid = torch.rand(n, p, generator=g) < 0.9
+        props = PackedProposals(boxes, torch.zeros(n, p), valid, [(128, 128)] * n)
+        targets = []
+        for i, cnt in enumerate((5, 0, 2)):
+            t = Instances((128, 128))
+            # teacher boxes = jittered copies of some proposals, so that foreground matches exist
+            t.gt_boxes = Boxes(boxes[i, :cnt] + torch.rand(cnt, 4, generator=g))
+            t.gt_classes_offline = torch.randint(0, k, (cnt,), generator=g)
+            t.gt_probs_offline = torch.rand(cnt, k + 1, generator=g)
+            targets.append(t)
+        torch.manual_seed(9)
+        ps = heads.sample_packed(props, targets)
+        assert ps.per_image == min(r, p + (5 if heads.proposal_append_gt else 0)) and ps.boxes.shape[0] == n * ps.per_image
+        for i, t in enumerate(targets):
+            sl = slice(i * ps.per_image, (i + 1) * ps.per_image)
+            c, b, gb, pr = ps.gt_classes[sl], ps.boxes[sl], ps.gt_boxes[sl], ps.gt_probs[sl]
+            chosen = c >= 0
+            assert not bool(((b[chosen, 2] - b[chosen, 0]) == 0).any())             # a zero padding box was never sampled
+            if len(t) == 0:
+                assert bool((c[chosen] == k).all()) and torch.equal(gb[chosen], b[chosen]) and float(pr[chosen].abs().max()) == 0.0
+                continue
+            iou = pairwise_iou(t.gt_boxes, Boxes(b))
+            best, arg = iou.max(dim=0)
+            fg = chosen & (c < k)
+            assert bool((best[fg] >= 0.5).all()) and bool((best[chosen & (c == k)] < 0.5).all())
+            assert torch.equal(c[fg], t.gt_classes_offline[arg[fg]])
+            close(gb[fg], t.gt_boxes.tensor[arg[fg]], 0)
+            close(gb[chosen & ~fg], b[chosen & ~fg], 0)
+            close(pr[chosen], t.gt_probs_offline[arg[chosen]], 0)

@@ -20,13 +20,15 @@ t0, t1 = rows[k]["e"], rows[i_roi]["s"]
 print(f"window {(t1 - t0) / 1e3:.1f} us from end of {rows[k]['Kernel_Name'][:50]} to start of RoIAlign fwd")
 per_q = collections.defaultdict(lambda: [0, 0])
 names = collections.Counter()
+counts = collections.Counter()
 for r in rows[k + 1:i_roi]:
     if r["s"] >= t0 and r["e"] <= t1:
         per_q[r["Queue_Id"]][0] += 1
         per_q[r["Queue_Id"]][1] += r["e"] - r["s"]
         if r["Queue_Id"] == q:
-            names[r["Kernel_Name"][:70]] += (r["e"] - r["s"]) / 1e3
+            names[r["Kernel_Name"][:110]] += (r["e"] - r["s"]) / 1e3
+            counts[r["Kernel_Name"][:110]] += 1
 for qq, (n, ns) in per_q.items():
     print(f"queue {qq}{' (main)' if qq == q else ''}: {n} kernels, {ns / 1e3:.1f} us busy")
-for nm, us in names.most_common(14):
-    print(f"  {us:8.1f} us  {nm}")
+for nm, us in names.most_common(40):
+    print(f"  {us:8.1f} us  x{counts[nm]:3d}  {nm}")
