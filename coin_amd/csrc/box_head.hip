@@ -33,13 +33,14 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
 // leading dimension ld into `lds_tile` (16 KiB).  Rows >= nrows are clamped (their products only
 // reach outputs that are never stored).  Image: row r at byte r*128, 16-byte chunk c stored at
 // physical chunk c ^ (r & 7).
+template <int NW>   // waves of the workgroup (4 or 8): each stages 16 / NW of the tile's 8-row groups
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ mat, int ld, int row0, int nrows, int k0,
                                            char* lds_tile, int wave, int lane) {
   const int rl = lane >> 3;                 // row within the 8-row group written by one instruction
   const int c = (lane & 7) ^ rl;            // logical chunk that must land at physical chunk lane&7
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int rgrp = wave * 4 + j;          // 8-row group index (16 groups per tile)
+  for (int j = 0; j < 16 / NW; ++j) {
+    const int rgrp = wave * (16 / NW) + j;  // 8-row group index (16 groups per tile)
     int row = row0 + rgrp * 8 + rl;
     row = row < nrows ? row : nrows - 1;
     const bf16_t* src = mat + (size_t)row * ld + k0 + c * 8;
@@ -51,10 +52,15 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* lds_tile, int row, int ch
   return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + ((chunk ^ (row & 7)) << 4));
 }
 
-template <typename OutT>
-__global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(
+// NW = 4: 2 x 2 waves of 64 x 64 (the throughput shape: two workgroups per CU hide each other's waits).  NW = 8: 2 x 4 waves of 64 x 32
+// for launches with no more tiles than CUs (the box head's M = 2048 GEMMs): two waves per SIMD, so that one wave's 12 LDS fragment
+// reads run under the other's 16 MFMAs -- with one wave per SIMD they ran back to back (~512 + 512 cycles per half K-step).
+template <typename OutT, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_nt_bf16_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, OutT* __restrict__ Cmat, int ldc,
     int M, int N, int K, const float* __restrict__ bias, int act, float alpha, int tiles_m, int tiles_n) {
+  constexpr int WC = NW / 2;          // waves along N
+  constexpr int NJ = 4 / (WC / 2);    // 16-column fragments per wave: 4 (NW = 4) or 2 (NW = 8)
   __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // [buf][A|B]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -67,17 +73,17 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(
   }
   const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WC, wc = wave % WC;
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nt = K / BK;
-  stage_tile(A, lda, m0, M, 0, lds, wave, lane);
-  stage_tile(B, ldb, n0, N, 0, lds + TILE_BYTES, wave, lane);
+  stage_tile<NW>(A, lda, m0, M, 0, lds, wave, lane);
+  stage_tile<NW>(B, ldb, n0, N, 0, lds + TILE_BYTES, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -88,20 +94,20 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(
     char* lb = la + TILE_BYTES;
     if (t + 1 < nt) {
       char* na = lds + (cur ^ 1) * 2 * TILE_BYTES;
-      stage_tile(A, lda, m0, M, (t + 1) * BK, na, wave, lane);
-      stage_tile(B, ldb, n0, N, (t + 1) * BK, na + TILE_BYTES, wave, lane);
+      stage_tile<NW>(A, lda, m0, M, (t + 1) * BK, na, wave, lane);
+      stage_tile<NW>(B, ldb, n0, N, (t + 1) * BK, na + TILE_BYTES, wave, lane);
     }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[4], bfr[4];
+      bf16x8 af[4], bfr[NJ];
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[i] = lds_frag(la, wr * 64 + i * 16 + fr, kk * 4 + fq);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = lds_frag(lb, wc * 64 + j * 16 + fr, kk * 4 + fq);
+      for (int j = 0; j < NJ; ++j) bfr[j] = lds_frag(lb, wc * (16 * NJ) + j * 16 + fr, kk * 4 + fq);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -110,8 +116,8 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(
 
   // epilogue: C/D layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int col = n0 + wc * 64 + j * 16 + fr;
+  for (int j = 0; j < NJ; ++j) {
+    const int col = n0 + wc * (16 * NJ) + j * 16 + fr;
     if (col >= N) continue;
     const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
@@ -409,12 +415,19 @@ extern "C" int coin_gemm_nt(const void* A, int lda, const void* B, int ldb, void
     if (K % BK || lda % 8 || ldb % 8) return COIN_ESHAPE;
     if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return COIN_EALIGN;
     const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
-    if (out_dtype == COIN_BF16)
-      gemm_nt_bf16_kernel<bf16_t><<<tm * tn, 256, 0, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C,
-                                                            ldc, M, N, K, bias, act, act_alpha, tm, tn);
-    else
-      gemm_nt_bf16_kernel<float><<<tm * tn, 256, 0, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, (float*)C, ldc,
-                                                           M, N, K, bias, act, act_alpha, tm, tn);
+    static int ncu = 0;
+    if (!ncu) {
+      int dev = 0, v = 0;
+      ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+#define GO(OT, NW) gemm_nt_bf16_kernel<OT, NW><<<tm * tn, NW * 64, 0, st>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, (OT*)C, ldc, M, N, K, bias, act, act_alpha, tm, tn)
+    const bool small = tm * tn <= ncu;
+    if (out_dtype == COIN_BF16) {
+      if (small) GO(bf16_t, 8); else GO(bf16_t, 4);
+    } else {
+      if (small) GO(float, 8); else GO(float, 4);
+    }
+#undef GO
   } else {
     if (K % FK || lda % 4 || ldb % 4) return COIN_ESHAPE;
     if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return COIN_EALIGN;
