@@ -71,15 +71,15 @@ SIGNATURES = {
     "coin_aug_point_op_u8": [_P, _P, _I, _I, _I, _F, _I, _P, _I, _P],
     "coin_aug_gaussian_blur_u8": [_P, _P, _I, _I, _F, _P, _P],
     "coin_transpose2d": [_P, _P, _I, _I, _I, _P],
-    "coin_bias_act_bwd": [_P, _P, _P, _I, _I, _I, _P, _I, _F, _I, _P],
+    "coin_bias_act_bwd": [_P, _P, _P, _I, _I, _I, _P, _I, _F, _I, _P, _P],
     "coin_cosine_logits_fwd": [_P, _I, _P, _I, _I, _I, _F, _P, _P, _I, _P],
-    "coin_cosine_logits_bwd": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _F, _P, _P, _I, _P],
+    "coin_cosine_logits_bwd": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _F, _P, _P, _I, _P, _P],
     "coin_mil_ce_fwd_bwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "coin_mil_focal_fwd_bwd": [_P, _I, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P, _P, _P],
     "coin_kl_div_fwd_bwd": [_P, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P, _P],
     "coin_box_reg_l1_fwd_bwd": [_P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P],
     "coin_l1_mean_fwd_bwd": [_P, _P, _L, _P, _P, _P],
-    "coin_rpn_losses_fwd_bwd": [_P, _P, _P, _P, _P, _L, _L, _I, _P, _P, _P, _P, _P],
+    "coin_rpn_losses_fwd_bwd": [_P, _P, _P, _P, _P, _L, _L, _I, _P, _P, _P, _P, _P, _P],
     "coin_normalize_pad": [_P, _I, _I, ctypes.POINTER(c_float), ctypes.POINTER(c_float), _P, _I, _I, _I, _I, _I, _P],
     "coin_bn_stats": [_P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P],
     "coin_bn_apply_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

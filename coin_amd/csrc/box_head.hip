@@ -265,31 +265,62 @@ __global__ __launch_bounds__(256) void weight_dgrad_layout_kernel(const coin_wd_
 // ------------------------------------------------------------------------------------------
 // bias + activation backward
 // ------------------------------------------------------------------------------------------
-template <typename T>
+// Workgroup (bx, by) owns rows [256 by, 256 by + 256) x columns [64 bx, 64 bx + 64): dZ, and the column sums of its rows as ONE
+// partial row part[by][col] (no atomics: `bias_sum_kernel` adds the partials to dbias in block order, so the bias gradient is
+// bit-reproducible).  V = columns per thread: 16-byte accesses where N, ld and the pointers allow it, else 1.
+template <typename T, int V>
 __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__ dC, const T* __restrict__ Cm,
                                                            T* __restrict__ dZ, int ld, int M, int N,
-                                                           float* __restrict__ dbias, int act, float alpha) {
-  __shared__ float red[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + lane;
+                                                           float* __restrict__ part, int act, float alpha) {
+  constexpr int CL = 64 / V;          // column lanes
+  constexpr int RL = 256 / CL;        // row lanes
+  typedef T vec_t __attribute__((ext_vector_type(V)));
+  __shared__ float red[RL][64];
+  const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+  const int col = blockIdx.x * 64 + cl * V;
   const int r0 = blockIdx.y * 256;
-  float s = 0.f;
+  float s[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) s[i] = 0.f;
   if (col < N) {
-    for (int r = r0 + wave; r < M && r < r0 + 256; r += 4) {
+    for (int r = r0 + rl; r < M && r < r0 + 256; r += RL) {
       const size_t o = (size_t)r * ld + col;
-      float g = (float)dC[o];
+      const vec_t gin = *reinterpret_cast<const vec_t*>(dC + o);
+      float gf[V];
+#pragma unroll
+      for (int i = 0; i < V; ++i) gf[i] = (float)gin[i];
       if (act != COIN_ACT_NONE) {
-        const float c = (float)Cm[o];
-        if (act == COIN_ACT_LEAKY_RELU) g = c > 0.f ? g : g * alpha;
-        else g = c > 0.f ? g : 0.f;
+        const vec_t c = *reinterpret_cast<const vec_t*>(Cm + o);
+#pragma unroll
+        for (int i = 0; i < V; ++i) gf[i] = (float)c[i] > 0.f ? gf[i] : (act == COIN_ACT_LEAKY_RELU ? gf[i] * alpha : 0.f);
       }
-      if (dZ) dZ[o] = (T)g;
-      s += g;
+      if (dZ) {
+        vec_t g;
+#pragma unroll
+        for (int i = 0; i < V; ++i) g[i] = (T)gf[i];
+        *reinterpret_cast<vec_t*>(dZ + o) = g;
+      }
+#pragma unroll
+      for (int i = 0; i < V; ++i) s[i] += gf[i];   // the fp32 value, as before (not the rounded store)
     }
   }
-  red[wave][lane] = s;
+#pragma unroll
+  for (int i = 0; i < V; ++i) red[rl][cl * V + i] = s[i];
   __syncthreads();
-  if (wave == 0 && col < N && dbias) atomicAdd(dbias + col, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+  if (part && threadIdx.x < 64 && blockIdx.x * 64 + (int)threadIdx.x < N) {
+    float t = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < RL; ++k) t += red[k][threadIdx.x];
+    part[(size_t)blockIdx.y * N + blockIdx.x * 64 + threadIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void bias_sum_kernel(const float* __restrict__ part, int nby, int N, float* __restrict__ dbias) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= N) return;
+  float t = 0.f;
+  for (int y = 0; y < nby; ++y) t += part[(size_t)y * N + col];
+  dbias[col] += t;   // ACCUMULATED (one writer per column)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -335,7 +366,7 @@ __global__ __launch_bounds__(256) void cosine_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ scores,
                                                          const float* __restrict__ inv_norm_f, int R, int D, int Kc,
                                                          float inv_scale, T* __restrict__ d_feats,
-                                                         float* __restrict__ d_text) {
+                                                         float* __restrict__ d_text /* this block's partial [Kc][D] */) {
   __shared__ float s_inv_t[COS_MAX_K];
   __shared__ float s_ds[16][COS_MAX_K];
   __shared__ float s_sc[16][COS_MAX_K];
@@ -386,7 +417,7 @@ __global__ __launch_bounds__(256) void cosine_bwd_kernel(const float* __restrict
       if (d_text) {
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-          if (k < kn) atomicAdd(d_text + (size_t)(kb + k) * D + d, dt[k] * s_inv_t[kb + k]);
+          if (k < kn) d_text[((size_t)blockIdx.x * Kc + kb + k) * D + d] = dt[k] * s_inv_t[kb + k];   // joined in block order by cosine_dtext_sum_kernel
       }
     }
     if (d_feats) {
@@ -399,6 +430,15 @@ __global__ __launch_bounds__(256) void cosine_bwd_kernel(const float* __restrict
       }
     }
   }
+}
+
+// d_text[k][d] += sum over the row blocks' partials, in block order (no float atomics: bit-reproducible)
+__global__ __launch_bounds__(256) void cosine_dtext_sum_kernel(const float* __restrict__ part, int nblk, int n, float* __restrict__ d_text) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float t = 0.f;
+  for (int b = 0; b < nblk; ++b) t += part[(size_t)b * n + i];
+  d_text[i] += t;
 }
 
 }  // namespace
@@ -464,20 +504,26 @@ extern "C" int coin_weight_dgrad_layout(const coin_wd_tensor* table, int num_ten
 }
 
 extern "C" int coin_bias_act_bwd(const void* dC, const void* C, void* dZ, int ld, int M, int N, float* dbias, int act,
-                                 float act_alpha, int dtype, void* stream) {
+                                 float act_alpha, int dtype, void* workspace, void* stream) {
   if (!dC || M < 0 || N < 0 || ld < N) return COIN_EINVAL;
   if (act != COIN_ACT_NONE && !C) return COIN_EINVAL;
   if (act < COIN_ACT_NONE || act > COIN_ACT_RELU) return COIN_EINVAL;
   if (dtype != COIN_F32 && dtype != COIN_BF16) return COIN_EINVAL;
+  if (dbias && !workspace) return COIN_EINVAL;   // ceil(M / 256) * N floats of partial column sums
   if (M == 0 || N == 0) return COIN_OK;
   dim3 grid((N + 63) / 64, (M + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == COIN_F32)
-    bias_act_bwd_kernel<float><<<grid, 256, 0, st>>>((const float*)dC, (const float*)C, (float*)dZ, ld, M, N, dbias, act,
-                                                      act_alpha);
-  else
-    bias_act_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)dC, (const bf16_t*)C, (bf16_t*)dZ, ld, M, N, dbias,
-                                                       act, act_alpha);
+  float* part = dbias ? (float*)workspace : nullptr;
+  const int v = dtype == COIN_F32 ? 4 : 8;
+  const bool wide = N % v == 0 && ld % v == 0 && !(((uintptr_t)dC | (uintptr_t)C | (uintptr_t)dZ) & 15);
+#define GO(T, V) bias_act_bwd_kernel<T, V><<<grid, 256, 0, st>>>((const T*)dC, (const T*)C, (T*)dZ, ld, M, N, part, act, act_alpha)
+  if (dtype == COIN_F32) {
+    if (wide) GO(float, 4); else GO(float, 1);
+  } else {
+    if (wide) GO(bf16_t, 8); else GO(bf16_t, 1);
+  }
+#undef GO
+  if (dbias) bias_sum_kernel<<<(N + 255) / 256, 256, 0, st>>>(part, (int)grid.y, N, dbias);
   return coin_launch_status();
 }
 
@@ -499,8 +545,9 @@ extern "C" int coin_cosine_logits_fwd(const void* feats, int ldf, const float* t
 
 extern "C" int coin_cosine_logits_bwd(const float* d_scores, const void* feats, int ldf, const float* text,
                                       const float* scores, const float* inv_norm_f, int R, int D, int Kc,
-                                      float inv_scale, void* d_feats, float* d_text, int dtype, void* stream) {
+                                      float inv_scale, void* d_feats, float* d_text, int dtype, void* workspace, void* stream) {
   if (!d_scores || !feats || !text || !scores || !inv_norm_f) return COIN_EINVAL;
+  if (d_text && !workspace) return COIN_EINVAL;   // ceil(R / 16) * Kc * D floats: the row blocks' partial text gradients
   if (R < 0 || D <= 0 || Kc <= 0 || ldf < D) return COIN_EINVAL;
   if (Kc > COS_MAX_K) return COIN_ESHAPE;
   if (dtype != COIN_F32 && dtype != COIN_BF16) return COIN_EINVAL;
@@ -509,9 +556,10 @@ extern "C" int coin_cosine_logits_bwd(const float* d_scores, const void* feats, 
   const int grid = (R + 15) / 16;
   if (dtype == COIN_F32)
     cosine_bwd_kernel<float><<<grid, 256, 0, st>>>(d_scores, (const float*)feats, ldf, text, scores, inv_norm_f, R, D, Kc,
-                                                    inv_scale, (float*)d_feats, d_text);
+                                                    inv_scale, (float*)d_feats, d_text ? (float*)workspace : nullptr);
   else
     cosine_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>(d_scores, (const bf16_t*)feats, ldf, text, scores, inv_norm_f, R, D,
-                                                     Kc, inv_scale, (bf16_t*)d_feats, d_text);
+                                                     Kc, inv_scale, (bf16_t*)d_feats, d_text ? (float*)workspace : nullptr);
+  if (d_text) cosine_dtext_sum_kernel<<<(Kc * D + 255) / 256, 256, 0, st>>>((const float*)workspace, grid, Kc * D, d_text);
   return coin_launch_status();
 }

@@ -220,12 +220,12 @@ __global__ __launch_bounds__(LOSS_THREADS) void l1_mean_kernel(const float* __re
   if (threadIdx.x == 0) *loss = tot * inv;
 }
 
-// Multi-block (A_total ~ 250k): per-block partial sums, atomically added into the two outputs
-// (zeroed by a preceding memset node).
+// Multi-block (A_total ~ 250k): per-block partial sums part[block][2]; rpn_losses_sum_kernel adds them in block order (no float
+// atomics: the two totals are bit-reproducible).
 __global__ __launch_bounds__(256) void rpn_losses_kernel(
     const float* __restrict__ logits, const int8_t* __restrict__ labels, const float* __restrict__ deltas,
     const float* __restrict__ anchors, const float* __restrict__ gts, int64_t A_total, int64_t A_img, int min_label,
-    float* __restrict__ loss_cls, float* __restrict__ loss_loc, float* __restrict__ g_logits,
+    float* __restrict__ part, float* __restrict__ g_logits,
     float* __restrict__ g_deltas) {
   __shared__ float red[16];
   float lc = 0.f, ll = 0.f;
@@ -256,8 +256,17 @@ __global__ __launch_bounds__(256) void rpn_losses_kernel(
   const float tc = block_reduce_sum(lc, red);
   const float tl = block_reduce_sum(ll, red);
   if (threadIdx.x == 0) {
-    atomicAdd(loss_cls, tc);
-    atomicAdd(loss_loc, tl);
+    part[2 * blockIdx.x] = tc;
+    part[2 * blockIdx.x + 1] = tl;
+  }
+}
+
+__global__ __launch_bounds__(64) void rpn_losses_sum_kernel(const float* __restrict__ part, int nblk, float* __restrict__ loss_cls,
+                                                            float* __restrict__ loss_loc) {
+  if (threadIdx.x < 2) {
+    float t = 0.f;
+    for (int b = 0; b < nblk; ++b) t += part[2 * b + threadIdx.x];
+    *(threadIdx.x == 0 ? loss_cls : loss_loc) = t;
   }
 }
 
@@ -315,18 +324,15 @@ extern "C" int coin_l1_mean_fwd_bwd(const float* a, const float* b, int64_t n, f
 extern "C" int coin_rpn_losses_fwd_bwd(const float* logits, const int8_t* labels, const float* deltas,
                                        const float* anchors, const float* matched_gt, int64_t A_total,
                                        int64_t A_per_image, int min_label, float* loss_cls, float* loss_loc,
-                                       float* grad_logits, float* grad_deltas, void* stream) {
+                                       float* grad_logits, float* grad_deltas, void* workspace, void* stream) {
   if (!loss_cls || !loss_loc || A_total < 0 || A_per_image <= 0) return COIN_EINVAL;
-  if (A_total > 0 && (!logits || !labels || !deltas || !anchors || !matched_gt)) return COIN_EINVAL;
+  if (A_total > 0 && (!logits || !labels || !deltas || !anchors || !matched_gt || !workspace)) return COIN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(loss_cls, 0, sizeof(float), st);
-  if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(loss_loc, 0, sizeof(float), st);
-  if (e != hipSuccess) return (int)e;
-  if (A_total == 0) return COIN_OK;
   int grid = (int)((A_total + 255) / 256);
-  if (grid > 1024) grid = 1024;
-  rpn_losses_kernel<<<grid, 256, 0, st>>>(logits, labels, deltas, anchors, matched_gt, A_total, A_per_image, min_label,
-                                          loss_cls, loss_loc, grad_logits, grad_deltas);
+  if (grid > COIN_RPN_LOSS_MAX_BLOCKS) grid = COIN_RPN_LOSS_MAX_BLOCKS;
+  if (grid > 0)
+    rpn_losses_kernel<<<grid, 256, 0, st>>>(logits, labels, deltas, anchors, matched_gt, A_total, A_per_image, min_label,
+                                            (float*)workspace, grad_logits, grad_deltas);
+  rpn_losses_sum_kernel<<<1, 64, 0, st>>>((const float*)workspace, grid, loss_cls, loss_loc);
   return coin_launch_status();
 }

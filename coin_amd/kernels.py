@@ -418,8 +418,9 @@ def bias_act_bwd(dc: torch.Tensor, c: Optional[torch.Tensor], act: int, act_alph
     dz = torch.empty_strided(dc.shape, dc.stride(), dtype=dc.dtype, device=dc.device) if want_dz else None
     if dbias is None:
         dbias = torch.zeros(n, dtype=torch.float32, device=dc.device)
+    ws = torch.empty(((m + 255) // 256) * n, dtype=torch.float32, device=dc.device)   # per-256-row-block column sums (joined in block order)
     check(_lib.lib().coin_bias_act_bwd(_p(dc), _p(c), _p(dz), dc.stride(0), m, n, _p(dbias), act, float(act_alpha),
-                                       _dt(dc), _stream()), "coin_bias_act_bwd")
+                                       _dt(dc), _p(ws), _stream()), "coin_bias_act_bwd")
     return dz, dbias
 
 
@@ -445,8 +446,9 @@ def cosine_logits_bwd(d_scores: torch.Tensor, feats: torch.Tensor, text: torch.T
     kc = text.shape[0]
     d_feats = torch.empty_strided(feats.shape, feats.stride(), dtype=feats.dtype, device=feats.device)
     d_text = torch.zeros_like(text) if need_text_grad else None
+    ws = torch.empty(((r + 15) // 16) * kc * d, dtype=torch.float32, device=feats.device) if need_text_grad else None   # per-row-block partials
     check(_lib.lib().coin_cosine_logits_bwd(_p(d_scores), _p(feats), feats.stride(0), _p(text), _p(scores), _p(inv_norm),
-                                            r, d, kc, float(inv_scale), _p(d_feats), _p(d_text), _dt(feats), _stream()),
+                                            r, d, kc, float(inv_scale), _p(d_feats), _p(d_text), _dt(feats), _p(ws), _stream()),
           "coin_cosine_logits_bwd")
     return d_feats, d_text
 
@@ -562,9 +564,10 @@ def rpn_losses(logits: torch.Tensor, labels: torch.Tensor, deltas: torch.Tensor,
     out = torch.empty(2, dtype=torch.float32, device=logits.device)
     g_logits = torch.empty_like(logits) if want_grad else None
     g_deltas = torch.empty_like(deltas) if want_grad else None
+    ws = torch.empty(2 * 1024, dtype=torch.float32, device=logits.device)   # COIN_RPN_LOSS_MAX_BLOCKS partial pairs
     check(_lib.lib().coin_rpn_losses_fwd_bwd(_p(logits), _p(labels), _p(deltas), _p(anchors), _p(matched_gt), a_total,
                                              a_img, int(min_label), ctypes.c_void_p(out.data_ptr()),
-                                             ctypes.c_void_p(out.data_ptr() + 4), _p(g_logits), _p(g_deltas), _stream()),
+                                             ctypes.c_void_p(out.data_ptr() + 4), _p(g_logits), _p(g_deltas), _p(ws), _stream()),
           "coin_rpn_losses_fwd_bwd")
     return out[0], out[1], g_logits, g_deltas
 

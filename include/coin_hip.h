@@ -114,9 +114,10 @@ int coin_transpose2d(const void* in, void* out, int M, int N, int dtype, void* s
 /* Backward of bias + activation for C = act(Z + bias):
  *   dZ[M,N] = dC * act'(C)   (leaky/relu derivative recovered from the sign of C)
  *   dbias[N] += sum_m dZ[m,n]  (float32, ACCUMULATED; may be NULL)
- * dC, C, dZ share dtype `dtype` and leading dimension ld. */
+ * dC, C, dZ share dtype `dtype` and leading dimension ld.  workspace: ceil(M / 256) * N floats (required when dbias is given): the
+ * column sums of every 256-row block, added to dbias in block order by a second launch -- no float atomics, bit-reproducible. */
 int coin_bias_act_bwd(const void* dC, const void* C, void* dZ, int ld, int M, int N,
-                      float* dbias, int act, float act_alpha, int dtype, void* stream);
+                      float* dbias, int act, float act_alpha, int dtype, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused train-mode BatchNorm (+ residual) (+ ReLU) (+ 2x2 average pool), channels-last
@@ -174,10 +175,12 @@ int coin_cosine_logits_fwd(const void* feats, int ldf, const float* text, int R,
                            float inv_scale, float* scores, float* inv_norm_f, int dtype,
                            void* stream);
 
-/* d_feats[R,D] (dtype `dtype`) and d_text[Kc,D] (float32, ACCUMULATED) given d_scores[R,Kc]. */
+/* d_feats[R,D] (dtype `dtype`) and d_text[Kc,D] (float32, ACCUMULATED) given d_scores[R,Kc].  workspace (required when d_text is
+ * given): ceil(R / 16) * Kc * D floats -- every 16-row block's partial text gradient, added to d_text in block order by a second
+ * launch (no float atomics: bit-reproducible). */
 int coin_cosine_logits_bwd(const float* d_scores, const void* feats, int ldf, const float* text,
                            const float* scores, const float* inv_norm_f, int R, int D, int Kc,
-                           float inv_scale, void* d_feats, float* d_text, int dtype, void* stream);
+                           float inv_scale, void* d_feats, float* d_text, int dtype, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * bf16 GEMM / implicit-GEMM convolution of the res5 bottlenecks on the RoI tiles (coin/modeling/utils.py:77-90,184-186 as run by
@@ -305,10 +308,12 @@ int coin_l1_mean_fwd_bwd(const float* a, const float* b, int64_t n, float* loss,
  * anchors [A_per_image,4] (broadcast over images), matched_gt [A_total,4].
  * Outputs are SUMS (caller divides by batch_size_per_image * num_images).
  * grad_logits [A_total], grad_deltas [A_total,4] (unit upstream for each loss) or NULL. */
+#define COIN_RPN_LOSS_MAX_BLOCKS 1024
+/* workspace: 2 * COIN_RPN_LOSS_MAX_BLOCKS floats (per-block partial sums, joined in block order: no float atomics). */
 int coin_rpn_losses_fwd_bwd(const float* logits, const int8_t* labels, const float* deltas,
                             const float* anchors, const float* matched_gt, int64_t A_total,
                             int64_t A_per_image, int min_label, float* loss_cls, float* loss_loc,
-                            float* grad_logits, float* grad_deltas, void* stream);
+                            float* grad_logits, float* grad_deltas, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Batched greedy NMS  (replaces torchvision.ops.nms / batched_nms under detectron2

@@ -388,6 +388,20 @@ def test_transpose_and_bias_act_bwd(K):
     dz, db = K.bias_act_bwd(dev(dc.float()), dev(c.detach().float()), 1, 0.01)
     torch.testing.assert_close(dz.cpu().double(), z.grad, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(db.cpu().double(), bias.grad, rtol=1e-4, atol=1e-4)
+    # several 256-row blocks, ragged rows / columns, both access widths (N % 8 != 0 -> scalar lanes), bf16: the bias gradient is the sum of
+    # per-block partials in block order (no float atomics) -> identical bits on every run, and it accumulates into `dbias`
+    for m, n, dt in ((2048, 1024, torch.bfloat16), (777, 72, torch.bfloat16), (600, 9, torch.bfloat16), (1030, 100, torch.float32)):
+        dc2 = dev(torch.randn(m, n, generator=g).to(dt))
+        c2 = dev(torch.randn(m, n, generator=g).to(dt))
+        dz2, db2 = K.bias_act_bwd(dc2, c2, 2, 0.0)
+        ref = dc2.double() * (c2.double() > 0)
+        torch.testing.assert_close(dz2.double(), ref, rtol=0, atol=0)
+        torch.testing.assert_close(db2.double(), ref.sum(0), rtol=1e-5, atol=1e-4)
+        for _ in range(3):
+            assert torch.equal(K.bias_act_bwd(dc2, c2, 2, 0.0)[1], db2)
+        acc = torch.ones(n, device="cuda")
+        K.bias_act_bwd(dc2, c2, 2, 0.0, dbias=acc)
+        torch.testing.assert_close(acc, db2 + 1.0, rtol=1e-6, atol=1e-5)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -406,6 +420,8 @@ def test_cosine_logits(K, dtype, r, d, kc):
     tol = 1e-4 if dtype == torch.float32 else 1e-2
     torch.testing.assert_close(df.cpu().double(), fd.grad, rtol=tol, atol=tol * float(fd.grad.abs().max()))
     torch.testing.assert_close(dtx.cpu().double(), td.grad, rtol=1e-3, atol=1e-3 * float(td.grad.abs().max()))
+    for _ in range(2):   # the text gradient is joined over the row blocks in block order (no float atomics): identical bits on every run
+        assert torch.equal(K.cosine_logits_bwd(dev(ds), dev(f), dev(t), s, inv, 100.0)[1], dtx)
 
 
 # ------------------------------------------------------------------------------------------ losses
@@ -536,6 +552,9 @@ def test_rpn_losses_vs_golden_inputs(K):
     matched = torch.from_numpy(z["matched_boxes"])
     anchors = torch.from_numpy(z["anchors"])
     cls, loc, g_l, g_d = K.rpn_losses(dev(logits.contiguous()), dev(labels), dev(deltas), dev(anchors), dev(matched))
+    for _ in range(2):   # block partials joined in block order (no float atomics): identical totals on every run
+        c2, l2, _, _ = K.rpn_losses(dev(logits.contiguous()), dev(labels), dev(deltas), dev(anchors), dev(matched))
+        assert torch.equal(c2, cls) and torch.equal(l2, loc)
     norm = 64 * 2
     assert abs(float(cls) / norm - float(z["loss::loss_rpn_cls"])) < 1e-4
     assert abs(float(loc) / norm - float(z["loss::loss_rpn_loc"])) < 1e-4
