@@ -266,6 +266,7 @@ def run_secondary_targetdet(steps: int = 24, warmup: int = 8, images: int = 3):
         loss = float(sum(float(v) for v in rec.values()))
         return {"metric": "targetDET step_one student images/sec (667x1333, 512 RoI/img, teacher pass + A/B/C matching included)", "value": images / dt,
                 "unit": "images/sec", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": dt * 1e3, "median_group_ms_per_step": sorted(groups)[len(groups) // 2],
+                "fastest_group_ms_per_step": min(groups), "groups_ms_per_step_in_order": [round(g, 1) for g in groups],   # host-bound: a busy host shows as unequal groups
                 "images_per_step": images, "dtype": "bf16", "data": "synthetic", "final_loss": loss, "finite": loss == loss and abs(loss) < 1e6,
                 "config": {"workload": "BASELINE configs[2]: CoinTrainer.run_step + prepare_next, CLIP-RN50 C4/res5 student and EMA teacher (frozen in step_one), "
                                        "3 synthetic Foggy-Cityscapes-shaped images per step, 1000 teacher RoIs + 512 student RoIs per image, 8 classes"}}
