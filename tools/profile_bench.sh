@@ -16,7 +16,7 @@ stats=$(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1)
 trace=$(find /tmp/prof_$tag -name "*kernel_trace.csv" | head -1)
 if [ -n "$stats" ]; then
   head -1 "$stats" > "$out/bench_kernel_stats_ours.csv"
-  grep -E "roi_align|bn_|gemm_nt|conv_gemm|conv_wgrad|wgrad_reduce|tn_reduce|slab_sum|conv_stats|mil_focal|nms_|sgd_kernel|ema_kernel|cosine_|mil_ce|kl_div|box_reg|l1_mean|rpn_losses|normalize_pad|avgpool2|transpose_kernel|bias_act" "$stats" >> "$out/bench_kernel_stats_ours.csv"
+  grep -E "roi_align|bn_|gemm_nt|conv_gemm|conv_wgrad|wgrad_reduce|tn_reduce|slab_sum|conv_stats|mil_focal|nms_|sgd_kernel|ema_kernel|cosine_|mil_ce|kl_div|box_reg|l1_mean|rpn_losses|normalize_pad|avgpool2|transpose_kernel|bias_act|bias_sum|weight_dgrad|window_attn|anchor_match|sample_labels" "$stats" >> "$out/bench_kernel_stats_ours.csv"
   head -61 "$stats" > "$out/bench_kernel_stats_top60.csv"
 fi
 if [ -n "$trace" ]; then
