@@ -77,6 +77,13 @@ def test_argument_validation_without_gpu(lib):
     assert lib.coin_roi_align_bwd_level(None, 1, 8, 4, 4, None, None, 0, 1, 7, 7, 0.25, 0, 1, None, 1, None) == -1
     assert lib.coin_window_attn_bwd(None, None, None, None, None, None, None, 4, 1, 3, 49, 32, 0.17, None) == -1
     assert lib.coin_window_attn_bwd_workspace_bytes(3456, 3) == 341 * 3 * 64 * 64 * 4
+    # round 4: the pooled-residual GEMM needs its residual; the three reductions that replaced float atomics need their workspaces
+    x = ctypes.c_void_p(0x1000)   # any non-NULL, 16-byte-aligned address: rejected before it is dereferenced
+    assert lib.coin_conv_gemm_bf16_rpool(x, 64, 0, 0, 0, 0, x, 64, x, 256, None, 256, 14, 14, 196, 256, 64, None, 0, None) == -1
+    assert lib.coin_conv_gemm_bf16_rpool(x, 64, 0, 0, 0, 0, x, 64, x, 256, x, 256, 14, 14, 195, 256, 64, None, 0, None) == -1   # M % (h w)
+    assert lib.coin_bias_act_bwd(x, x, x, 64, 8, 64, x, 1, 0.01, 1, None, None) == -1
+    assert lib.coin_cosine_logits_bwd(x, x, 64, x, x, x, 8, 64, 9, 100.0, x, x, 1, None, None) == -1
+    assert lib.coin_rpn_losses_fwd_bwd(x, x, x, x, x, 16, 16, 0, x, x, None, None, None, None) == -1
 
 
 def test_product_has_no_cpu_fallback():
