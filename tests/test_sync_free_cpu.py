@@ -237,3 +237,19 @@ def test_sample_packed_batched_over_images_equals_the_per_image_rules_with_ragge
             close(gb[fg], t.gt_boxes.tensor[arg[fg]], 0)
             close(gb[chosen & ~fg], b[chosen & ~fg], 0)
             close(pr[chosen], t.gt_probs_offline[arg[chosen]], 0)
+
+
+def test_apply_deltas_on_coordinate_pairs_equals_the_column_form_bit_for_bit():
+    """`Box2BoxTransform.apply_deltas` (round 4: (x, y) / (w, h) pairs, a third of the launches) against the oracle's column-by-column
+    restatement of detectron2's: identical bits, class-agnostic and per-class deltas, both weight sets of the detector."""
+    from coin_amd.box_ops import Box2BoxTransform
+    from oracle import d2
+
+    g = torch.Generator().manual_seed(0)
+    for w in ((1.0, 1.0, 1.0, 1.0), (10.0, 10.0, 5.0, 5.0)):
+        t, o = Box2BoxTransform(w), d2.Box2BoxTransform(w)
+        for k in (1, 9):
+            boxes = torch.rand(4000, 4, generator=g) * 500
+            boxes[:, 2:] += boxes[:, :2]
+            deltas = torch.randn(4000, 4 * k, generator=g) * 3          # incl. values beyond the scale clamp
+            assert torch.equal(t.apply_deltas(deltas, boxes), o.apply_deltas(deltas, boxes))
