@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // Block = 16 channels x 64 tile lanes (thread = channel c16 + 16 * tile lane): a thread folds tiles lane, lane + 64, ... (a serial
 // chain of ~tiles/64 dependent updates; the [401 408, 512] res5 outputs have 1568 tiles), then one thread per channel folds the 64
 // partial results in lane order.  N/16 workgroups (32..128) instead of N/64: the launch was latency-bound at 8 workgroups.
-// CPB = channels per workgroup (16 or 4), 1024 / CPB tile lanes; SF_U tiles per round.
+// CPB = channels per workgroup, 1024 / CPB tile lanes; SF_U tiles per round.
 template <int CPB, int SF_U>
 __global__ __launch_bounds__(1024) void conv_stats_finalize_kernel(const float* __restrict__ part, int tiles_m, int N, int64_t rows,
                                                                     float eps, float momentum, float* __restrict__ mean,
@@ -788,17 +788,11 @@ extern "C" int coin_conv_gemm_stats_finalize(const float* partials, int M, int N
                                              float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream) {
   if (!partials || !mean || !rstd || M <= 0 || N <= 0 || rows <= 0 || rows > M) return COIN_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return COIN_EINVAL;
-  static const int lab = [] { const char* e = getenv("COIN_STATS_FIN"); return e ? atoi(e) : 0; }();   // measurements only: 1 = 16 channels per workgroup, 2 = 4
+  // 8 channels x 128 tile lanes per workgroup, 8 tiles per round (tools/statsfin_bench.py, us per call incl. the wrapper's ~8 us floor:
+  // [401408, 512] 16.3, [100352, 2048] 11.4, [100352, 512] 8.3; 16 channels x 64 lanes: 24.6 / 14.9 / 14.4; 4 x 256: 20.5 / 20.9 / 8.4)
   const int tiles = (M + GM - 1) / GM;
-  // 4 channels x 256 tile lanes per workgroup up to N = 1024 (tools/statsfin_bench.py: 8.3 against 14.5 us at [100352, 512], 20.4 / 24.7 at
-  // [401408, 512], 8.0 / 11.9 at [16700, 1024]); 16 x 64 for N = 2048 (15.1 against 20.9 us)
-  const bool narrow = lab ? lab == 2 : N <= 1024;
-  if (narrow)
-    conv_stats_finalize_kernel<4, 8><<<(N + 3) / 4, 1024, 0, (hipStream_t)stream>>>(partials, tiles, N, rows, eps, momentum, mean, rstd, running_mean,
-                                                                                   running_var, num_batches_tracked);
-  else
-    conv_stats_finalize_kernel<16, 4><<<(N + 15) / 16, 1024, 0, (hipStream_t)stream>>>(partials, tiles, N, rows, eps, momentum, mean, rstd, running_mean,
-                                                                                     running_var, num_batches_tracked);
+  conv_stats_finalize_kernel<8, 8><<<(N + 7) / 8, 1024, 0, (hipStream_t)stream>>>(partials, tiles, N, rows, eps, momentum, mean, rstd, running_mean,
+                                                                                 running_var, num_batches_tracked);
   return coin_launch_status();
 }
 
