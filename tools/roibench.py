@@ -31,8 +31,12 @@ def main():
     for dt, name in ((torch.bfloat16, "bf16"), (torch.float32, "f32")):
         feat = torch.randn(n, h, w, c, device="cuda").to(dt)
         es = feat.element_size()
-        for tag, lo, hi in (("small_16_96", 16, 96), ("bench_32_400", 32, 400), ("large_300_800", 300, 800)):
-            rois = boxes(n, 512, lo, hi, g).cuda()
+        cases = [("small_16_96", 16, 96), ("bench_32_400", 32, 400), ("large_300_800", 300, 800)]
+        real = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--rois=")]
+        if real:   # the RoIs of a real bench step (tools/dump_rois.py)
+            cases.append(("real_step", real[0], None))
+        for tag, lo, hi in cases:
+            rois = (torch.load(lo) if hi is None else boxes(n, 512, lo, hi, g)).cuda()
             alg = feat.numel() * es + rois.numel() * 4 + r * 196 * c * es
             row = {}
             outs = []
