@@ -36,7 +36,8 @@ def main():
     g = torch.Generator().manual_seed(0)
     res = {}
     n, c, h, w, r = 4, 1024, 50, 83, 2048
-    rois = rois_like_bench(n, 512, g).cuda()
+    real = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--rois=")]   # e.g. profiles/r4_real_rois.pt (tools/dump_rois.py)
+    rois = (torch.load(real[0]) if real else rois_like_bench(n, 512, g)).cuda()
     for dt, name in ((torch.bfloat16, "bf16"), (torch.float32, "f32")):
         feat = torch.randn(n, h, w, c, device="cuda").to(dt)
         es = feat.element_size()
