@@ -39,7 +39,7 @@ FLOP_PER_VIEW = 4.259e12     # fwd 1449 + bwd 2811 GFLOP per 800
 # C-ABI entry point -> the device kernels one call launches (rocprofv3 lists these; their average durations add up to the
 # entry point's `mean_launch_ms`)
 ENTRY_KERNELS = {
-    "coin_roi_align_fwd": ["roi_align_fwd_nhwc_kernel"], "coin_roi_align_bwd": ["roi_align_bwd_gather_kernel"],
+    "coin_roi_align_fwd": ["roi_align_fwd_cols_kernel  (pooled widths 7 / 14; roi_align_fwd_nhwc_kernel for other bin counts)"], "coin_roi_align_bwd": ["roi_align_bwd_gather_kernel"],
     "coin_bn_stats": ["bn_stats_kernel", "bn_finalize_kernel"], "coin_bn_apply_fwd": ["bn_apply_kernel | bn_apply_mean_kernel"],
     "coin_bn_bwd": ["bn_bwd_reduce_kernel", "bn_bwd_finalize_kernel", "bn_bwd_dx_kernel"], "coin_gemm_nt": ["gemm_nt_bf16_kernel"],
     "coin_conv_gemm_bf16": ["conv_gemm_p8_kernel (+ conv_gemm_p8_slab_sum_kernel, conv_gemm_p8_tail_kernel where leftover tiles are cut along K) | "
@@ -52,19 +52,20 @@ MFMA_ENTRIES = ("coin_gemm_nt", "coin_conv_gemm_bf16", "coin_conv_wgrad_bf16")  
 
 
 def pmc_traffic(entry: str, alg_bytes: float):
-    """HBM bytes per launch from the committed PMC passes (profiles/r4_pmc_traffic.json, else older rounds': FETCH_SIZE x2 on gfx950 +
-    WRITE_SIZE, KB units, MI355X_MICROARCH.md) -- only when that pass measured this entry point at this launch size (for the MFMA
-    entry points: at this mean FLOP count per launch), else None."""
-    for name in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    """(HBM bytes per launch, the file it comes from) from the committed PMC passes (profiles/r5_pmc_traffic.json, else older rounds':
+    FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB units, MI355X_MICROARCH.md) -- only when that pass measured this entry point at this launch
+    size (for the MFMA entry points: at this mean FLOP count per launch), else (None, None).  rocprofv3 cannot attach to a running
+    process, so the figure is NOT measured by the run that prints the line: `roofline.traffic_source` names the file."""
+    for name in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 table = json.load(f)
             rec = table.get(entry)
             if rec and abs(rec["alg_bytes"] - alg_bytes) <= 0.01 * alg_bytes:
-                return rec["hbm_bytes"]
+                return rec["hbm_bytes"], "profiles/" + name
         except (OSError, ValueError, KeyError):
             pass
-    return None
+    return None, None
 
 
 def build_cfg(world: int, device: str, dtype: str, extra=()):
@@ -169,7 +170,9 @@ def run_cpu_baseline(timeout_s: int):
     stdout = ""
     try:
         try:
-            out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+            # the CPU leg chooses its own thread count by a probe: it must not inherit this rank's thread caps / core set
+            env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "COIN_RANK_CPUSET")}
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT, env=env)
             stdout = out.stdout
         except subprocess.TimeoutExpired as te:  # the multi-thread line is printed first: keep it if only the single-thread leg ran out of time
             stdout = te.stdout.decode() if isinstance(te.stdout, bytes) else (te.stdout or "")
@@ -189,11 +192,16 @@ def run_cpu_baseline(timeout_s: int):
         return {"value": None, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port", "sample": f"not measured: {type(e).__name__}: {e}"[:300]}
 
 
-def child_env(rank: int, world: int, port: int, base=None) -> dict:
+def child_env(rank: int, world: int, port: int, base=None, allowed=None, topology=None) -> dict:
     """Environment of rank `rank` of a self-launched run (what torch.distributed.run would set, rendezvous on 127.0.0.1)."""
     env = dict(os.environ if base is None else base)
     env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
                 "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    # host hygiene (coin_amd/hostenv.py): a disjoint NUMA-local core set per rank + OMP / MKL thread caps, decided by the launcher so that
+    # all ranks agree; the rank pins itself (apply_rank_affinity) before the HIP runtime starts.  No re-exec anywhere.
+    from coin_amd.hostenv import rank_env
+
+    env.update(rank_env(rank, world, base=env, allowed=allowed, topology=topology))
     return env
 
 
@@ -294,9 +302,13 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:   # no outer launcher: become the launcher (before anything touches the GPU)
         raise SystemExit(self_launch(args, sys.argv[1:]))
 
+    from coin_amd.hostenv import apply_rank_affinity, cap_torch_threads
+
+    affinity = apply_rank_affinity()   # before the HIP runtime starts; under torch.distributed.run (the driver's launcher) from LOCAL_RANK
     import torch
     import torch.distributed as dist
 
+    cap_torch_threads(affinity)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -328,25 +340,33 @@ def main():
     timed = ["coin_roi_align_fwd", "coin_roi_align_bwd", "coin_gemm_nt", "coin_bn_stats", "coin_bn_apply_fwd", "coin_bn_bwd",
              "coin_conv_gemm_bf16", "coin_conv_wgrad_bf16"]
     K.timing_begin(timed)
+    host_ms = []   # per step: wall time the host spent inside run_step (enqueue; close to ms_per_step = the rank is host-bound)
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == KERNEL_TIMING_STEPS:   # 460 events per step cost the host 1.3 ms per step, and tens of thousands of live events more
             K.timing_pause()           # (60 fully instrumented steps: 36 -> 49 ms/step, measured): the rest of the region runs bare
+        th = time.perf_counter()
         rec = trainer.run_step()
+        host_ms.append((time.perf_counter() - th) * 1e3)
     sync()
     dt = time.perf_counter() - t0
+    bare = sorted(host_ms[KERNEL_TIMING_STEPS:] or host_ms)
+    host_enqueue_ms = bare[len(bare) // 2]
     ktimes = K.timing_end()
     loss = float(sum(rec.values()))
-    per_rank = [[dt, loss]]
-    if world > 1:   # every rank's wall time and final loss: the line reports the slowest rank (value) and the spread (stragglers)
-        mine = torch.tensor([dt, loss], device="cuda", dtype=torch.float64)
+    per_rank = [[dt, loss, host_enqueue_ms]]
+    affinities = [affinity]
+    if world > 1:   # every rank's wall time, final loss and host enqueue time: the line reports the slowest rank (value) and the spread
+        mine = torch.tensor([dt, loss, host_enqueue_ms], device="cuda", dtype=torch.float64)
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        per_rank = [[float(a[0]), float(a[1])] for a in allr]
-        dt = max(t for t, _ in per_rank)
+        per_rank = [[float(a[0]), float(a[1]), float(a[2])] for a in allr]
+        dt = max(r[0] for r in per_rank)
+        affinities = [None] * world
+        dist.all_gather_object(affinities, affinity)
     views_per_step = IMAGES_PER_GPU * VIEWS_PER_IMAGE * world
     value = views_per_step * args.steps / dt
-    for r, (_t, lr_) in enumerate(per_rank):
+    for r, (_t, lr_, _h) in enumerate(per_rank):
         if not (lr_ == lr_ and abs(lr_) < 1e6):
             raise SystemExit(f"bench.py: the training loss of rank {r} is not finite ({lr_}) after {args.warmup + args.steps} steps: the run is invalid")
 
@@ -366,13 +386,15 @@ def main():
             name, (n, ms, units) = best
             if name in MFMA_ENTRIES:
                 ach = units / (ms * 1e-3) / 1e12
+                traffic, tsrc = pmc_traffic(name, units)
                 roofline = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(name, units), "alg_flop_per_launch": units,
+                            "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc, "alg_flop_per_launch": units,
                             "device_kernels": ENTRY_KERNELS.get(name)}
             else:
                 ach = units / (ms * 1e-3) / 1e9
+                traffic, tsrc = pmc_traffic(name, units)
                 roofline = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                            "frac": ach / HBM_PEAK_GBPS, "traffic": pmc_traffic(name, units), "alg_bytes_per_launch": units,
+                            "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": tsrc, "alg_bytes_per_launch": units,
                             "device_kernels": ENTRY_KERNELS.get(name)}
             roofline["launches_timed"] = n
             roofline["kernel_timing_steps"] = min(args.steps, KERNEL_TIMING_STEPS)
@@ -385,8 +407,12 @@ def main():
                                    "images x (strong+weak) = 4 views, real RPN + sampler, 512 RoIs/view, 8 classes, 32 cached teacher "
                                    "boxes/image, random-init weights, SGD",
                        "views_per_gpu_per_step": IMAGES_PER_GPU * VIEWS_PER_IMAGE, "parallelism": f"dp{world}", "final_loss": loss,
-                       "rank_ms_per_step": {"min": min(t for t, _ in per_rank) / args.steps * 1e3, "max": max(t for t, _ in per_rank) / args.steps * 1e3},
-                       "rank_final_loss": [l for _, l in per_rank],
+                       "rank_ms_per_step": {"min": min(r[0] for r in per_rank) / args.steps * 1e3, "max": max(r[0] for r in per_rank) / args.steps * 1e3},
+                       "rank_final_loss": [r[1] for r in per_rank],
+                       # median wall time per step the host spent enqueueing (run_step call to return, un-instrumented steps): a rank whose
+                       # figure is close to ms_per_step is host-bound, one well below it is device-bound
+                       "host_enqueue_ms": [round(r[2], 2) for r in per_rank],
+                       "rank_affinity": affinities,
                        "end_to_end_mfma_frac": value / world * FLOP_PER_VIEW / (MFMA_BF16_PEAK_TFLOPS * 1e12)},
             "roofline": roofline, "kernels": detail,
         }

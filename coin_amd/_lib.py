@@ -92,6 +92,8 @@ SIGNATURES = {
     "coin_ema_update": [_P, _I, _L, _F, _P],
 }
 
+ABI_VERSION = 2   # == COIN_ABI_VERSION of include/coin_hip.h (tests/test_abi.py); lib() refuses any other library
+
 _lib = None
 
 
@@ -141,6 +143,9 @@ def lib() -> ctypes.CDLL:
     l.coin_window_attn_bwd_workspace_bytes.argtypes = [c_int, c_int]
     l.coin_window_attn_bwd_workspace_bytes.restype = ctypes.c_size_t
     l.coin_abi_version.restype = c_int
+    if l.coin_abi_version() != ABI_VERSION:   # a stale build: ctypes would pass shifted arguments to changed prototypes
+        raise CoinHipError(f"{LIB_PATH} implements C-ABI version {l.coin_abi_version()}, this package binds version {ABI_VERSION}: "
+                           "rebuild it (`make -C coin_amd/csrc`)")
     l.coin_build_arch.restype = c_char_p
     _lib = l
     return l

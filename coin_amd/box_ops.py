@@ -99,8 +99,11 @@ class Box2BoxTransform:
         return torch.stack((wx * (tx - sx) / sw, wy * (ty - sy) / sh, ww * torch.log(tw / sw), wh * torch.log(th / sh)), dim=1)
 
     def apply_deltas(self, deltas: torch.Tensor, boxes: torch.Tensor) -> torch.Tensor:
-        """detectron2 Box2BoxTransform.apply_deltas on (x, y) / (w, h) pairs: the same arithmetic per element as the column-by-column
-        form (every multiplication by 0.5 is exact, the products and sums are separate roundings as before), a third of the launches."""
+        """detectron2 Box2BoxTransform.apply_deltas on (x, y) / (w, h) pairs, a third of the launches of the column-by-column form.
+        Every multiplication by 0.5 is exact and the products / sums are separate roundings as there.  The division by the box weights
+        is a TRUE division by a device tensor; detectron2's `deltas[:, 0::4] / wx` with a Python float is evaluated by torch as a
+        multiplication by the reciprocal on the GPU, so dx / dy / dw / dh may differ from it by one ulp for weights whose reciprocal is
+        inexact (10, 5) -- within the 1e-3 px the inference golden allows, not bit-identical (round-4 ADVICE)."""
         deltas = deltas.float()
         boxes = boxes.to(deltas.dtype)
         wh = boxes[:, 2:] - boxes[:, :2]                                   # [R, 2] (w, h)
@@ -115,7 +118,7 @@ class Box2BoxTransform:
     _wdev = None
 
     def _weights_on(self, device):
-        """(wx, wy, ww, wh) as a device tensor, built once per device from a pinned staging tensor (no blocking pageable copy per call)."""
+        """(wx, wy, ww, wh) as a device tensor, uploaded once per device (one blocking pageable copy on first use, none per call)."""
         if self._wdev is None:
             self._wdev = {}
         t = self._wdev.get(device)
@@ -195,6 +198,9 @@ def _sizes_on_device(image_sizes, device):
     return torch.tensor(image_sizes, dtype=torch.float32, device=device)
 
 
+NMS_MAX_CANDIDATES = 16384   # coin_nms_batched (include/coin_hip.h): boxes per image
+
+
 @functools.lru_cache(maxsize=64)
 def _clip_limits(image_sizes, device):
     return torch.tensor([[w, h, w, h] for h, w in image_sizes], dtype=torch.float32, device=device).view(len(image_sizes), 1, 4)
@@ -223,6 +229,9 @@ def find_top_rpn_proposals(proposals: torch.Tensor, logits: torch.Tensor, image_
             off += al
         # the candidates of all levels in ONE descending score order (ties: lower level first): the order NMS visits them in and the
         # order the final top-k is taken in
+        if sum(l.shape[1] for l in ls) > NMS_MAX_CANDIDATES:
+            raise ValueError(f"find_top_rpn_proposals: {sum(l.shape[1] for l in ls)} candidates over {len(ls)} levels exceed coin_nms_batched's "
+                             f"{NMS_MAX_CANDIDATES}; lower MODEL.RPN.PRE_NMS_TOPK_TRAIN / _TEST (it applies per level: detectron2's FPN configs use 2000 / 1000)")
         top_logits, order = torch.cat(ls, dim=1).sort(descending=True, dim=1, stable=True)
         boxes = torch.gather(torch.cat(bs, dim=1), 1, order.unsqueeze(-1).expand(-1, -1, 4))
         lvl = torch.gather(torch.cat(ids, dim=1), 1, order)

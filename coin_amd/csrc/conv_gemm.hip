@@ -675,7 +675,11 @@ __global__ __launch_bounds__(1024) void conv_stats_finalize_kernel(const float* 
 
 }  // namespace
 
-int coin_conv_gemm_force_impl = 0;  // lab hook (tools/gemm_lab.hip): 0 = environment / default, 1 = p8, 2 = sq, 3 = rect
+#ifdef COIN_LAB
+int coin_conv_gemm_force_impl = 0;  // lab hook (tools/gemm_lab.hip): 0 = default, 1 = p8, 2 = sq, 3 = rect
+#else
+static constexpr int coin_conv_gemm_force_impl = 0;   // the product library has no implementation switch
+#endif
 
 extern "C" size_t coin_conv_gemm_stats_bytes(int M, int N) {
   if (M <= 0 || N <= 0) return 0;
@@ -733,13 +737,8 @@ extern "C" int coin_conv_gemm_bf16_ws(const void* A, int lda, int mode, int H, i
   const bf16_t* a = (const bf16_t*)A;
   const bf16_t* b = (const bf16_t*)B;
   bf16_t* c = (bf16_t*)C;
-  // COIN_CONV_GEMM_IMPL (measurements only): "p8" / unset = the persistent 8-phase core where the shape fits it, "sq" = the 256x256x32
-  // kernel of round 2, "rect" = the 256x128x64 kernel
-  static const int env_impl = [] {
-    const char* e = getenv("COIN_CONV_GEMM_IMPL");
-    return !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 'r' ? 2 : 0));
-  }();
-  const int impl = coin_conv_gemm_force_impl ? coin_conv_gemm_force_impl - 1 : env_impl;
+  // the persistent 8-phase core where the shape fits it; lab builds can force "sq" (the 256x256x32 kernel of round 2) / "rect" (256x128x64)
+  const int impl = coin_conv_gemm_force_impl ? coin_conv_gemm_force_impl - 1 : 0;
   if (impl == 0 && coin_p8_nt_ok(M, N, K, mode, Cin, lda, ldb))
     return coin_p8_nt_launch(A, lda, mode, H, W, Cin, B, ldb, C, ldc, R, ldr, M, N, K, stats, (long long)stats_rows,
                              ((uintptr_t)workspace & 15) ? nullptr : workspace, workspace_bytes, st);
@@ -816,8 +815,7 @@ extern "C" int coin_conv_wgrad_bf16(const void* GY, const void* X, int mode, int
   if (Cout % WB || Cin % WB) return COIN_ESHAPE;
   if (mode == 0 ? Ktot != Cin : (Ktot != 9 * Cin || H <= 0 || W <= 0 || M % (H * W))) return COIN_EINVAL;
   if (((uintptr_t)GY & 15) || ((uintptr_t)X & 15) || ((uintptr_t)dW & 15) || ((uintptr_t)workspace & 15)) return COIN_EALIGN;
-  static const int env_old = [] { const char* e = getenv("COIN_CONV_WGRAD_IMPL"); return e && e[0] == 's' ? 1 : 0; }();  // measurements only
-  const bool use_old = coin_conv_gemm_force_impl ? coin_conv_gemm_force_impl != 1 : env_old != 0;
+  const bool use_old = coin_conv_gemm_force_impl ? coin_conv_gemm_force_impl != 1 : false;   // lab builds only
   if (!use_old && coin_p8_tn_ok(M, Cout, Cin, Ktot, mode))
     return coin_p8_tn_launch(GY, X, mode, H, W, Cin, M, Cout, Ktot, dW, workspace, (hipStream_t)stream);
   const int tco = Cout / WB, tk = Ktot / WB;

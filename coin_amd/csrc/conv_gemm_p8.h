@@ -13,8 +13,10 @@ COIN_HIDDEN bool coin_p8_tn_ok(int M, int Cout, int Cin, int Ktot, int mode);
 COIN_HIDDEN size_t coin_p8_tn_workspace_bytes(int M, int Cout, int Ktot);
 COIN_HIDDEN int coin_p8_tn_launch(const void* GY, const void* X, int mode, int H, int W, int Cin, int M, int Cout, int Ktot, float* dW, void* workspace,
                                   hipStream_t st);
+#ifdef COIN_LAB   // development switches of tools/gemm_lab: not part of the product library (built without -DCOIN_LAB)
 COIN_HIDDEN extern int coin_conv_gemm_force_impl;
 COIN_HIDDEN extern int coin_p8_debug;
 COIN_HIDDEN int coin_p8_read_stamps(long long* out, int n);
 COIN_HIDDEN extern int coin_p8_splitk;
 COIN_HIDDEN extern int coin_p8_stagger;
+#endif

@@ -26,8 +26,15 @@
 #include "common.h"
 #include "conv_gemm_p8.h"
 
-// lab only (coin_p8_debug bit 6): per workgroup [sum of main-loop cycles, sum of epilogue cycles, tiles]
+// Lab switches (tools/gemm_lab: zero-page DMA, epilogue off, s_memtime stamps, split-K / stagger overrides) exist only in objects
+// compiled with -DCOIN_LAB (tools/build_lab.sh); in the product library every P8_DBG() below is the constant 0 and no switch is linked.
+#ifdef COIN_LAB
+#define P8_DBG(p, bits) ((p).dbg & (bits))
+// (coin_p8_debug bit 6): per workgroup [sum of main-loop cycles, sum of epilogue cycles, tiles]
 __device__ long long coin_p8_stamp_buf[1024 * 4];
+#else
+#define P8_DBG(p, bits) 0
+#endif
 
 namespace {
 
@@ -170,13 +177,13 @@ __device__ __forceinline__ void nt_stage(const NtCursor<GATHER3>& c, const P8Arg
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         unsigned off = ((c.taps[H * 2 + e] >> tap) & 1u) ? c.a[H * 2 + e] + (unsigned)shift : P8_OOB;
-        if (p.dbg & 1) off = P8_OOB;
+        if (P8_DBG(p, 1)) off = P8_OOB;
         blds16(p.A, p.a_bytes, off, 0, dst + e * 1024);
       }
     } else {
 #pragma unroll
       for (int e = 0; e < 2; ++e)
-        blds16(p.A, p.a_bytes, (p.dbg & 1) ? P8_OOB : c.a[H * 2 + e], c.kt * (PK * 2), dst + e * 1024);
+        blds16(p.A, p.a_bytes, (P8_DBG(p, 1)) ? P8_OOB : c.a[H * 2 + e], c.kt * (PK * 2), dst + e * 1024);
     }
   } else {
     int koff = c.kt * PK;
@@ -186,7 +193,7 @@ __device__ __forceinline__ void nt_stage(const NtCursor<GATHER3>& c, const P8Arg
     }
 #pragma unroll
     for (int e = 0; e < 2; ++e)
-      blds16(p.B, p.b_bytes, (p.dbg & 1) ? P8_OOB : c.b[H * 2 + e], koff * 2, dst + e * 1024);
+      blds16(p.B, p.b_bytes, (P8_DBG(p, 1)) ? P8_OOB : c.b[H * 2 + e], koff * 2, dst + e * 1024);
   }
 }
 
@@ -231,7 +238,7 @@ __device__ __forceinline__ void p8_epilogue(const P8Args& p, f32x4 (&acc)[2][2][
   const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
   const int m0 = tm * PM, n0 = tn * PN;
   const int chunk = threadIdx.x & 15, rsub = threadIdx.x >> 4;
-  if (p.dbg & 4) return;  // lab only: main loop without the epilogue
+  if (P8_DBG(p, 4)) return;  // lab only: main loop without the epilogue
 #pragma unroll
   for (int bh = 0; bh < 2; ++bh) {
     // statistics in pairs of channels: v_pk_add_f32 / v_pk_fma_f32 (a wave64 vector instruction holds its SIMD for 4 cycles; the
@@ -272,9 +279,15 @@ __device__ __forceinline__ void p8_epilogue(const P8Args& p, f32x4 (&acc)[2][2][
           grow = grow < p.M ? grow : p.M - 1;
           size_t rrow = (size_t)grow;
           if (p.rp_w) {   // wave-uniform: pooled residual
-            const int n = (int)__umulhi((unsigned)grow, p.rp_magic_hw);
+            // magic = ceil(2^32 / d): umulhi(x, magic) is floor(x / d) or one more (the excess x * (magic * d - 2^32) / (d * 2^32) is
+            // below 1 for every 32-bit x) -- the fix-up makes both quotients exact for every map size (round-4 ADVICE: without it
+            // [2, 200, 336] maps lost the last pixel of an image)
+            int n = (int)__umulhi((unsigned)grow, p.rp_magic_hw);
+            n -= (unsigned)n * (unsigned)(p.rp_h * p.rp_w) > (unsigned)grow ? 1 : 0;
             const int rem = grow - n * (p.rp_h * p.rp_w);
-            const int h = (int)__umulhi((unsigned)rem, p.rp_magic_w), w = rem - h * p.rp_w;
+            int h = (int)__umulhi((unsigned)rem, p.rp_magic_w);
+            h -= h * p.rp_w > rem ? 1 : 0;
+            const int w = rem - h * p.rp_w;
             const int oh = h >> 1, ow = w >> 1, OH = p.rp_h >> 1, OW = p.rp_w >> 1;
             rscale[q] = (oh < OH && ow < OW) ? 0.25f : 0.f;
             rrow = ((size_t)n * OH + (oh < OH ? oh : OH - 1)) * OW + (ow < OW ? ow : OW - 1);
@@ -306,10 +319,10 @@ __device__ __forceinline__ void p8_epilogue(const P8Args& p, f32x4 (&acc)[2][2][
       for (int q = 0; q < 4; ++q) {
         const int grow = m0 + ah * 128 + q * 32 + rsub;
         if (grow < p.M) {
-          if (p.dbg & 16) __builtin_nontemporal_store(v[q], reinterpret_cast<bf16x8*>(p.C + (size_t)grow * p.ldc + gcol));
+          if (P8_DBG(p, 16)) __builtin_nontemporal_store(v[q], reinterpret_cast<bf16x8*>(p.C + (size_t)grow * p.ldc + gcol));
           else *reinterpret_cast<bf16x8*>(p.C + (size_t)grow * p.ldc + gcol) = v[q];
         }
-        if (STATS && (long long)grow < p.stats_rows && !(p.dbg & 256)) {
+        if (STATS && (long long)grow < p.stats_rows && !(P8_DBG(p, 256))) {
           f32x2 f[4];
           p8_pairs(v[q], f);
 #pragma unroll
@@ -322,7 +335,7 @@ __device__ __forceinline__ void p8_epilogue(const P8Args& p, f32x4 (&acc)[2][2][
       }
       P8_LDS_SYNC();
     }
-    if (STATS && !(p.dbg & 512)) {
+    if (STATS && !(P8_DBG(p, 512))) {
       // threads with equal `chunk`: lanes l, l ^ 16, l ^ 32 of a wave, then the 8 waves through the (free) image, fixed order
       // lanes l, l ^ 32, then l ^ 16, with v_permlane32_swap / v_permlane16_swap (vector ALU).  As 64 `ds_bpermute`s per wave and
       // tile these sums cost ~4 000 cycles of the CU's LDS crossbar per tile (lab stamps: statistics epilogue 14 800 cycles against
@@ -436,7 +449,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(const P8Args p) {
 
   int g = 0;  // K-tile sequence number of this workgroup (buffer g & 1)
   long long st_main = 0, st_epi = 0, st_n = 0, st_t = 0;   // lab only (dbg bit 6): s_memtime split of a tile into main loop / epilogue
-  if (p.dbg & 64) st_t = __builtin_amdgcn_s_memtime();
+  if (P8_DBG(p, 64)) st_t = __builtin_amdgcn_s_memtime();
   for (;;) {
     f32x4 acc[2][2][4][2];
 #pragma unroll
@@ -561,7 +574,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(const P8Args p) {
       P8_SCHED();
     }
     if (wr == 0) P8_BAR();  // both groups aligned again
-    if (p.dbg & 64) {
+    if (P8_DBG(p, 64)) {
       const long long t = __builtin_amdgcn_s_memtime();
       st_main += t - st_t;
       st_t = t;
@@ -569,8 +582,8 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(const P8Args p) {
 
     if (items.whole(item_idx)) {
       p8_epilogue<STATS>(p, acc, items.tile(item_idx), lds + P_IMG, lane, wave);
-      if (p.dbg & 64) {
-        if (p.dbg & 128) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // bit 7: the stores' drain is charged to the epilogue
+      if (P8_DBG(p, 64)) {
+        if (P8_DBG(p, 128)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // bit 7: the stores' drain is charged to the epilogue
         const long long t = __builtin_amdgcn_s_memtime();
         st_epi += t - st_t;
         st_t = t;
@@ -592,11 +605,13 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(const P8Args p) {
     }
     if (++item_idx >= items.n_items) break;
   }
-  if ((p.dbg & 64) && threadIdx.x == 0 && blockIdx.x < 1024) {
+#ifdef COIN_LAB
+  if ((P8_DBG(p, 64)) && threadIdx.x == 0 && blockIdx.x < 1024) {
     coin_p8_stamp_buf[blockIdx.x * 4 + 0] = st_main;
     coin_p8_stamp_buf[blockIdx.x * 4 + 1] = st_epi;
     coin_p8_stamp_buf[blockIdx.x * 4 + 2] = st_n;
   }
+#endif
 }
 
 // Split-K tail, pass 1: slab[tile][0] += slab[tile][1] + ... (piece order: bit-reproducible), every CU busy: grid = rem * 32 workgroups
@@ -740,7 +755,7 @@ __device__ __forceinline__ void tn_stage(const TnCursor<GATHER3>& c, const TnArg
       }
       off = tn_tap_ok(r, c.dy, c.dx, p) ? off : TN_OOB;
     }
-    if (p.dbg & 1) off = TN_OOB;
+    if (P8_DBG(p, 1)) off = TN_OOB;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(IS_G ? rg : rx, (__attribute__((address_space(3))) void*)(dst + e * 1024), 16, off, 0, 0, 0);
   }
 }
@@ -938,7 +953,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const TnArgs p) {
     // ------------------------------------------------ end of an item: partial tile -> slab
     if (--left_c == 0) {
       float* __restrict__ out = p.slab + ((size_t)item_c * gridDim.x + blockIdx.x) * 65536;
-      if (!(p.dbg & 2))
+      if (!(P8_DBG(p, 2)))
 #pragma unroll
       for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -1008,10 +1023,14 @@ static int p8_grid(int ntiles) {
   return ntiles < cus ? ntiles : cus;
 }
 
+#ifdef COIN_LAB
 int coin_p8_debug = 0;  // lab hook, see TnArgs::dbg
 int coin_p8_read_stamps(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(coin_p8_stamp_buf), sizeof(long long) * 4 * (size_t)n); }
 int coin_p8_stagger = -1;  // lab hook: phases of the start-time stagger (-1: default, 0/1: off)
 int coin_p8_splitk = -1;  // lab hook: -1 = default policy, 0 = never split the tail round, 1 = split whenever it is possible
+#else
+static constexpr int coin_p8_debug = 0, coin_p8_stagger = -1, coin_p8_splitk = -1;
+#endif
 
 bool coin_p8_nt_ok(int M, int N, int K, int mode, int Cin, int lda, int ldb) {
   if (M <= 0 || N % PN || K % PK || K < 2 * PK) return false;
@@ -1062,15 +1081,13 @@ int coin_p8_nt_launch(const void* A, int lda, int mode, int H, int W, int Cin, c
   const int ntiles = a.tiles_m * a.tiles_n;
   const int cus = p8_grid(1 << 30);
   int grid = ntiles < cus ? ntiles : cus;
-  static const int env_split = [] { const char* e = getenv("COIN_CONV_GEMM_SPLITK"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();  // measurements only
-  const int force = coin_p8_splitk >= 0 ? coin_p8_splitk : env_split;
+  const int force = coin_p8_splitk;   // -1 = the default policy (lab builds can override it)
   p8_nt_plan(ntiles, K / PK, cus, workspace != nullptr, force, a.whole_tiles, a.rem, a.split);
   if ((size_t)a.rem * a.split * 65536 * sizeof(float) > workspace_bytes) { a.whole_tiles = ntiles; a.rem = 0; a.split = 1; }
   if (a.split > 1 && a.whole_tiles == 0) grid = a.rem * a.split;   // fewer tiles than CUs: only pieces (<= cus of them)
   a.slab = (float*)workspace;
   {
-    static const int env_st = [] { const char* e = getenv("COIN_CONV_GEMM_STAGGER"); return e ? atoi(e) : -1; }();  // measurements only
-    const int phases = coin_p8_stagger >= 0 ? coin_p8_stagger : (env_st >= 0 ? env_st : 0);   // off: no effect measured (lab13)
+    const int phases = coin_p8_stagger >= 0 ? coin_p8_stagger : 0;   // off: no effect measured (lab13)
     const int r = ntiles % grid;
     if (phases > 1 && a.split == 1 && ntiles > grid && r != 0) {
       const int tile_ticks = (K / PK) * 150 + 300;   // 10 ns ticks: ~1.5 us per K-tile of 64 at ~1 PFLOP/s + the epilogue

@@ -20,6 +20,13 @@
 #include <stdlib.h>
 #include "common.h"
 
+// lab-only predicates (tools/roibench.py: kernel without its loads / stores) compile to `false` unless built with -DCOIN_LAB
+#ifdef COIN_LAB
+#define ROI_LAB(x) (x)
+#else
+#define ROI_LAB(x) false
+#endif
+
 namespace {
 
 struct RoiGeom {
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_cols_kernel(
   for (int p = 0; p < PG; ++p)
 #pragma unroll
     for (int k = 0; k < VEC / 2; ++k) acc[p][k] = f32x2{0.f, 0.f};
-  if (g.gh > 0 && g.gw > 0 && !(variant & 4)) {
+  if (g.gh > 0 && g.gw > 0 && !ROI_LAB(variant & 4)) {
     // footprint of this output row (rows) and of this wave's 7 bins (columns); a superset is harmless (weights of untouched lines are 0)
     const float xstep = g.bw / (float)g.gw, ystep = g.bh / (float)g.gh;
     const float ya = g.y0 + (float)py * g.bh + 0.5f * ystep, yb = g.y0 + (float)py * g.bh + ((float)g.gh - 0.5f) * ystep;
@@ -376,7 +383,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_cols_kernel(
       }
     }
   }
-  if (cg < ncg && !((variant & 8) && acc[0][0].x != 12345.f)) {
+  if (cg < ncg && !ROI_LAB((variant & 8) && acc[0][0].x != 12345.f)) {
     T* __restrict__ orow = out + (((size_t)roi * ph + py) * pw + px0) * C + (size_t)cg * VEC;
 #pragma unroll
     for (int p = 0; p < PG; ++p) {
@@ -809,7 +816,11 @@ int check_common(const void* a, const void* rois, const void* b, int N, int C, i
 #ifndef BF16_SW
 #define BF16_SW 3
 #endif
+#ifdef COIN_LAB
 int g_roi_fwd_variant = 0;   // lab hook (tools/roibench.py): bit 0 = per-sample kernel for every shape; bits 2 / 3 = column-walk kernel without its loads / stores
+#else
+static constexpr int g_roi_fwd_variant = 0;   // the product library has no variant switch (ROI_LAB() is the constant false)
+#endif
 
 template <bool ML>
 static bool launch_fwd_cols(const void* feat, const float* rois, void* out, int C, int H, int W, int R, int ph, int pw, float scale,
@@ -830,7 +841,9 @@ static bool launch_fwd_cols(const void* feat, const float* rois, void* out, int 
   return true;
 }
 
+#ifdef COIN_LAB
 extern "C" void coin_roi_align_lab_variant(int v) { g_roi_fwd_variant = v; }
+#endif
 
 extern "C" int coin_roi_align_fwd(const void* feat, int N, int C, int H, int W, int layout, const float* rois,
                                   int R, int ph, int pw, float spatial_scale, int sampling_ratio, int aligned,

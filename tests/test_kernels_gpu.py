@@ -323,6 +323,26 @@ def test_bottleneck_gradient_fan_in_fused_in_dgrad_epilogue(monkeypatch, inplane
     torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-2, atol=1e-2 * float(res[1][2].abs().max()))
 
 
+@pytest.mark.parametrize("nhw", [(2, 200, 336), (16, 200, 334), (8, 160, 160), (3, 15, 15)])
+def test_pooled_residual_epilogue_on_large_maps_equals_the_materialised_pool_gradient(nhw):
+    """coin_conv_gemm_bf16_rpool splits an output row into (image, h, w) with multiply-high divisions; round-4 ADVICE: without a fix-up the
+    quotient is one too large from row 134 399 of a [2, 200, 336] map on (the pooled quarter of the last pixel of an image was lost and the
+    next image's row was read).  Same bits as the plain GEMM with the materialised avg-pool gradient as its residual."""
+    from coin_amd import kernels as K
+
+    n, h, w = nhw
+    m, nn, k = n * h * w, 256, 128
+    g = torch.Generator(device="cuda").manual_seed(11)
+    a = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
+    b = (torch.randn(nn, k, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    r = torch.randn(n, h // 2, w // 2, nn, device="cuda", generator=g).to(torch.bfloat16)
+    full = K.avgpool2_bwd(r, (n, h, w, nn)).reshape(m, nn)
+    want, _ = K.conv_gemm(a, b, residual=full)
+    got = K.conv_gemm(a, b, residual=r.reshape(-1, nn), residual_pool=(h, w))
+    assert got is not None, "the persistent kernel must serve this shape"
+    assert torch.equal(got[0], want), float((got[0].float() - want.float()).abs().max())
+
+
 @pytest.mark.parametrize("shape", [(2, 256, 40, 56, 256), (4, 1024, 50, 83, 1024)])   # small; the RPN head at the timed shape
 def test_rpn_head_conv_bias_relu_on_the_gemm_path_vs_fp64(monkeypatch, shape):
     """relu(conv3x3(x) + bias) of the RPN head (StandardRPNHead, called at rpn.py:65) on coin_conv_gemm_bf16 + the streaming bias/clamp pass

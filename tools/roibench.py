@@ -26,6 +26,8 @@ def boxes(n_img, per_img, lo, hi, g):
 def main():
     g = torch.Generator().manual_seed(0)
     n, c, h, w, r = 4, 1024, 50, 83, 2048
+    # the variant hook exists only in the lab build of the library (tools/build_lab.sh -> tools/lab/libcoin_hip_lab.so)
+    _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab", "libcoin_hip_lab.so")
     lab = _lib.lib().coin_roi_align_lab_variant
     res = {}
     for dt, name in ((torch.bfloat16, "bf16"), (torch.float32, "f32")):

@@ -46,8 +46,13 @@ def setup(args):
 
 
 def main(args):
+    from coin_amd.hostenv import apply_rank_affinity, cap_torch_threads
+
+    affinity = apply_rank_affinity()   # a disjoint, NUMA-local core set + thread caps per rank, before the HIP runtime starts
     import torch
     import torch.distributed as dist
+
+    cap_torch_threads(affinity)
 
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
