@@ -276,6 +276,7 @@ def run_secondary_targetdet(steps: int = 24, warmup: int = 8, images: int = 3):
                 "unit": "images/sec", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": dt * 1e3, "median_group_ms_per_step": sorted(groups)[len(groups) // 2],
                 "fastest_group_ms_per_step": min(groups), "groups_ms_per_step_in_order": [round(g, 1) for g in groups],   # host-bound: a busy host shows as unequal groups
                 "images_per_step": images, "dtype": "bf16", "data": "synthetic", "final_loss": loss, "finite": loss == loss and abs(loss) < 1e6,
+                "step_graphs": dict(__import__("coin_amd.graphs", fromlist=["STATS"]).STATS),
                 "config": {"workload": "BASELINE configs[2]: CoinTrainer.run_step + prepare_next, CLIP-RN50 C4/res5 student and EMA teacher (frozen in step_one), "
                                        "3 synthetic Foggy-Cityscapes-shaped images per step, 1000 teacher RoIs + 512 student RoIs per image, 8 classes"}}
     except Exception as e:  # the headline stands on its own: report, do not fail the line
@@ -321,6 +322,7 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    from coin_amd import graphs as G
     from coin_amd import kernels as K
     from coin_amd.engine import PRETrainer
 
@@ -413,6 +415,8 @@ def main():
                        # figure is close to ms_per_step is host-bound, one well below it is device-bound
                        "host_enqueue_ms": [round(r[2], 2) for r in per_rank],
                        "rank_affinity": affinities,
+                       # coin_amd/graphs.py: captured (shape, segment) pairs, graph replays / eager calls of the two graphed stretches so far
+                       "step_graphs": dict(G.STATS, enabled=G.ENABLED["on"]),
                        "end_to_end_mfma_frac": value / world * FLOP_PER_VIEW / (MFMA_BF16_PEAK_TFLOPS * 1e12)},
             "roofline": roofline, "kernels": detail,
         }

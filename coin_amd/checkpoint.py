@@ -16,8 +16,12 @@
    "ap_50_student", "ap_50_offline_teacher", "online_results"}; pre-train checkpoints hold the bare detector under "model"
    (pre_train.py:138-146) and model-zoo files are a bare state dict (trainer.py:229-231).
 
-PARITY UNPINNED: the container has neither detectron2 nor a real COIN artefact, so these readers / writers are checked only
-against files written here under the reference's class paths (tests/test_host_cpu.py).
+Pinned (round 5) against artefacts written by the reference's OWN save code -- `PRETrainer.save` / `collect_results`, `CoinTrainer.save` over
+`EnsembleTSModel` + `DetectionTSCheckpointer`, with `MyInstances` and detectron2-path containers inside -- committed under
+tests/golden/ckpt/ (generator: tests/golden/gen_golden.py::case_checkpoint_formats; readers: tests/test_checkpoint_formats.py), and in the
+other direction by the reference's `resume_or_load` reading what this module writes (tests/golden/live_checkpoint_roundtrip.py, run by
+tests/test_reference_live.py where the reference checkout exists).  fvcore's `Checkpointer` / detectron2's `DetectionCheckpointer` are not
+installed here: they are restated from their published behaviour as scaffolding in tests/golden/_ref_shim.py.
 """
 from __future__ import annotations
 
@@ -29,7 +33,7 @@ from typing import Any, Callable, Dict, Optional
 
 import torch
 
-from .structures import Boxes, Instances
+from .structures import Boxes, Instances, MyInstances
 
 # reference-side class path -> our class (both are plain attribute bags with the same attribute names)
 _CLASS_MAP = {
@@ -37,7 +41,7 @@ _CLASS_MAP = {
     ("detectron2.structures", "Instances"): Instances,
     ("detectron2.structures.boxes", "Boxes"): Boxes,
     ("detectron2.structures", "Boxes"): Boxes,
-    ("coin.utils.util", "MyInstances"): Instances,
+    ("coin.utils.util", "MyInstances"): MyInstances,
 }
 
 
@@ -65,19 +69,24 @@ def load_file(path: str, map_location="cpu") -> Any:
     return torch.load(path, map_location=map_location, pickle_module=_PickleModule, weights_only=False)
 
 
+_MISSING = object()
+
+
 class _as_detectron2:
     """While active, our Instances / Boxes pickle under detectron2's class paths (what the reference's torch.load expects)."""
 
-    _PATHS = ((Instances, "detectron2.structures.instances", "Instances"), (Boxes, "detectron2.structures.boxes", "Boxes"))
+    _PATHS = ((Instances, "detectron2.structures.instances", "Instances"), (Boxes, "detectron2.structures.boxes", "Boxes"),
+              (MyInstances, "coin.utils.util", "MyInstances"))
 
     def __enter__(self):
-        self._saved_mods, self._saved_names = {}, []
+        self._saved_mods, self._saved_names, self._saved_attrs = {}, [], []
         for cls, mod, name in self._PATHS:
             for m in (mod.rpartition(".")[0].rpartition(".")[0], mod.rpartition(".")[0], mod):
                 if m and m not in sys.modules:
                     self._saved_mods[m] = None
                     sys.modules[m] = types.ModuleType(m)
             self._saved_names.append((cls, cls.__module__, cls.__qualname__, cls.__name__))
+            self._saved_attrs.append((sys.modules[mod], name, sys.modules[mod].__dict__.get(name, _MISSING)))   # a real module may be loaded
             setattr(sys.modules[mod], name, cls)
             cls.__module__, cls.__qualname__, cls.__name__ = mod, name, name
         return self
@@ -85,6 +94,11 @@ class _as_detectron2:
     def __exit__(self, *a):
         for cls, mod, qual, name in self._saved_names:
             cls.__module__, cls.__qualname__, cls.__name__ = mod, qual, name
+        for module, name, old in self._saved_attrs:
+            if old is _MISSING:
+                module.__dict__.pop(name, None)
+            else:
+                setattr(module, name, old)
         for m in self._saved_mods:
             sys.modules.pop(m, None)
         return False
@@ -144,7 +158,7 @@ class CloudResults:
 
 
 def _copy_instances(inst: Instances, device) -> Instances:
-    new = Instances(inst.image_size)
+    new = type(inst)(inst.image_size)
     for k, v in inst.get_fields().items():
         new.set(k, Boxes(v.tensor.clone().to(device)) if isinstance(v, Boxes) else (v.clone().to(device) if torch.is_tensor(v) else v),
                 check_len=False)

@@ -371,6 +371,7 @@ def add_config(cfg: CfgNode) -> None:
     _C.AMD.SYNC_FREE = True            # pre_train step without host<->device round trips (random-key sampling)
     _C.AMD.SYNC_FREE_STEP = True       # the same for the step_one / step_two branches of CoinTrainer (losses pinned to the goldens on CPU and GPU; measured faster and steadier: DESIGN.md section 7)
     _C.AMD.TEXT_GRAPH = True           # prompt-conditioned text transformer: forward + backward replayed from two captured HIP graphs
+    _C.AMD.STEP_GRAPHS = True          # training forward + backward of the backbone's trainable stages and of RoIAlign -> res5 replayed as HIP graphs per shape (coin_amd/graphs.py)
     _C.AMD.TEACHER_GRAPH = True        # CoinTrainer: EMA-due iterations replay the teacher's fixed-shape inference half as one HIP graph (default stream)
     _C.AMD.TEACHER_PREFETCH = True     # CoinTrainer: while the teacher is frozen (no EMA due), enqueue the next iteration's teacher pass ahead of this step
     _C.AMD.TEACHER_STREAM = True       # CoinTrainer: teacher EMA / inference / detection read-back on their own HIP stream

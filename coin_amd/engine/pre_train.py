@@ -17,6 +17,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.distributed as dist
 
+from .. import graphs
 from ..data import SyntheticTwoViewLoader
 from ..modeling import build_model
 from ..solver import build_lr_scheduler, build_optimizer
@@ -99,6 +100,7 @@ class PRETrainer(BASE_Trainer):
         losses.backward()   # with a reducer: 32 MiB gradient slices are all-reduced over RCCL while backward is still running
         self.optimizer.step(inv_loss_scale=self.reducer.finalize() if self.reducer is not None else 1.0)
         self.scheduler.step()
+        graphs.step_done()
         self.last_losses = record
         self.iter += 1
         return record

@@ -25,6 +25,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.distributed as dist
 
+from .. import graphs
 from .. import kernels as K
 from ..data import SyntheticTwoViewLoader
 from ..modeling import build_model
@@ -284,6 +285,7 @@ class CoinTrainer(BASE_Trainer):
         self.optimizer.step(inv_loss_scale=self.reducer.finalize() if self.reducer is not None else 1.0)
         self.scheduler.step()
         self.scheduler_merge.step()
+        graphs.step_done()
         self.last_losses = record
         if self.iter >= burn:  # trainer.py:150-157 (after_step): fused A boxes from the next step on
             self.WEIGHT_FOR_BOX_A = 0.5

@@ -1,0 +1,198 @@
+"""HIP-graph capture of the fixed-shape stretches of a training step (forward AND backward).
+
+The student's step (coin/engine/trainer.py:160-218, pre_train.py:178-211) enqueues ~1 400 kernels; about half of them belong to two
+stretches whose launch sequence depends on tensor SHAPES only, never on the targets of the batch:
+
+* the trainable stages of the backbone (frozen-stage output -> res4), and
+* the RoI trunk (res4 + sampled RoIs -> RoIAlign -> res5 -> pooled features).
+
+Everything in between (RPN head, proposal selection, NMS, the samplers, the losses) depends on per-image target counts that are host
+integers and stays eager.  A ``GraphedSegment`` wraps one stretch: the first calls of a shape run eagerly (library solver searches,
+workspace growth), then the forward is captured as one HIP graph and -- through ``torch.autograd.grad`` under capture, as
+``torch.cuda.make_graphed_callables`` does -- its backward as a second one sharing the memory pool.  A call then costs the host three
+launches (copy-in, replay) instead of hundreds, and autograd sees ONE node whose backward replays the second graph.
+
+Rules the capture keeps (each one is there because its absence produced a wrong result or a failed capture):
+* graphs are replayed on the device's default stream only (a graph launched from a side stream serialised the whole step on this
+  runtime); any other stream, an active capture, or live kernel-timing events -> the eager path;
+* a segment between its forward and its backward is BUSY: a second call of the same shape in that window (step_one / step_two pool
+  twice per forward) runs eagerly, it would overwrite the activations the pending backward reads;
+* the data-gradient weight layouts (layers.dgrad_weight) are refreshed eagerly BEFORE a backward capture / replay: captured, the
+  refresh would not execute while the host-side stamp says it did;
+* BatchNorm running statistics and `num_batches_tracked` are updated by kernels inside the graph: replays update them in place;
+* parameter gradients: the backward graph writes them into static buffers.  Without gradient hooks on a parameter (single GPU) the
+  static buffer itself becomes ``p.grad`` (stable pointers: the optimizer's device table is uploaded once); with hooks (the
+  data-parallel reducer) they are returned to autograd, which accumulates and fires the hooks as usual.
+
+``cfg.AMD.STEP_GRAPHS`` (default on) / ``COIN_STEP_GRAPHS=0`` switch the mechanism; a failed capture warns once and leaves the segment
+eager for good (same kernels either way).
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import kernels as K
+from . import layers as L
+
+ENABLED = {"on": os.environ.get("COIN_STEP_GRAPHS", "1") != "0"}
+WARM_CALLS = 2          # eager calls of a shape before it is captured
+MAX_GRAPHS = 3          # shapes per segment (real data: a few padded sizes); further shapes stay eager
+STATS = {"captures": 0, "replays": 0, "eager": 0, "busy": 0}
+
+
+_SEGMENTS: "List[GraphedSegment]" = []
+
+
+def set_enabled(flag: bool) -> None:
+    ENABLED["on"] = bool(flag) and os.environ.get("COIN_STEP_GRAPHS", "1") != "0"
+
+
+def step_done() -> None:
+    """End of an optimizer step: no backward is pending any more.  A segment whose forward ran under grad mode but whose output never
+    reached a backward (an exception, a discarded pass) would otherwise stay busy -- i.e. eager -- for ever."""
+    for seg in _SEGMENTS:
+        for ent in seg.graphs.values():
+            ent.busy = False
+
+
+class _Entry:
+    __slots__ = ("fwd", "bwd", "static_in", "outs", "out_req", "static_gout", "grads_in", "grads_p", "params", "busy", "pool", "single")
+
+
+def _has_grad_hooks(p: torch.Tensor) -> bool:
+    return bool(getattr(p, "_post_accumulate_grad_hooks", None)) or bool(getattr(p, "_backward_hooks", None))
+
+
+class _Replay(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ent: _Entry, n_in: int, *args):
+        for s, x in zip(ent.static_in, args[:n_in]):
+            if s.data_ptr() != x.data_ptr():
+                s.copy_(x)
+        ent.fwd.replay()
+        ctx.ent = ent
+        ctx.n_in = n_in
+        ent.busy = ent.bwd is not None and torch.is_grad_enabled()
+        outs = tuple(o.detach() for o in ent.outs)
+        ctx.mark_non_differentiable(*[o for o, r in zip(outs, ent.out_req) if not r])
+        return outs
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gouts):
+        ent: _Entry = ctx.ent
+        assert ent.bwd is not None, "graphed segment was captured without a backward"
+        L.refresh_dgrad_layouts()
+        gi = iter(ent.static_gout)
+        for g, r in zip(gouts, ent.out_req):
+            if not r:
+                continue
+            s = next(gi)
+            if g is None:
+                s.zero_()
+            elif s.data_ptr() != g.data_ptr():
+                s.copy_(g)
+        ent.bwd.replay()
+        ent.busy = False
+        gin = tuple(None if g is None else g.detach() for g in ent.grads_in)
+        gp = []
+        for p, g in zip(ent.params, ent.grads_p):
+            if g is None:
+                gp.append(None)
+            elif p.grad is None and not _has_grad_hooks(p):
+                p.grad = g          # the static buffer itself: no accumulate copy, stable address for the optimizer's table
+                gp.append(None)
+            else:
+                gp.append(g)
+        return (None, None) + gin + tuple(gp)
+
+
+class GraphedSegment:
+    """fn(*tensors) -> tensor | tuple of tensors, replayed as HIP graphs once a shape has repeated.  `params`: callable returning the
+    parameters whose gradients the stretch produces (evaluated at capture)."""
+
+    def __init__(self, name: str, fn: Callable, params: Callable[[], Sequence[torch.nn.Parameter]]):
+        self.name, self.fn, self.params_fn = name, fn, params
+        self.graphs: Dict[tuple, _Entry] = {}
+        self.seen: Dict[tuple, int] = {}
+        self.failed = False
+        _SEGMENTS.append(self)
+
+    # ---------------------------------------------------------------- eligibility
+    def _eligible(self, inputs) -> bool:
+        if not ENABLED["on"] or self.failed or not inputs or not all(torch.is_tensor(x) and x.is_cuda for x in inputs):
+            return False
+        if K.timing_active() or torch.cuda.is_current_stream_capturing():
+            return False
+        dev = inputs[0].device
+        return torch.cuda.current_stream(dev) == torch.cuda.default_stream(dev)
+
+    def _key(self, inputs, extra) -> tuple:
+        cg = L.CONV_GEMM
+        return (tuple((tuple(x.shape), tuple(x.stride()), x.dtype, bool(x.requires_grad)) for x in inputs), torch.is_grad_enabled(),
+                torch.is_autocast_enabled("cuda"), torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None,
+                (cg["enabled"], cg["wgrad"], cg["min_rows"]), L._VALID_ROWS[0], extra)
+
+    def __call__(self, *inputs, key_extra=()):
+        if not self._eligible(inputs):
+            STATS["eager"] += 1
+            return self.fn(*inputs)
+        key = self._key(inputs, key_extra)
+        ent = self.graphs.get(key)
+        if ent is None:
+            n = self.seen.get(key, 0) + 1
+            self.seen[key] = n
+            if n <= WARM_CALLS or len(self.graphs) >= MAX_GRAPHS:
+                STATS["eager"] += 1
+                return self.fn(*inputs)
+            try:
+                ent = self._capture(inputs)
+            except Exception as e:   # same kernels either way
+                warnings.warn(f"step graph '{self.name}': capture failed ({type(e).__name__}: {e}); this stretch stays eager")
+                self.failed = True
+                torch.cuda.synchronize()
+                STATS["eager"] += 1
+                return self.fn(*inputs)
+            self.graphs[key] = ent
+            STATS["captures"] += 1
+        if ent.busy:
+            STATS["busy"] += 1
+            return self.fn(*inputs)
+        STATS["replays"] += 1
+        outs = _Replay.apply(ent, len(inputs), *inputs, *ent.params)
+        return outs[0] if ent.single else outs
+
+    # ---------------------------------------------------------------- capture
+    def _capture(self, inputs) -> _Entry:
+        ent = _Entry()
+        ent.busy = False
+        grad_mode = torch.is_grad_enabled()
+        ent.static_in = [x.detach().clone(memory_format=torch.preserve_format).requires_grad_(bool(x.requires_grad) and grad_mode) for x in inputs]
+        ent.params = [p for p in self.params_fn() if p.requires_grad] if grad_mode else []
+        L.refresh_dgrad_layouts()
+        torch.cuda.synchronize()
+        ent.pool = torch.cuda.graph_pool_handle()
+        ent.fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ent.fwd, pool=ent.pool, capture_error_mode="thread_local"):
+            out = self.fn(*ent.static_in)
+        ent.single = torch.is_tensor(out)
+        outs = (out,) if ent.single else tuple(out)
+        ent.outs = outs
+        ent.out_req = [bool(o.requires_grad) for o in outs]
+        ent.bwd, ent.static_gout, ent.grads_in, ent.grads_p = None, [], [None] * len(ent.static_in), [None] * len(ent.params)
+        if grad_mode and any(ent.out_req):
+            req = [o for o in outs if o.requires_grad]
+            ent.static_gout = [torch.zeros_like(o) for o in req]
+            wrt_in = [i for i, s in enumerate(ent.static_in) if s.requires_grad]
+            wrt = [ent.static_in[i] for i in wrt_in] + list(ent.params)
+            ent.bwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ent.bwd, pool=ent.pool, capture_error_mode="thread_local"):
+                grads = torch.autograd.grad(req, wrt, grad_outputs=ent.static_gout, allow_unused=True)
+            for j, i in enumerate(wrt_in):
+                ent.grads_in[i] = grads[j]
+            ent.grads_p = list(grads[len(wrt_in):])
+        return ent

@@ -72,6 +72,12 @@ def timing_pause() -> None:
 _PAUSED = False
 
 
+def timing_active() -> bool:
+    """HIP events are being recorded around the timed entry points (bench.py's first timed steps): the step graphs stay off meanwhile,
+    a replayed graph launches none of them from the host."""
+    return _TIMING is not None and not _PAUSED
+
+
 def timing_end() -> dict:
     """-> {name: (launches, mean_ms, algorithmic_bytes_per_launch)}; call after a device synchronize."""
     global _TIMING

@@ -104,6 +104,38 @@ def weights_updated() -> None:
         _DGRAD_STATE["dirty"] = True
 
 
+def _run_dgrad_table(device) -> None:
+    st = _DGRAD_STATE
+    if st["table"] is None:
+        live = [x for x in _DGRAD.values() if x.ref() is not None]
+        st["table"] = K.WdTable([(x.src, x.tensor, *x.dims) for x in live])
+        st["live"] = live
+    st["table"].run()
+    for x in st["live"]:
+        p = x.ref()
+        if p is None:
+            continue
+        # stamp only layouts built from a CURRENT shadow: a master rewritten with a version bump (load_state_dict, init_, copy_) whose
+        # shadow has not been refreshed by a forward yet keeps version -1 and takes the reference copy at its next use (round-4 ADVICE)
+        sh = _SHADOWS.get(id(p))
+        fresh = sh is not None and sh.ref() is p and sh.version == p._version and sh.ptr == p.data_ptr()
+        x.version, x.ptr = (p._version, p.data_ptr()) if fresh else (-1, 0)
+    st["dirty"] = False
+    st["stream"] = torch.cuda.current_stream(device)
+    st["event"] = torch.cuda.Event()
+    st["event"].record(st["stream"])
+
+
+def refresh_dgrad_layouts() -> None:
+    """Run the pending one-launch refresh of the data-gradient layouts NOW, eagerly, on the current stream (coin_amd.graphs calls it
+    before a backward graph is captured or replayed: inside a capture the launch would be recorded, not executed, while the host-side
+    stamps said it had run)."""
+    if _DGRAD_STATE["dirty"] and _DGRAD and not torch.cuda.is_current_stream_capturing():
+        live = [x for x in _DGRAD.values() if x.ref() is not None]
+        if live:
+            _run_dgrad_table(live[0].tensor.device)
+
+
 def _dgrad_reference(wq: torch.Tensor, ks: int) -> torch.Tensor:
     if wq.dim() == 2:
         return wq.t().contiguous()
@@ -129,28 +161,14 @@ def dgrad_weight(param: Optional[torch.Tensor], wq: torch.Tensor, ks: int) -> to
         _DGRAD[id(param)] = e
         _DGRAD_STATE["table"] = None
     st = _DGRAD_STATE
-    if st["dirty"]:
+    capturing = torch.cuda.is_current_stream_capturing()
+    if st["dirty"] and not capturing:
         # one launch for every registered weight, on the stream of the first backward node that needs one; nodes on other streams wait
-        if st["table"] is None:
-            live = [x for x in _DGRAD.values() if x.ref() is not None]
-            st["table"] = K.WdTable([(x.src, x.tensor, *x.dims) for x in live])
-            st["live"] = live
-        st["table"].run()
-        for x in st["live"]:
-            p = x.ref()
-            if p is None:
-                continue
-            # stamp only layouts built from a CURRENT shadow: a master rewritten with a version bump (load_state_dict, init_, copy_) whose
-            # shadow has not been refreshed by a forward yet keeps version -1 and takes the reference copy at its next use (round-4 ADVICE)
-            sh = _SHADOWS.get(id(p))
-            fresh = sh is not None and sh.ref() is p and sh.version == p._version and sh.ptr == p.data_ptr()
-            x.version, x.ptr = (p._version, p.data_ptr()) if fresh else (-1, 0)
-        st["dirty"] = False
-        st["stream"] = torch.cuda.current_stream(wq.device)
-        st["event"] = torch.cuda.Event()
-        st["event"].record(st["stream"])
-    elif st["event"] is not None and torch.cuda.current_stream(wq.device) != st["stream"]:
+        _run_dgrad_table(wq.device)
+    elif st["event"] is not None and not capturing and torch.cuda.current_stream(wq.device) != st["stream"]:
         torch.cuda.current_stream(wq.device).wait_event(st["event"])
+    # (under a graph capture nothing is launched or waited for here: coin_amd.graphs refreshed the layouts eagerly before the capture,
+    # and a new entry registered during the capture takes the reference copy below, recorded into the graph)
     if e.version != param._version or e.ptr != param.data_ptr():
         # first use, or the master was written by something other than the fused SGD kernel (init, load_state_dict)
         with torch.no_grad():

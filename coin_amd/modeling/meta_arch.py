@@ -70,7 +70,13 @@ class OpenVocabularyRCNN(nn.Module):
         return cls(backbone=backbone, roi_heads=roi_heads, pixel_mean=cfg.INPUT.TEACHER_OFFLINE.PIXEL_MEAN,
                    pixel_std=cfg.INPUT.TEACHER_OFFLINE.PIXEL_STD, device=cfg.MODEL.DEVICE, input_format=cfg.INPUT.FORMAT,
                    vis_period=cfg.VIS_PERIOD, proposal_generator=build_proposal_generator(cfg, backbone.output_shape()),
-                   compute_dtype=torch.bfloat16 if cfg.AMD.COMPUTE_DTYPE == "bf16" else torch.float32)._with_sync_free(cfg.AMD.SYNC_FREE, cfg.AMD.SYNC_FREE_STEP)
+                   compute_dtype=torch.bfloat16 if cfg.AMD.COMPUTE_DTYPE == "bf16" else torch.float32)._with_sync_free(
+                       cfg.AMD.SYNC_FREE, cfg.AMD.SYNC_FREE_STEP)._with_step_graphs(bool(getattr(cfg.AMD, "STEP_GRAPHS", True)))
+
+    def _with_step_graphs(self, flag: bool):
+        self.step_graphs = bool(flag)
+        self.roi_heads.step_graphs = bool(flag)
+        return self
 
     def _with_sync_free(self, flag, flag_step=False):
         self.set_sync_free(flag)
@@ -151,6 +157,29 @@ class OpenVocabularyRCNN(nn.Module):
     def _autocast(self):
         return torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.compute_dtype == torch.bfloat16)
 
+    # ---- the trainable stages of the backbone as one pair of HIP graphs (coin_amd/graphs.py) --------------------------------------
+    step_graphs = True
+    _seg_backbone = None
+
+    def _backbone_features(self, images, frozen_out):
+        """backbone(images) of the training forward.  C4 CLIP backbone on the GPU: the stages without trainable parameters run as before
+        (or arrive from the look-ahead), the trainable stages -- whose launch sequence depends on the padded batch shape only -- go through a
+        `GraphedSegment` (eager for the first calls of a shape, then one graph launch forward and one backward)."""
+        bb = self.backbone
+        if not (self.step_graphs and images.tensor.is_cuda and type(bb).__name__ == "CLIP_IMAGE" and hasattr(bb, "frozen_forward")
+                and list(bb.encoder.visual._out_features) == ["res4"]):
+            return bb(frozen_out, frozen_done=True) if frozen_out is not None else bb(images.tensor)
+        if frozen_out is None:
+            frozen_out = bb.frozen_forward(images.tensor)
+        if self._seg_backbone is None:
+            from ..graphs import GraphedSegment
+
+            vis = bb.encoder.visual
+            self._seg_backbone = GraphedSegment("backbone", lambda x: bb(x, frozen_done=True)["res4"],
+                                                lambda: [p for n, p in vis.named_parameters() if not n.startswith("layer4.")])
+        vis = bb.encoder.visual
+        return {"res4": self._seg_backbone(frozen_out, key_extra=(bb.training, vis.layer2.training, vis.layer3.training, vis.freeze_at))}
+
     def preprocess_image(self, batched_inputs: List[Dict]) -> ImageList:
         imgs = [x["image"].to(self.pixel_mean.device, non_blocking=True).contiguous() for x in batched_inputs]
         batch, sizes = K.normalize_pad(imgs, self._mean, self._std, self.backbone.size_divisibility, COIN_NHWC, self.compute_dtype)
@@ -170,7 +199,7 @@ class OpenVocabularyRCNN(nn.Module):
                 rpn = [x["RPN"].to(dev) for x in batched_inputs]
                 merge_module = None
                 side = self._overlap_side_work(images, rpn)
-            features = self.backbone(frozen_out, frozen_done=True) if frozen_out is not None else self.backbone(images.tensor)
+            features = self._backbone_features(images, frozen_out)
             self._launch_lookahead()
             if branch == "pre_train":
                 if side is not None:

@@ -121,8 +121,31 @@ class OpenVocabularyRes5ROIHeads(nn.Module):
         if pad:
             rois = torch.cat([rois, rois.new_zeros((pad, 5))], dim=0)
         with L.valid_rows(r if pad else None):
-            out = self._pooled_rows(features, rois, res5, attnpool)
+            out = self._pooled_graphed(features, rois, res5, attnpool)
         return out[:r] if pad else out
+
+    step_graphs = True
+    _trunk_segs = None
+
+    def _pooled_graphed(self, features, rois, res5, attnpool):
+        """`_pooled_rows` through a `GraphedSegment` (coin_amd/graphs.py) during training on the GPU: RoIAlign -> res5 -> mean pool is a fixed
+        launch sequence for a given (feature map shape, RoI count)."""
+        if not (self.step_graphs and self.training and torch.is_grad_enabled() and self.pooling_type == "meanpool" and len(self.in_features) == 1
+                and rois.is_cuda and rois.shape[0] > 0 and isinstance(res5, torch.nn.Sequential)):
+            return self._pooled_rows(features, rois, res5, attnpool)
+        if self._trunk_segs is None:
+            self._trunk_segs = {}
+        seg = self._trunk_segs.get(id(res5))
+        if seg is None or seg[0]() is not res5:
+            import weakref
+
+            from ..graphs import GraphedSegment
+
+            name = self.in_features[0]
+            seg = (weakref.ref(res5), GraphedSegment("roi_trunk", lambda feat, r: self._pooled_rows({name: feat}, r, res5, attnpool),
+                                                     lambda: list(res5.parameters())))
+            self._trunk_segs[id(res5)] = seg
+        return seg[1](features[self.in_features[0]], rois, key_extra=(res5.training, self.compute_dtype))
 
     def _pooled_rows(self, features, rois, res5, attnpool):
         if self.pooling_type == "meanpool" and isinstance(res5, torch.nn.Sequential) and len(res5) > 0 and hasattr(res5[-1], "conv3"):

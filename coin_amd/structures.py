@@ -162,7 +162,10 @@ class Instances:
         return f"Instances(num={len(self) if self._fields else 0}, size={self._image_size}, fields={list(self._fields)})"
 
 
-MyInstances = Instances  # coin/utils/util.py:188 (the check_len extension is folded into `set`)
+class MyInstances(Instances):
+    """coin/utils/util.py:188-267.  Its extensions (`set(check_len=False)`, `to` / `__getitem__` / `cat` returning the subclass) are already
+    in the base class above; the subclass exists so that a cached result keeps its class across a save / load round trip
+    (coin_amd/checkpoint.py writes it under the reference's class path coin.utils.util.MyInstances)."""
 
 
 class ImageList:

