@@ -377,10 +377,15 @@ def main():
         best = max(ktimes.items(), key=lambda kv: kv[1][0] * kv[1][1]) if ktimes else None
         roofline = None
         detail = {}
+        tsteps = min(args.steps, KERNEL_TIMING_STEPS)
         for name, (n, ms, units) in ktimes.items():
             if name in MFMA_ENTRIES:
                 detail[name] = {"launches": n, "mean_ms": ms, "total_ms_per_step": n * ms / min(args.steps, KERNEL_TIMING_STEPS), "TFLOP/s": units / (ms * 1e-3) / 1e12,
                                 "alg_flop": units, "device_kernels": ENTRY_KERNELS.get(name)}
+                if name in K.SHAPES:   # the launch mix behind the mean: one row per (M, N, K, kernel size), by time
+                    rows = sorted(K.SHAPES[name].items(), key=lambda kv: -kv[1][1])
+                    detail[name]["shapes"] = [{"M": t[0], "N": t[1], "K": t[2], "ks": t[3], "calls_per_step": c / tsteps, "ms": round(tot / c, 4),
+                                               "ms_per_step": round(tot / tsteps, 4), "TFLOP/s": round(fl / (tot / c * 1e-3) / 1e12, 1)} for t, (c, tot, fl) in rows]
             else:
                 detail[name] = {"launches": n, "mean_ms": ms, "total_ms_per_step": n * ms / min(args.steps, KERNEL_TIMING_STEPS), "GB/s": units / (ms * 1e-3) / 1e9,
                                 "alg_bytes": units, "device_kernels": ENTRY_KERNELS.get(name)}

@@ -143,6 +143,7 @@ def lib() -> ctypes.CDLL:
     l.coin_window_attn_bwd_workspace_bytes.argtypes = [c_int, c_int]
     l.coin_window_attn_bwd_workspace_bytes.restype = ctypes.c_size_t
     l.coin_abi_version.restype = c_int
+    l.coin_clear_last_error.restype = c_int
     if l.coin_abi_version() != ABI_VERSION:   # a stale build: ctypes would pass shifted arguments to changed prototypes
         raise CoinHipError(f"{LIB_PATH} implements C-ABI version {l.coin_abi_version()}, this package binds version {ABI_VERSION}: "
                            "rebuild it (`make -C coin_amd/csrc`)")

@@ -132,6 +132,13 @@ struct NtCursor {
   int kt, ke, idx, buf;
 };
 
+// N % 256 == 128 (layer2's 128-channel convolutions): the last column tile has no upper B half.  Its DMA offsets lie beyond the operand
+// (the range check returns zeros, no memory traffic), its two MFMA phases are skipped and the epilogue stores the lower 128 columns only.
+__device__ __forceinline__ bool p8_has_bhi(const P8Args& p, int tile) {
+  const int tn = tile % p.tiles_n;
+  return tn * PN + 128 < p.N;
+}
+
 template <bool GATHER3>
 __device__ __forceinline__ void nt_set_tile(NtCursor<GATHER3>& c, const P8Args& p, int tile, int wave, int lane) {
   const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
@@ -159,7 +166,7 @@ __device__ __forceinline__ void nt_set_tile(NtCursor<GATHER3>& c, const P8Args& 
         c.taps[h * 2 + e] = 0;
         c.a[h * 2 + e] = (unsigned)(((size_t)row * p.lda + sc) * 2);
       }
-      c.b[h * 2 + e] = (unsigned)(((size_t)(tn * PN + rloc) * p.ldb + sc) * 2);  // N % 256 == 0: always inside
+      c.b[h * 2 + e] = (unsigned)(((size_t)(tn * PN + rloc) * p.ldb + sc) * 2);  // rows >= N (N % 256 == 128): beyond b_bytes -> zeros
     }
 }
 
@@ -241,6 +248,7 @@ __device__ __forceinline__ void p8_epilogue(const P8Args& p, f32x4 (&acc)[2][2][
   if (P8_DBG(p, 4)) return;  // lab only: main loop without the epilogue
 #pragma unroll
   for (int bh = 0; bh < 2; ++bh) {
+    if (bh == 1 && n0 + 128 >= p.N) break;   // workgroup-uniform: a half-width last column tile
     // statistics in pairs of channels: v_pk_add_f32 / v_pk_fma_f32 (a wave64 vector instruction holds its SIMD for 4 cycles; the
     // unpacked form spent ~4 000 SIMD cycles per tile here: 7-15 % of a 1x1 convolution's tile)
     f32x2 s1[4], s2[4], piv[4];
@@ -461,6 +469,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(const P8Args p) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[x][y][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    const bool bhi = p8_has_bhi(p, items.tile(item_idx));
     if (wr == 1) P8_BAR();  // G1 runs one barrier behind G0
     for (int kt = items.kb(item_idx), kt_end = items.ke(item_idx); kt < kt_end; ++kt, ++g) {
       const char* kb = lds + (g & 1) * P_KT;
@@ -518,12 +527,14 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(const P8Args p) {
       P8_BAR();
       P8_SCHED();
       __builtin_amdgcn_s_setprio(1);
+      if (bhi) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[0][1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][ks], af[i][ks], acc[0][1][i][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) acc[0][1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][ks], af[i][ks], acc[0][1][i][j], 0, 0, 0);
+      }
       __builtin_amdgcn_s_setprio(0);
       P8_SCHED();
       P8_BAR();
@@ -539,12 +550,14 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(const P8Args p) {
       P8_BAR();
       P8_SCHED();
       __builtin_amdgcn_s_setprio(1);
+      if (bhi) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[1][1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][ks], af[i][ks], acc[1][1][i][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) acc[1][1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][ks], af[i][ks], acc[1][1][i][j], 0, 0, 0);
+      }
       __builtin_amdgcn_s_setprio(0);
       P8_SCHED();
       P8_BAR();
@@ -1033,7 +1046,7 @@ static constexpr int coin_p8_debug = 0, coin_p8_stagger = -1, coin_p8_splitk = -
 #endif
 
 bool coin_p8_nt_ok(int M, int N, int K, int mode, int Cin, int lda, int ldb) {
-  if (M <= 0 || N % PN || K % PK || K < 2 * PK) return false;
+  if (M <= 0 || N % 128 || K % PK || K < 2 * PK) return false;   // N % 256 == 128: a half-width last column tile (p8_has_bhi)
   if ((size_t)M * (mode == 1 ? Cin : lda) * 2 >= 0x7f000000ull || (size_t)N * ldb * 2 >= 0x7f000000ull) return false;  // 32-bit buffer offsets
   if (mode == 1 && (Cin % PK || K != 9 * Cin)) return false;
   return true;
@@ -1054,8 +1067,8 @@ static void p8_nt_plan(int ntiles, int nk, int G, bool have_ws, int force, int& 
 }
 
 size_t coin_p8_nt_workspace_bytes(int M, int N, int K) {
-  if (M <= 0 || N % PN || K % PK) return 0;
-  const int ntiles = ((M + PM - 1) / PM) * (N / PN), G = p8_grid(1 << 30);
+  if (M <= 0 || N % 128 || K % PK) return 0;
+  const int ntiles = ((M + PM - 1) / PM) * ((N + PN - 1) / PN), G = p8_grid(1 << 30);
   int whole, rem, split;
   p8_nt_plan(ntiles, K / PK, G, true, 1, whole, rem, split);   // upper bound: as if forced on
   return (size_t)rem * split * 65536 * sizeof(float);
@@ -1073,7 +1086,7 @@ int coin_p8_nt_launch(const void* A, int lda, int mode, int H, int W, int Cin, c
   a.rp_magic_w = a.rp_w ? (unsigned)((0x100000000ull + (unsigned)rp_w - 1) / (unsigned)rp_w) : 0;
   a.M = M; a.N = N; a.K = K; a.H = H; a.W = W; a.Cin = Cin;
   a.stats = stats; a.stats_rows = stats_rows;
-  a.tiles_m = (M + PM - 1) / PM; a.tiles_n = N / PN;
+  a.tiles_m = (M + PM - 1) / PM; a.tiles_n = (N + PN - 1) / PN;
   a.dbg = coin_p8_debug;
   a.stagger_first = a.stagger_phases = a.stagger_ticks = 0;
   a.a_bytes = (unsigned)((size_t)M * (mode == 1 ? Cin : lda) * 2);

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void normalize_pad_kernel(const uint8_t* __res
 
 extern "C" int coin_abi_version(void) { return COIN_ABI_VERSION; }
 extern "C" const char* coin_build_arch(void) { return "gfx950"; }
+extern "C" int coin_clear_last_error(void) { return (int)hipGetLastError(); }
 
 extern "C" int coin_sgd_step(const coin_sgd_tensor* table, int num_tensors, int64_t max_numel, float momentum,
                              float inv_loss_scale, float lr_scale, int first_step, const float* gate, void* stream) {

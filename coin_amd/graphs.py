@@ -42,6 +42,7 @@ ENABLED = {"on": os.environ.get("COIN_STEP_GRAPHS", "1") != "0"}
 WARM_CALLS = 2          # eager calls of a shape before it is captured
 MAX_GRAPHS = 3          # shapes per segment (real data: a few padded sizes); further shapes stay eager
 STATS = {"captures": 0, "replays": 0, "eager": 0, "busy": 0}
+CAPTURE_MODE = {"fwd": "thread_local", "bwd": "thread_local"}   # other threads (image decoding) may touch the device meanwhile
 
 
 _SEGMENTS: "List[GraphedSegment]" = []
@@ -57,6 +58,100 @@ def step_done() -> None:
     for seg in _SEGMENTS:
         for ent in seg.graphs.values():
             ent.busy = False
+
+
+def _backward_on_this_thread(roots: Sequence[torch.Tensor], root_grads: Sequence[torch.Tensor], wrt: Sequence[torch.Tensor]):
+    """d(roots)/d(wrt) by calling the autograd nodes one by one ON THE CALLING THREAD, in dependency order -- what
+    ``torch.autograd.grad(roots, wrt, root_grads, allow_unused=True)`` computes, without the engine.
+
+    Why not the engine, under a stream capture: (1) it runs device work on its own worker thread, and (2) a leaf's gradient accumulator
+    node that is still alive from an earlier eager step (the previous step's loss dict keeps its graph) carries the DEFAULT stream, so the
+    engine makes the default stream wait for an event of the capturing stream -- an illegal dependency that ended in a segmentation fault
+    inside hipStreamEndCapture (torch 2.10 / ROCm 7.0, reproduced with a bare nn.Linear).  Here every node runs on the capturing thread
+    and stream, accumulator nodes are never executed (their incoming gradient IS the result), no cross-stream event is created.
+    Runs with grad mode and autocast off, as the engine's worker threads do."""
+    import collections
+
+    leaf = {id(t): i for i, t in enumerate(wrt)}
+    result: List[Optional[torch.Tensor]] = [None] * len(wrt)
+    start = []
+    for r in roots:
+        if r.grad_fn is not None and r.grad_fn not in start:
+            start.append(r.grad_fn)
+    deps: Dict = collections.Counter()
+    seen, stack = set(start), list(start)
+    while stack:
+        n = stack.pop()
+        for nxt, _ in n.next_functions:
+            if nxt is None:
+                continue
+            deps[nxt] += 1
+            if nxt not in seen:
+                seen.add(nxt)
+                stack.append(nxt)
+    pending: Dict = {}
+
+    def add(node, idx, g):
+        if g is None:
+            return
+        # the engine's validate_outputs: a gradient is reduced to the shape (broadcast operands) and cast to the dtype its consumer recorded
+        meta = node._input_metadata[idx]
+        if tuple(g.shape) != tuple(meta.shape):
+            g = g.sum_to_size(tuple(meta.shape))
+        if g.dtype != meta.dtype:
+            g = g.to(meta.dtype)
+        slot = pending.setdefault(node, {})
+        slot[idx] = g if idx not in slot else slot[idx] + g
+
+    for r, g in zip(roots, root_grads):
+        if r.grad_fn is None:           # a root that is itself a wanted leaf
+            i = leaf.get(id(r))
+            if i is not None:
+                result[i] = g if result[i] is None else result[i] + g
+        else:
+            add(r.grad_fn, r.output_nr, g)
+    ready = [n for n in start if deps[n] == 0]
+    with torch.no_grad(), torch.autocast("cuda", enabled=False):
+        while ready:
+            n = ready.pop()
+            got = pending.pop(n, {})
+            if hasattr(n, "variable"):       # AccumulateGrad of a leaf: not executed, its input is the leaf's gradient
+                i = leaf.get(id(n.variable))
+                if i is not None and 0 in got:
+                    result[i] = got[0] if result[i] is None else result[i] + got[0]
+                continue
+            outs = None
+            edges = n.next_functions
+            where = list(range(len(edges)))          # edge k takes the node's output where[k]
+            if got:
+                args = [got.get(i) for i in range(len(n._input_metadata))]
+                if isinstance(n, torch.autograd.function.BackwardCFunction):
+                    # a Python autograd.Function: its node object is the ctx.  The engine's PyNode materialises undefined gradients as zeros
+                    # (unless the Function opted out) before it calls backward, and keeps only the results at TENSOR argument positions:
+                    # `backward` returns one value per forward argument, the edges exist per tensor argument.  The j-th argument that needs
+                    # a gradient is the j-th live edge (an edge is live exactly when its tensor requires grad).
+                    if getattr(n, "materialize_grads", True):
+                        args = [a if a is not None else torch.zeros(tuple(m.shape), dtype=m.dtype, device=m.device) for a, m in zip(args, n._input_metadata)]
+                    outs = n.apply(*args)
+                    need = [i for i, f in enumerate(n.needs_input_grad) if f]
+                    live = [k for k, e in enumerate(edges) if e[0] is not None]
+                    assert len(need) == len(live), (type(n).__name__, n.needs_input_grad, len(live))
+                    where = [None] * len(edges)
+                    for k, i in zip(live, need):
+                        where[k] = i
+                else:
+                    outs = n(*args)
+                if not isinstance(outs, (tuple, list)):
+                    outs = (outs,)
+            for k, (nxt, idx) in enumerate(edges):
+                if nxt is None:
+                    continue
+                if outs is not None and where[k] is not None and where[k] < len(outs):
+                    add(nxt, idx, outs[where[k]])
+                deps[nxt] -= 1
+                if deps[nxt] == 0:
+                    ready.append(nxt)
+    return result
 
 
 class _Entry:
@@ -76,7 +171,6 @@ class _Replay(torch.autograd.Function):
         ent.fwd.replay()
         ctx.ent = ent
         ctx.n_in = n_in
-        ent.busy = ent.bwd is not None and torch.is_grad_enabled()
         outs = tuple(o.detach() for o in ent.outs)
         ctx.mark_non_differentiable(*[o for o, r in zip(outs, ent.out_req) if not r])
         return outs
@@ -111,12 +205,32 @@ class _Replay(torch.autograd.Function):
         return (None, None) + gin + tuple(gp)
 
 
+def _recover_from_failed_capture() -> None:
+    """A capture that failed half way leaves a sticky runtime error behind: the next launch status check would report it for an innocent
+    kernel.  Drain the device and consume the error (hipGetLastError through the library's own status call)."""
+    for _ in range(2):
+        try:
+            torch.cuda.synchronize()
+            break
+        except Exception:
+            pass
+    try:
+        from . import _lib
+
+        _lib.lib().coin_clear_last_error()
+    except Exception:
+        pass
+
+
 class GraphedSegment:
     """fn(*tensors) -> tensor | tuple of tensors, replayed as HIP graphs once a shape has repeated.  `params`: callable returning the
     parameters whose gradients the stretch produces (evaluated at capture)."""
 
-    def __init__(self, name: str, fn: Callable, params: Callable[[], Sequence[torch.nn.Parameter]]):
-        self.name, self.fn, self.params_fn = name, fn, params
+    def __init__(self, name: str, fn: Callable, params: Callable[[], Sequence[torch.nn.Parameter]],
+                 buffers: Optional[Callable[[], Sequence[torch.Tensor]]] = None):
+        """`buffers`: the stretch's mutable state besides the parameters (BatchNorm running statistics, `num_batches_tracked`): restored
+        after the dry run that precedes a capture."""
+        self.name, self.fn, self.params_fn, self.buffers_fn = name, fn, params, buffers
         self.graphs: Dict[tuple, _Entry] = {}
         self.seen: Dict[tuple, int] = {}
         self.failed = False
@@ -154,7 +268,7 @@ class GraphedSegment:
             except Exception as e:   # same kernels either way
                 warnings.warn(f"step graph '{self.name}': capture failed ({type(e).__name__}: {e}); this stretch stays eager")
                 self.failed = True
-                torch.cuda.synchronize()
+                _recover_from_failed_capture()
                 STATS["eager"] += 1
                 return self.fn(*inputs)
             self.graphs[key] = ent
@@ -164,6 +278,8 @@ class GraphedSegment:
             return self.fn(*inputs)
         STATS["replays"] += 1
         outs = _Replay.apply(ent, len(inputs), *inputs, *ent.params)
+        # until this call's backward has replayed, the graph's buffers hold the activations it will read: a second call must not replay
+        ent.busy = ent.bwd is not None and any(o.requires_grad for o in outs)
         return outs[0] if ent.single else outs
 
     # ---------------------------------------------------------------- capture
@@ -174,10 +290,28 @@ class GraphedSegment:
         ent.static_in = [x.detach().clone(memory_format=torch.preserve_format).requires_grad_(bool(x.requires_grad) and grad_mode) for x in inputs]
         ent.params = [p for p in self.params_fn() if p.requires_grad] if grad_mode else []
         L.refresh_dgrad_layouts()
+        wants_bwd = grad_mode and (bool(ent.params) or any(s.requires_grad for s in ent.static_in))
+        if wants_bwd:
+            # Dry run of forward + backward ON THIS THREAD before anything is recorded.  In the eager steps the backward ran on the autograd
+            # engine's worker thread, so this thread's MIOpen handle has never loaded the backward kernels of the library convolutions that
+            # remain in the stretch: loading a code object during a capture fails (miopenStatusUnknownError, and the stream is left
+            # invalidated).  The running statistics the dry run advances are put back.
+            saved = [b.detach().clone() for b in self.buffers_fn()] if self.buffers_fn is not None else []
+            out = self.fn(*ent.static_in)
+            outs = (out,) if torch.is_tensor(out) else tuple(out)
+            req = [o for o in outs if o.requires_grad]
+            if req:
+                _backward_on_this_thread(req, [torch.zeros_like(o) for o in req], [s for s in ent.static_in if s.requires_grad] + list(ent.params))
+            del out, outs, req
+            if self.buffers_fn is not None:
+                with torch.no_grad():
+                    for b, s in zip(self.buffers_fn(), saved):
+                        b.copy_(s)
+            L.refresh_dgrad_layouts()
         torch.cuda.synchronize()
         ent.pool = torch.cuda.graph_pool_handle()
         ent.fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ent.fwd, pool=ent.pool, capture_error_mode="thread_local"):
+        with torch.cuda.graph(ent.fwd, pool=ent.pool, capture_error_mode=CAPTURE_MODE["fwd"]):
             out = self.fn(*ent.static_in)
         ent.single = torch.is_tensor(out)
         outs = (out,) if ent.single else tuple(out)
@@ -190,8 +324,8 @@ class GraphedSegment:
             wrt_in = [i for i, s in enumerate(ent.static_in) if s.requires_grad]
             wrt = [ent.static_in[i] for i in wrt_in] + list(ent.params)
             ent.bwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ent.bwd, pool=ent.pool, capture_error_mode="thread_local"):
-                grads = torch.autograd.grad(req, wrt, grad_outputs=ent.static_gout, allow_unused=True)
+            with torch.cuda.graph(ent.bwd, pool=ent.pool, capture_error_mode=CAPTURE_MODE["bwd"]):
+                grads = _backward_on_this_thread(req, ent.static_gout, wrt)
             for j, i in enumerate(wrt_in):
                 ent.grads_in[i] = grads[j]
             ent.grads_p = list(grads[len(wrt_in):])

@@ -78,22 +78,32 @@ def timing_active() -> bool:
     return _TIMING is not None and not _PAUSED
 
 
+SHAPES: dict = {}   # filled by timing_end: {entry point: {shape tag: [launches, total ms, algorithmic units per launch]}} for the tagged calls
+
+
 def timing_end() -> dict:
-    """-> {name: (launches, mean_ms, algorithmic_bytes_per_launch)}; call after a device synchronize."""
+    """-> {name: (launches, mean_ms, algorithmic_bytes_per_launch)}; call after a device synchronize.  The per-shape breakdown of the
+    entry points whose calls carry a tag (the GEMM convolutions: (M, N, K, kernel size)) is left in `SHAPES`."""
     global _TIMING
     out = {}
+    SHAPES.clear()
     for n, evs in (_TIMING or {}).items():
         if evs:
-            ms = [s.elapsed_time(e) for s, e, _ in evs]
-            out[n] = (len(ms), sum(ms) / len(ms), sum(b for _, _, b in evs) / len(evs))
+            ms = [ev[0].elapsed_time(ev[1]) for ev in evs]
+            out[n] = (len(ms), sum(ms) / len(ms), sum(ev[2] for ev in evs) / len(evs))
+            for t, ev in zip(ms, evs):
+                if ev[3] is not None:
+                    rec = SHAPES.setdefault(n, {}).setdefault(ev[3], [0, 0.0, ev[2]])
+                    rec[0] += 1
+                    rec[1] += t
     _TIMING = None
     return out
 
 
 class _timed:
-    def __init__(self, name: str, alg_bytes: int = 0):
+    def __init__(self, name: str, alg_bytes: int = 0, tag=None):
         self.on = _TIMING is not None and not _PAUSED and name in _TIMING
-        self.name, self.bytes = name, alg_bytes
+        self.name, self.bytes, self.tag = name, alg_bytes, tag
 
     def __enter__(self):
         if self.on:
@@ -103,7 +113,7 @@ class _timed:
     def __exit__(self, *a):
         if self.on:
             self.e.record(torch.cuda.current_stream())
-            _TIMING[self.name].append((self.s, self.e, self.bytes))
+            _TIMING[self.name].append((self.s, self.e, self.bytes, self.tag))
         return False
 
 
@@ -249,7 +259,7 @@ def conv_gemm(a: torch.Tensor, w: torch.Tensor, spatial: Optional[Tuple[int, int
         shape_key = (m, n, k, mode, a.stride(0), w.stride(0))
         if shape_key in _RPOOL_UNSERVED:
             return None
-        with _timed("coin_conv_gemm_bf16", 2 * m * n * k):
+        with _timed("coin_conv_gemm_bf16", 2 * m * n * k, (m, n, k, 3 if mode else 1)):
             rc = _lib.lib().coin_conv_gemm_bf16_rpool(_p(a), a.stride(0), mode, h, wd, cin, _p(w), w.stride(0), _p(out), out.stride(0), _p(residual),
                                                       residual.stride(0), int(residual_pool[0]), int(residual_pool[1]), m, n, k, _p(ws),
                                                       wsb if ws is not None else 0, _stream())
@@ -258,7 +268,7 @@ def conv_gemm(a: torch.Tensor, w: torch.Tensor, spatial: Optional[Tuple[int, int
             return None
         check(rc, "coin_conv_gemm_bf16_rpool")
         return out, None
-    with _timed("coin_conv_gemm_bf16", 2 * m * n * k):  # "bytes" slot carries FLOPs for the MFMA entry point
+    with _timed("coin_conv_gemm_bf16", 2 * m * n * k, (m, n, k, 3 if mode else 1)):  # "bytes" slot carries FLOPs for the MFMA entry point
         check(_lib.lib().coin_conv_gemm_bf16_ws(_p(a), a.stride(0), mode, h, wd, cin, _p(w), w.stride(0), _p(out), out.stride(0),
                                                 _p(residual), residual.stride(0) if residual is not None else 0, m, n, k,
                                                 _p(part), int(stats_rows or 0), _p(ws), wsb if ws is not None else 0, _stream()), "coin_conv_gemm_bf16_ws")
@@ -293,7 +303,7 @@ def conv_wgrad(gy: torch.Tensor, x: torch.Tensor, spatial: Optional[Tuple[int, i
     if ws is None:
         ws = _WGRAD_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=gy.device)
     dw = torch.empty((cout, ktot), dtype=torch.float32, device=gy.device)
-    with _timed("coin_conv_wgrad_bf16", 2 * m * cout * ktot):
+    with _timed("coin_conv_wgrad_bf16", 2 * m * cout * ktot, (m, cout, ktot, 3 if mode else 1)):
         check(_lib.lib().coin_conv_wgrad_bf16(_p(gy), _p(x), mode, h, w, cin, m, cout, ktot, _p(dw), _p(ws), _stream()), "coin_conv_wgrad_bf16")
     return dw
 

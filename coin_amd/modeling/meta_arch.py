@@ -176,7 +176,8 @@ class OpenVocabularyRCNN(nn.Module):
 
             vis = bb.encoder.visual
             self._seg_backbone = GraphedSegment("backbone", lambda x: bb(x, frozen_done=True)["res4"],
-                                                lambda: [p for n, p in vis.named_parameters() if not n.startswith("layer4.")])
+                                                lambda: [p for n, p in vis.named_parameters() if not n.startswith("layer4.")],
+                                                lambda: [b for n, b in vis.named_buffers() if not n.startswith("layer4.")])
         vis = bb.encoder.visual
         return {"res4": self._seg_backbone(frozen_out, key_extra=(bb.training, vis.layer2.training, vis.layer3.training, vis.freeze_at))}
 

@@ -143,7 +143,7 @@ class OpenVocabularyRes5ROIHeads(nn.Module):
 
             name = self.in_features[0]
             seg = (weakref.ref(res5), GraphedSegment("roi_trunk", lambda feat, r: self._pooled_rows({name: feat}, r, res5, attnpool),
-                                                     lambda: list(res5.parameters())))
+                                                     lambda: list(res5.parameters()), lambda: list(res5.buffers())))
             self._trunk_segs[id(res5)] = seg
         return seg[1](features[self.in_features[0]], rois, key_extra=(res5.training, self.compute_dtype))
 

@@ -47,6 +47,9 @@ enum {
 /* Library / ABI version and the offload arch the code objects were built for ("gfx950"). */
 int coin_abi_version(void);
 const char* coin_build_arch(void);
+/* Returns and CLEARS the calling thread's last HIP runtime error (hipGetLastError): after a failed stream capture the error is sticky and
+ * the next entry point would report it as its own launch failure (coin_amd/graphs.py calls this when a capture is abandoned). */
+int coin_clear_last_error(void);
 
 /* ------------------------------------------------------------------------------------------
  * RoIAlign   (replaces coin/modeling/roi_heads/clip_roi_heads.py:172-176 `self.pooler(...)`

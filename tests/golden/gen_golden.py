@@ -30,7 +30,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-HERE = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.dirname(os.path.abspath(__file__))   # where the fixtures are written (tests/test_reference_live.py points it at a scratch directory)
+_SRC = HERE                                          # where this script lives
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
 
@@ -1368,7 +1369,7 @@ def _sub(t, *steps):
 
 
 def case_real_width():
-    sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..")))
+    sys.path.insert(0, os.path.abspath(os.path.join(_SRC, "..")))
     import seeded
 
     mu = shim.ref("coin.modeling.utils")
@@ -1472,7 +1473,7 @@ def case_rn101():
     coin/modeling/utils.py:184-186 with layers (3, 4, 23, 3), coin/data/datasets/builtin.py:162): the reference's ModifiedResNet-101
     trunk (frozen stem + layer1, train-mode BN in layer2 / layer3) on a small image and its CKGNet at 512 dims / 8 classes.
     Weights and inputs are seeded (tests/seeded.py); res5 of RN101 is RN50's (real_width_res5)."""
-    sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..")))
+    sys.path.insert(0, os.path.abspath(os.path.join(_SRC, "..")))
     import seeded
 
     mu = shim.ref("coin.modeling.utils")

@@ -72,7 +72,7 @@ def test_binding_table_matches_header(lib):
             if not is_ptr:
                 want = {"int": ctypes.c_int, "float": ctypes.c_float, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t}[d.split()[-2] if len(d.split()) > 1 else d]
                 assert ct is want, (name, d, ct)
-    unbound = set(decl) - set(_lib.SIGNATURES) - {"coin_abi_version", "coin_build_arch", "coin_nms_workspace_bytes", "coin_conv_gemm_stats_bytes", "coin_conv_wgrad_workspace_bytes", "coin_conv_gemm_workspace_bytes",
+    unbound = set(decl) - set(_lib.SIGNATURES) - {"coin_abi_version", "coin_build_arch", "coin_clear_last_error", "coin_nms_workspace_bytes", "coin_conv_gemm_stats_bytes", "coin_conv_wgrad_workspace_bytes", "coin_conv_gemm_workspace_bytes",
                                                       "coin_window_attn_bwd_workspace_bytes"}
     assert not unbound, unbound
 

@@ -1,0 +1,154 @@
+"""HIP-graph replay of the fixed-shape stretches of the training step (coin_amd/graphs.py) against the eager launches of the same kernels.
+
+The stretches replace launches of coin/modeling/utils.py:77-90,184-186 (Bottleneck stacks: the backbone's trainable stages, res5 on the
+RoI tiles) and clip_roi_heads.py:172-176 (RoIAlign); a replayed graph must give what the eager launches give: outputs, input and
+parameter gradients, BatchNorm running statistics, over steps with changing inputs and an optimizer update in between."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _blocks(seed):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    import seeded
+    from coin_amd.modeling.backbone import Bottleneck
+
+    m = torch.nn.Sequential(seeded.fill_module(Bottleneck(1024, 256, 2), seed), seeded.fill_module(Bottleneck(1024, 256, 1), seed + 1))
+    return m.cuda().to(memory_format=torch.channels_last).train()
+
+
+def test_graphed_segment_equals_the_eager_launches_bit_for_bit_over_steps(monkeypatch):
+    """Two res5-shaped Bottlenecks (every convolution on the hand-written, bit-reproducible GEMMs) for 6 'steps' with a new input and a
+    weight update each: the GraphedSegment twin (eager for 2 calls, captured at the 3rd, replayed afterwards) and the eager twin stay
+    bit-identical in outputs, input gradients, parameter gradients and running statistics."""
+    from coin_amd import graphs as G
+    from coin_amd import layers as L
+
+    monkeypatch.setitem(L.CONV_GEMM, "enabled", True)
+    monkeypatch.setitem(L.CONV_GEMM, "min_rows", 0)
+    monkeypatch.setitem(L.CONV_GEMM, "wgrad", True)
+    monkeypatch.setitem(G.ENABLED, "on", True)
+    from coin_amd.solver.build import FusedSGD
+
+    a, b = _blocks(5), _blocks(5)
+    # the product's optimizer: ONE launch rewrites masters, momentum and the bf16 shadows in place (no version bump, no Python per step --
+    # which is what lets a replayed graph see the new weights)
+    opt_a, opt_b = (FusedSGD([{"params": [p]} for p in m.parameters()], lr=1e-3, momentum=0.9, weight_decay=1e-4) for m in (a, b))
+    seg = G.GraphedSegment("test_blocks", lambda x: b(x), lambda: list(b.parameters()))
+    before = dict(G.STATS)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for step in range(6):
+        x0 = torch.randn(16, 1024, 14, 14, device="cuda", generator=gen).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        gy = torch.randn(16, 1024, 7, 7, device="cuda", generator=gen).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        outs = []
+        for mod, run in ((a, lambda x: a(x)), (b, seg)):
+            x = x0.clone().requires_grad_(True)
+            for p in mod.parameters():
+                p.grad = None
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = run(x)
+            y.backward(gy)
+            outs.append((y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in mod.parameters()], [bf.clone() for bf in mod.buffers()]))
+        G.step_done()
+        (ya, gxa, gpa, bfa), (yb, gxb, gpb, bfb) = outs
+        assert torch.equal(ya, yb), (step, float((ya.float() - yb.float()).abs().max()))
+        assert torch.equal(gxa, gxb), (step, float((gxa.float() - gxb.float()).abs().max()))
+        for i, (u, v) in enumerate(zip(gpa, gpb)):
+            assert torch.equal(u, v), (step, i, float((u - v).abs().max()))
+        for i, (u, v) in enumerate(zip(bfa, bfb)):
+            assert torch.equal(u, v), (step, "buffer", i)
+        opt_a.step()
+        opt_b.step()
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert torch.equal(pa, pb)
+    assert G.STATS["captures"] - before["captures"] == 1 and G.STATS["replays"] - before["replays"] == 4, G.STATS
+    assert len(seg.graphs) == 1 and not seg.failed
+
+
+def test_a_busy_segment_and_foreign_streams_fall_back_to_the_eager_launches(monkeypatch):
+    """A second forward of the same shape before the first one's backward must not replay (it would overwrite the saved activations):
+    it runs eagerly, both backward passes are right.  A call from a side stream stays eager as well."""
+    from coin_amd import graphs as G
+    from coin_amd import layers as L
+
+    monkeypatch.setitem(L.CONV_GEMM, "enabled", True)
+    monkeypatch.setitem(L.CONV_GEMM, "min_rows", 0)
+    monkeypatch.setitem(G.ENABLED, "on", True)
+    b = _blocks(9)
+    b.eval()   # frozen statistics: two forwards of one step do not interact through the running averages
+    for p in b.parameters():
+        p.requires_grad_(False)
+    seg = G.GraphedSegment("test_busy", lambda x: b(x), lambda: [])
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    mk = lambda: torch.randn(8, 1024, 14, 14, device="cuda", generator=gen).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        for _ in range(3):   # warm-up + capture
+            x = mk().requires_grad_(True)
+            seg(x).sum().backward()
+        x1, x2 = mk().requires_grad_(True), mk().requires_grad_(True)
+        busy0 = G.STATS["busy"]
+        y1 = seg(x1)              # replay: busy until its backward
+        y2 = seg(x2)              # eager
+        assert G.STATS["busy"] == busy0 + 1
+        r1, r2 = b(x1.detach()), b(x2.detach())
+        assert torch.equal(y1, r1) and torch.equal(y2, r2)
+        (y1.float().sum() + 2 * y2.float().sum()).backward()
+        xr = x1.detach().clone().requires_grad_(True)
+        b(xr).float().sum().backward()
+        assert torch.equal(x1.grad, xr.grad)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        eager0 = G.STATS["eager"]
+        with torch.cuda.stream(side):
+            y3 = seg(x1.detach())
+        torch.cuda.current_stream().wait_stream(side)
+        assert G.STATS["eager"] == eager0 + 1 and torch.equal(y3, r1)
+
+
+def _pretrainer(graphs_on, steps, seed=7):
+    from coin_amd import graphs as G
+    from coin_amd.config import get_cfg
+    from coin_amd.engine import PRETrainer
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(root, "configs", "coin", "PRETRAINS", "CLIPDET_synthetic.yaml"))
+    cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", 1, "AMD.SYNTHETIC.NUM_IMAGES", 1, "AMD.COMPUTE_DTYPE", "bf16", "AMD.TEXT_TEMPLATES", 2,
+                         "MODEL.DEVICE", "cuda:0", "AMD.STEP_GRAPHS", graphs_on, "AMD.SYNTHETIC.HEIGHT", 608, "AMD.SYNTHETIC.WIDTH", 800])
+    torch.manual_seed(seed)
+    tr = PRETrainer(cfg)
+    with torch.no_grad():
+        for n, p in tr.model.named_parameters():
+            if n.endswith("bn3.weight"):
+                p.fill_(0.5)
+    torch.manual_seed(seed + 1)
+    s0 = dict(G.STATS)
+    recs = [{k: float(v) for k, v in tr.run_step().items()} for _ in range(steps)]
+    return tr, recs, {k: G.STATS[k] - s0[k] for k in s0}
+
+
+def test_pretrain_steps_with_step_graphs_track_the_eager_run():
+    """PRETrainer (RN50, 608x800, 2 views, 512 RoIs/view, bf16) for 7 steps from the same seeds with cfg.AMD.STEP_GRAPHS on and off:
+    both stretches are captured at their third call and replayed from then on; the loss trajectories agree to the run-to-run noise of
+    the library convolutions that remain in the step (calibrated by a second eager run), parameters move, running statistics follow."""
+    steps = 7
+    _, eager, st0 = _pretrainer(False, steps)
+    _, eager2, _ = _pretrainer(False, steps)
+    tr, graphed, st = _pretrainer(True, steps)
+    assert st0["captures"] == 0 and st0["replays"] == 0
+    assert st["captures"] == 2 and st["replays"] == 2 * (steps - 2), st
+    for i in range(steps):
+        assert set(eager[i]) == set(graphed[i])
+        for k in eager[i]:
+            assert np.isfinite(graphed[i][k])
+            noise = abs(eager[i][k] - eager2[i][k])
+            assert abs(eager[i][k] - graphed[i][k]) <= 4 * noise + 2e-2 * max(1.0, abs(eager[i][k])), (i, k, eager[i][k], eager2[i][k], graphed[i][k])
+    bn = tr.model.backbone.encoder.visual.layer3[0].bn1
+    assert int(bn.num_batches_tracked) == steps and float(bn.running_mean.abs().sum()) > 0
+    assert int(tr.model.backbone.encoder.visual.layer4[0].bn1.num_batches_tracked) == steps

@@ -67,7 +67,8 @@ struct Shape {
 
 static const Shape kShapes[] = {{"l4.0.conv1", 2048, 14, 14, 1024, 512, 1}, {"l4.0.conv2", 2048, 14, 14, 512, 512, 3}, {"l4.0.conv3", 2048, 7, 7, 512, 2048, 1},
                                 {"l4.0.down", 2048, 7, 7, 1024, 2048, 1},   {"l4.1.conv1", 2048, 7, 7, 2048, 512, 1},  {"l4.1.conv2", 2048, 7, 7, 512, 512, 3},
-                                {"rpn.conv", 4, 50, 83, 1024, 1024, 3},     {"l3.x.conv2", 4, 50, 83, 256, 256, 3}};   // backbone-resolution convolutions
+                                {"rpn.conv", 4, 50, 83, 1024, 1024, 3},     {"l3.x.conv2", 4, 50, 83, 256, 256, 3},    // backbone-resolution convolutions
+                                {"l2.x.conv2", 4, 100, 167, 128, 128, 3},   {"l2.x.conv1", 4, 100, 167, 512, 128, 1}};  // N = 128: a half-width column tile (round 5)
 
 static void* g_ws = nullptr;
 static size_t g_ws_bytes = 0;
@@ -217,11 +218,11 @@ static void bench_shape(const Shape& sh, int iters, int rounds) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     constexpr int NV = 5;
-    const int impls[NV] = {1, 1, 1, 1, 1};
+    const int impls[NV] = {1, 2, 1, 2, 1};   // 2 = the round-2 kernels (256x256x32 where N % 256 == 0, else the 256x128 kernel that served N = 128 until round 5)
     const bool stats[NV] = {false, false, true, true, false};
     const int splits[NV] = {-1, -1, -1, -1, 0};
-    const int stags[NV] = {-1, 0, -1, 0, -1};
-    const char* names[NV] = {"p8", "p8nostag", "p8+stats", "p8+stats_nostag", "p8nosplit"};
+    const int stags[NV] = {-1, -1, -1, -1, -1};
+    const char* names[NV] = {"p8", "r2", "p8+stats", "r2+stats", "p8nosplit"};
     std::vector<float> best(NV, 1e30f), med[NV];
     for (int r = 0; r < rounds; ++r)
       for (int v = 0; v < NV; ++v) {
@@ -444,6 +445,11 @@ int main(int argc, char** argv) {
     fails += check_case("splitK 3x3 14x14", 196 * 700, 512, 4608, 1, 14, 14, 512, false, 196 * 700, 1);
     fails += check_case("fewer tiles than CUs 3x3 (default policy)", 4 * 50 * 83, 256, 2304, 1, 50, 83, 256, false, 4 * 50 * 83, -1);
     fails += check_case("RPN head 3x3 1024 (default policy)", 4 * 50 * 83, 1024, 9216, 1, 50, 83, 1024, true, 0, -1);
+    // round 5: N % 256 == 128 -- the last column tile has no upper B half (layer2's 128-channel convolutions ran on the 256x128 kernel before)
+    fails += check_case("N=128 1x1 + stats", 4 * 100 * 167, 128, 512, 0, 0, 0, 0, false, 4 * 100 * 167, 0);
+    fails += check_case("N=128 3x3 + R + stats prefix", 4 * 100 * 167, 128, 9 * 128, 1, 100, 167, 128, true, 3 * 100 * 167, 0);
+    fails += check_case("N=384 1x1 tail rows + R", 256 * 20 + 50, 384, 256, 0, 0, 0, 0, true, 0, 0);
+    fails += check_case("N=128 splitK forced", 256 * 257 + 9, 128, 2048, 0, 0, 0, 0, false, 256 * 257 + 9, 1);
     printf("CHECK total failures: %d\n", fails);
   }
   if (!strcmp(what, "wcheck") || !strcmp(what, "all")) {
@@ -456,7 +462,10 @@ int main(int argc, char** argv) {
   }
   if (getenv("LAB_DBG")) coin_p8_debug = atoi(getenv("LAB_DBG"));   // e.g. 4: main loops without the epilogue
   if (!strcmp(what, "bench") || !strcmp(what, "all")) {
-    for (const Shape& s : kShapes) bench_shape(s, iters, g_cold ? 2 : 5);
+    for (const Shape& s : kShapes) {
+      if (getenv("LAB_SHAPES") && !strstr(getenv("LAB_SHAPES"), s.name)) continue;
+      bench_shape(s, iters, g_cold ? 2 : 5);
+    }
   }
   if (!strcmp(what, "dbg")) bench_debug(iters);
   if (!strcmp(what, "stamps")) {
