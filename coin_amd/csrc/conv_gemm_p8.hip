@@ -1046,7 +1046,10 @@ static constexpr int coin_p8_debug = 0, coin_p8_stagger = -1, coin_p8_splitk = -
 #endif
 
 bool coin_p8_nt_ok(int M, int N, int K, int mode, int Cin, int lda, int ldb) {
-  if (M <= 0 || N % 128 || K % PK || K < 2 * PK) return false;   // N % 256 == 128: a half-width last column tile (p8_has_bhi)
+  // N % 256 == 128: a half-width last column tile (p8_has_bhi).  N = 128 itself stays on the 256 x 128 kernel of conv_gemm.hip: one column
+  // tile with half of its MFMA phases empty ran layer2's 128-channel convolutions SLOWER than that kernel (tools/gemm_lab, round 5:
+  // 3x3 [66 800 x 128 x 1152] 0.057 vs 0.045 ms, 1x1 K = 512 0.0265 vs 0.0234 ms -- 261 row tiles are two rounds on 256 CUs either way)
+  if (M <= 0 || N % 128 || N < 256 || K % PK || K < 2 * PK) return false;
   if ((size_t)M * (mode == 1 ? Cin : lda) * 2 >= 0x7f000000ull || (size_t)N * ldb * 2 >= 0x7f000000ull) return false;  // 32-bit buffer offsets
   if (mode == 1 && (Cin % PK || K != 9 * Cin)) return false;
   return true;
@@ -1067,7 +1070,7 @@ static void p8_nt_plan(int ntiles, int nk, int G, bool have_ws, int force, int& 
 }
 
 size_t coin_p8_nt_workspace_bytes(int M, int N, int K) {
-  if (M <= 0 || N % 128 || K % PK) return 0;
+  if (M <= 0 || N % 128 || N < 256 || K % PK) return 0;
   const int ntiles = ((M + PM - 1) / PM) * ((N + PN - 1) / PN), G = p8_grid(1 << 30);
   int whole, rem, split;
   p8_nt_plan(ntiles, K / PK, G, true, 1, whole, rem, split);   // upper bound: as if forced on

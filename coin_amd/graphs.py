@@ -30,6 +30,7 @@ eager for good (same kernels either way).
 from __future__ import annotations
 
 import os
+import time
 import warnings
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -41,7 +42,7 @@ from . import layers as L
 ENABLED = {"on": os.environ.get("COIN_STEP_GRAPHS", "1") != "0"}
 WARM_CALLS = 2          # eager calls of a shape before it is captured
 MAX_GRAPHS = 3          # shapes per segment (real data: a few padded sizes); further shapes stay eager
-STATS = {"captures": 0, "replays": 0, "eager": 0, "busy": 0}
+STATS = {"captures": 0, "replays": 0, "eager": 0, "busy": 0, "launch_ms": 0.0}   # launch_ms: host time spent inside hipGraphLaunch
 CAPTURE_MODE = {"fwd": "thread_local", "bwd": "thread_local"}   # other threads (image decoding) may touch the device meanwhile
 
 
@@ -168,7 +169,9 @@ class _Replay(torch.autograd.Function):
         for s, x in zip(ent.static_in, args[:n_in]):
             if s.data_ptr() != x.data_ptr():
                 s.copy_(x)
+        t0 = time.perf_counter()
         ent.fwd.replay()
+        STATS["launch_ms"] += (time.perf_counter() - t0) * 1e3
         ctx.ent = ent
         ctx.n_in = n_in
         outs = tuple(o.detach() for o in ent.outs)
@@ -190,7 +193,9 @@ class _Replay(torch.autograd.Function):
                 s.zero_()
             elif s.data_ptr() != g.data_ptr():
                 s.copy_(g)
+        t0 = time.perf_counter()
         ent.bwd.replay()
+        STATS["launch_ms"] += (time.perf_counter() - t0) * 1e3
         ent.busy = False
         gin = tuple(None if g is None else g.detach() for g in ent.grads_in)
         gp = []

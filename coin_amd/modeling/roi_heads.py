@@ -131,7 +131,8 @@ class OpenVocabularyRes5ROIHeads(nn.Module):
         """`_pooled_rows` through a `GraphedSegment` (coin_amd/graphs.py) during training on the GPU: RoIAlign -> res5 -> mean pool is a fixed
         launch sequence for a given (feature map shape, RoI count)."""
         if not (self.step_graphs and self.training and torch.is_grad_enabled() and self.pooling_type == "meanpool" and len(self.in_features) == 1
-                and rois.is_cuda and rois.shape[0] > 0 and isinstance(res5, torch.nn.Sequential)):
+                and rois.is_cuda and rois.shape[0] > 0 and isinstance(res5, torch.nn.Sequential) and L._VALID_ROWS[0] is None):
+            # (a padded pass -- the C boxes, whose count changes every step -- stays eager: each (count, padding) pair would be its own graph)
             return self._pooled_rows(features, rois, res5, attnpool)
         if self._trunk_segs is None:
             self._trunk_segs = {}

@@ -29,6 +29,56 @@ CLIP_MEAN = [0.48145466, 0.4578275, 0.40821073]   # coin/config.py:59
 CLIP_STD = [0.26862954, 0.26130258, 0.27577711]   # coin/config.py:60
 
 
+# --------------------------------------------------------------------------- storage-rounding emulation (bf16 throughput mode)
+# The product's bf16 mode keeps fp32 masters and accumulates in fp32, but STORES activations, weights' compute copies and the outputs
+# of its GEMM convolutions in bf16.  `emulate_rounding(torch.bfloat16)` makes this oracle -- run in fp64 -- round at exactly those
+# points (coin_amd/layers.py: conv inputs / weight shadows / outputs, the fused BatchNorm + residual + ReLU (+ pool / mean) stores, the
+# box head's linear layers), with a straight-through gradient: the forward is then the function the bf16 kernels compute up to
+# accumulation order, and an output that differs from it by more than a few bf16 ulps is a kernel error, not "bf16 noise".
+# (The backward's own roundings -- gradients are stored in bf16 too -- are not emulated: gradients agree to ~1e-2, not to an ulp.)
+ROUND = {"dtype": None}
+
+
+class _RoundSTE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        return x.to(dtype).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def rnd(x):
+    return x if ROUND["dtype"] is None else _RoundSTE.apply(x, ROUND["dtype"])
+
+
+class emulate_rounding:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.prev, ROUND["dtype"] = ROUND["dtype"], self.dtype
+
+    def __exit__(self, *a):
+        ROUND["dtype"] = self.prev
+        return False
+
+
+def _conv(conv: nn.Conv2d, x):
+    """conv(x); under `emulate_rounding`: operands and result rounded (the input normally already is)."""
+    if ROUND["dtype"] is None:
+        return conv(x)
+    return rnd(F.conv2d(rnd(x), rnd(conv.weight), None if conv.bias is None else conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups))
+
+
+def _linear(lin: nn.Linear, x, round_out=True):
+    if ROUND["dtype"] is None:
+        return lin(x)
+    y = F.linear(rnd(x), rnd(lin.weight), lin.bias)      # bias added in the fp32 accumulator, before the store
+    return rnd(y) if round_out else y
+
+
 # --------------------------------------------------------------------------- backbone (A2)
 class Bottleneck(nn.Module):
     """coin/modeling/utils.py:26-90: 1x1 -> 3x3 -> avgpool(stride) -> 1x1, anti-aliased shortcut."""
@@ -55,12 +105,30 @@ class Bottleneck(nn.Module):
                 ("1", nn.BatchNorm2d(out)),
             ]))
 
-    def forward(self, x):
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.relu(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(self.avgpool(y)))
-        sc = x if self.downsample is None else self.downsample(x)
-        return self.relu(y + sc)
+    def forward(self, x, mean_pool: bool = False):
+        """mean_pool (the RoI head's last block, clip_roi_heads.py:207-208): the spatial mean [N, C, 1, 1] of the output."""
+        if ROUND["dtype"] is None:
+            y = self.relu(self.bn1(self.conv1(x)))
+            y = self.relu(self.bn2(self.conv2(y)))
+            y = self.bn3(self.conv3(self.avgpool(y)))
+            sc = x if self.downsample is None else self.downsample(x)
+            out = self.relu(y + sc)
+            return out.mean(dim=[2, 3], keepdim=True) if mean_pool else out
+        # the product's stores (coin_amd/modeling/backbone.py:Bottleneck.forward + layers.conv_bn_act): every convolution output; BatchNorm +
+        # ReLU fused with the anti-aliasing pool (the kernel rounds the un-pooled value "as nn.AvgPool2d sees it", then the pooled one --
+        # found with tools/round_debug.py: every other stage matched to 2e-5, this one to 2e-3 until the oracle rounded twice as well);
+        # the downsample branch's pooled input, convolution and norm;
+        # bn3 + identity + ReLU in one store -- or, for the last block of the RoI head, only the spatial mean of it
+        x = rnd(x)
+        y = rnd(self.relu(self.bn1(_conv(self.conv1, x))))
+        y = rnd(self.avgpool(rnd(self.relu(self.bn2(_conv(self.conv2, y))))))   # coin_bn_apply_fwd rounds the un-pooled activation, then pools
+        z = _conv(self.conv3, y)
+        if self.downsample is None:
+            sc = x
+        else:
+            sc = rnd(self.downsample[2](_conv(self.downsample[1], rnd(self.downsample[0](x)))))
+        out = self.relu(self.bn3(z) + sc)
+        return rnd(out.mean(dim=[2, 3], keepdim=True)) if mean_pool else rnd(out)
 
 
 class ModifiedResNet(nn.Module):
@@ -399,10 +467,18 @@ class BoxPredictor(nn.Module):
 
     # ---- forward (fast_rcnn.py:318-353)
     def forward(self, x, branch, return_feats=True):
-        x = self.trans(torch.flatten(x, start_dim=1))
-        feats = self.cls_score(x)
+        if ROUND["dtype"] is None:
+            x = self.trans(torch.flatten(x, start_dim=1))
+            feats = self.cls_score(x)
+            deltas = self.bbox_pred(x)
+        else:   # coin_amd/modeling/fast_rcnn.py:forward in the bf16 mode: five linear layers on coin_gemm_nt, bf16 stores except the fp32 deltas
+            t = self.trans
+            h = rnd(F.leaky_relu(_linear(t[0], torch.flatten(x, start_dim=1), round_out=False), 0.01))
+            h = rnd(F.leaky_relu(_linear(t[2], h, round_out=False), 0.01))
+            x = _linear(t[4], h)
+            feats = _linear(self.cls_score, x)
+            deltas = _linear(self.bbox_pred, x, round_out=False)
         scores = self.do_classify(feats, branch)
-        deltas = self.bbox_pred(x)
         if return_feats and self.training and branch != "test":
             return scores, deltas, feats
         return scores, deltas

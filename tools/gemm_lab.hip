@@ -446,10 +446,10 @@ int main(int argc, char** argv) {
     fails += check_case("fewer tiles than CUs 3x3 (default policy)", 4 * 50 * 83, 256, 2304, 1, 50, 83, 256, false, 4 * 50 * 83, -1);
     fails += check_case("RPN head 3x3 1024 (default policy)", 4 * 50 * 83, 1024, 9216, 1, 50, 83, 1024, true, 0, -1);
     // round 5: N % 256 == 128 -- the last column tile has no upper B half (layer2's 128-channel convolutions ran on the 256x128 kernel before)
-    fails += check_case("N=128 1x1 + stats", 4 * 100 * 167, 128, 512, 0, 0, 0, 0, false, 4 * 100 * 167, 0);
-    fails += check_case("N=128 3x3 + R + stats prefix", 4 * 100 * 167, 128, 9 * 128, 1, 100, 167, 128, true, 3 * 100 * 167, 0);
+    fails += check_case("N=384 1x1 + stats", 4 * 100 * 167, 384, 512, 0, 0, 0, 0, false, 4 * 100 * 167, 0);
+    fails += check_case("N=384 3x3 + R + stats prefix", 4 * 50 * 83, 384, 9 * 128, 1, 50, 83, 128, true, 3 * 50 * 83, 0);
     fails += check_case("N=384 1x1 tail rows + R", 256 * 20 + 50, 384, 256, 0, 0, 0, 0, true, 0, 0);
-    fails += check_case("N=128 splitK forced", 256 * 257 + 9, 128, 2048, 0, 0, 0, 0, false, 256 * 257 + 9, 1);
+    fails += check_case("N=640 splitK forced", 256 * 103 + 9, 640, 2048, 0, 0, 0, 0, false, 256 * 103 + 9, 1);
     printf("CHECK total failures: %d\n", fails);
   }
   if (!strcmp(what, "wcheck") || !strcmp(what, "all")) {

@@ -113,3 +113,12 @@ for i in range(20):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 20
 say(f"RESULT mode={mode} ms_per_step={dt * 1e3:.2f} views_per_s={4 / dt:.1f} host_ms_median={sorted(hs)[10]:.1f}", G.STATS)
+# pure host enqueue time: the device is idle when a step starts, nothing throttles the host
+hs, l0 = [], G.STATS["launch_ms"]
+for i in range(10):
+    torch.cuda.synchronize()
+    th = time.perf_counter()
+    tr.run_step()
+    hs.append((time.perf_counter() - th) * 1e3)
+torch.cuda.synchronize()
+say(f"HOST mode={mode} enqueue_ms_median={sorted(hs)[5]:.1f} min={min(hs):.1f} graph_launch_ms_per_step={(G.STATS['launch_ms'] - l0) / 10:.2f}")

@@ -18,10 +18,12 @@ ap.add_argument("--list", default=None, help="also list every dispatch whose nam
 ap.add_argument("--list-ms", type=float, default=45.0)
 a = ap.parse_args()
 rows = []
+queues = []
 with open(a.trace) as f:
     r = csv.DictReader(f)
     for row in r:
         rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), row["Kernel_Name"]))
+        queues.append(row.get("Queue_Id", "?"))
 end = max(e for _, e, _ in rows)
 lo = end - int(a.window_ms * 1e6)
 agg = collections.defaultdict(lambda: [0, 0])
@@ -38,6 +40,24 @@ with open(a.out, "w") as f:
     for n, (c, t) in items:
         w.writerow([n[:160], c, t, t // c, f"{100.0*t/busy:.2f}"])
 print(f"window {a.window_ms} ms: busy {busy/1e6:.1f} ms over {len(items)} kernels")
+# time during which at least one kernel runs (overlapping streams counted once), the idle remainder, and the share per hardware queue
+iv = sorted((max(s, lo), e) for s, e, _ in rows if e > lo)
+union, cur_s, cur_e = 0, None, None
+for s, e in iv:
+    if cur_e is None or s > cur_e:
+        if cur_e is not None:
+            union += cur_e - cur_s
+        cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+if cur_e is not None:
+    union += cur_e - cur_s
+perq = collections.defaultdict(int)
+for (s, e, _), q in zip(rows, queues):
+    if s >= lo:
+        perq[q] += e - s
+print(f"device occupied (union over streams) {union/1e6:.1f} ms = {100.0*union/(a.window_ms*1e6):.1f}% of the window; idle {a.window_ms - union/1e6:.1f} ms; "
+      f"kernel time per hardware queue: " + ", ".join(f"q{q}: {t/1e6:.1f} ms" for q, t in sorted(perq.items(), key=lambda kv: -kv[1])[:6]))
 for n, (c, t) in items[:40]:
     print(f"{t/1e6:8.2f} ms {100.0*t/busy:5.1f}% n={c:5d} avg={t/c/1e3:9.1f}us {n[:100]}")
 
