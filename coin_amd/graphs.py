@@ -8,9 +8,13 @@ stretches whose launch sequence depends on tensor SHAPES only, never on the targ
 
 Everything in between (RPN head, proposal selection, NMS, the samplers, the losses) depends on per-image target counts that are host
 integers and stays eager.  A ``GraphedSegment`` wraps one stretch: the first calls of a shape run eagerly (library solver searches,
-workspace growth), then the forward is captured as one HIP graph and -- through ``torch.autograd.grad`` under capture, as
-``torch.cuda.make_graphed_callables`` does -- its backward as a second one sharing the memory pool.  A call then costs the host three
-launches (copy-in, replay) instead of hundreds, and autograd sees ONE node whose backward replays the second graph.
+workspace growth), then the forward is captured as one HIP graph and its backward as a second one sharing the memory pool.  The backward
+is recorded by walking the autograd graph node by node ON THE CAPTURING THREAD (`_backward_on_this_thread`), not by the autograd engine:
+the engine runs device work on its own worker thread and, for a leaf whose gradient accumulator is still alive from an earlier eager
+step, makes the default stream wait on the capturing stream -- which ended in a segmentation fault inside hipStreamEndCapture on this
+runtime even for a bare nn.Linear.  A call then costs the host three launches (copy-in, replay) instead of hundreds (measured: 23.0 ->
+12.2 ms of host enqueue per pre-train step, 0.2 ms of it inside hipGraphLaunch), and autograd sees ONE node whose backward replays the
+second graph.
 
 Rules the capture keeps (each one is there because its absence produced a wrong result or a failed capture):
 * graphs are replayed on the device's default stream only (a graph launched from a side stream serialised the whole step on this
@@ -19,6 +23,11 @@ Rules the capture keeps (each one is there because its absence produced a wrong 
   twice per forward) runs eagerly, it would overwrite the activations the pending backward reads;
 * the data-gradient weight layouts (layers.dgrad_weight) are refreshed eagerly BEFORE a backward capture / replay: captured, the
   refresh would not execute while the host-side stamp says it did;
+* before a capture the stretch is run once, forward and backward, on the capturing thread (its MIOpen handle has never loaded the
+  backward kernels of the library convolutions that remain in the stretch -- the eager backward ran on the engine's thread -- and loading
+  a code object during a capture fails with miopenStatusUnknownError); the running statistics that run advances are put back;
+* only passes whose shapes are fixed by construction are captured (a padded pass -- the C boxes of step_one / step_two, whose count
+  changes every step -- stays eager);
 * BatchNorm running statistics and `num_batches_tracked` are updated by kernels inside the graph: replays update them in place;
 * parameter gradients: the backward graph writes them into static buffers.  Without gradient hooks on a parameter (single GPU) the
   static buffer itself becomes ``p.grad`` (stable pointers: the optimizer's device table is uploaded once); with hooks (the
@@ -32,6 +41,7 @@ from __future__ import annotations
 import os
 import time
 import warnings
+import weakref
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -46,7 +56,7 @@ STATS = {"captures": 0, "replays": 0, "eager": 0, "busy": 0, "launch_ms": 0.0}  
 CAPTURE_MODE = {"fwd": "thread_local", "bwd": "thread_local"}   # other threads (image decoding) may touch the device meanwhile
 
 
-_SEGMENTS: "List[GraphedSegment]" = []
+_SEGMENTS: "weakref.WeakSet[GraphedSegment]" = weakref.WeakSet()   # weak: a dropped model must release its graphs' memory pools
 
 
 def set_enabled(flag: bool) -> None:
@@ -56,7 +66,7 @@ def set_enabled(flag: bool) -> None:
 def step_done() -> None:
     """End of an optimizer step: no backward is pending any more.  A segment whose forward ran under grad mode but whose output never
     reached a backward (an exception, a discarded pass) would otherwise stay busy -- i.e. eager -- for ever."""
-    for seg in _SEGMENTS:
+    for seg in list(_SEGMENTS):
         for ent in seg.graphs.values():
             ent.busy = False
 
@@ -239,7 +249,7 @@ class GraphedSegment:
         self.graphs: Dict[tuple, _Entry] = {}
         self.seen: Dict[tuple, int] = {}
         self.failed = False
-        _SEGMENTS.append(self)
+        _SEGMENTS.add(self)
 
     # ---------------------------------------------------------------- eligibility
     def _eligible(self, inputs) -> bool:

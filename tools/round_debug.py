@@ -50,3 +50,20 @@ with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
     outm = L.bn_act(z3, seeded.fill_module(Bottleneck(1024, 512, 2), 7).cuda().train().bn3, True, sx, 0, stats_part=(part3, 64 * 49))
     om = R(torch.relu(ob.bn3(z3.double().cpu()) + sx.double().cpu()).mean(dim=[2, 3], keepdim=True))
     print("mean-pool tail given the product's inputs", l2(outm, om), "equal fraction", float((outm.double().cpu() == om).double().mean()))
+
+# ---- whole blocks: the product's Bottleneck.forward against the oracle's emulated forward on the same (bf16) input
+def whole(inpl, planes, stride, hw, seed, mean_pool=False):
+    pb = seeded.fill_module(Bottleneck(inpl, planes, stride), seed).cuda().to(memory_format=torch.channels_last).train()
+    oo = seeded.fill_module(OC.Bottleneck(inpl, planes, stride), seed).double().train()
+    xi = seeded.randn((64, inpl, hw, hw), seed + 100)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        yp = pb(xi.cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last), mean_pool=mean_pool)
+    with torch.no_grad(), OC.emulate_rounding(torch.bfloat16):
+        yo = oo(xi.double(), mean_pool=mean_pool)
+    with torch.no_grad():
+        yplain = seeded.fill_module(OC.Bottleneck(inpl, planes, stride), seed).double().train()(xi.double(), mean_pool=mean_pool)
+    print(f"whole block {inpl}->{planes} stride {stride} mean_pool={mean_pool}: product vs emulated oracle L2 {l2(yp, yo):.2e} (equal fraction {float((yp.double().cpu() == yo).double().mean()):.4f}); vs plain fp64 {l2(yp, yplain):.2e}")
+
+whole(1024, 512, 2, 14, 7)
+whole(2048, 512, 1, 7, 8)
+whole(2048, 512, 1, 7, 9, mean_pool=True)
