@@ -278,9 +278,15 @@ class GraphedSegment:
             if n <= WARM_CALLS or len(self.graphs) >= MAX_GRAPHS:
                 STATS["eager"] += 1
                 return self.fn(*inputs)
-            try:
+            rng = torch.cuda.get_rng_state(inputs[0].device)   # a capture registers the generator with the graph and moves its offset: the
+            try:                                                 # samplers' draws of the following eager code must not depend on it
                 ent = self._capture(inputs)
+                torch.cuda.set_rng_state(rng, inputs[0].device)
             except Exception as e:   # same kernels either way
+                try:
+                    torch.cuda.set_rng_state(rng, inputs[0].device)
+                except Exception:
+                    pass
                 warnings.warn(f"step graph '{self.name}': capture failed ({type(e).__name__}: {e}); this stretch stays eager")
                 self.failed = True
                 _recover_from_failed_capture()

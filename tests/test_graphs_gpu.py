@@ -178,3 +178,51 @@ def test_pretrain_steps_replay_both_stretches_and_a_replayed_step_equals_the_eag
     for n in names:
         noise = l2(e2[1][n], e1[1][n])
         assert l2(g[1][n], e1[1][n]) <= 4 * noise + 1e-2, (n, noise, l2(g[1][n], e1[1][n]))
+
+
+def test_training_with_step_graphs_follows_the_eager_training_step_by_step():
+    """Two PRETrainers from one seed, cfg.AMD.STEP_GRAPHS on and off, 8 optimizer steps with the device generator re-seeded before every
+    step (so that both draw the same anchor / RoI samples whatever a capture does to the generator): the loss trajectories must stay
+    together -- a stretch that replayed stale weights, dropped a gradient or mixed up a buffer would drive loss_cls (2.40 -> 1.74 over ten
+    steps in every run) apart within a step or two -- and the weights after eight updates agree as two eager runs do."""
+    from coin_amd import graphs as G
+    from coin_amd.config import get_cfg
+    from coin_amd.engine import PRETrainer
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+    def run(graphs_on, steps=8):
+        cfg = get_cfg()
+        cfg.merge_from_file(os.path.join(root, "configs", "coin", "PRETRAINS", "CLIPDET_synthetic.yaml"))
+        cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", 1, "AMD.SYNTHETIC.NUM_IMAGES", 1, "AMD.COMPUTE_DTYPE", "bf16", "AMD.TEXT_TEMPLATES", 2,
+                             "MODEL.DEVICE", "cuda:0", "AMD.STEP_GRAPHS", graphs_on, "AMD.SYNTHETIC.HEIGHT", 608, "AMD.SYNTHETIC.WIDTH", 800])
+        torch.manual_seed(21)
+        tr = PRETrainer(cfg)
+        with torch.no_grad():
+            for n, p in tr.model.named_parameters():
+                if n.endswith("bn3.weight"):
+                    p.fill_(0.5)
+        s0, out = dict(G.STATS), []
+        for i in range(steps):
+            torch.manual_seed(1000 + i)
+            out.append({k: float(v) for k, v in tr.run_step().items()})
+        w = {n: p.detach().float().clone() for n, p in tr.model.named_parameters() if n in WATCH}
+        return out, w, G.STATS["replays"] - s0["replays"]
+
+    WATCH = ("backbone.encoder.visual.layer3.0.conv2.weight", "backbone.encoder.visual.layer4.1.conv1.weight", "proposal_generator.rpn_head.conv.weight",
+             "roi_heads.box_predictor.trans.0.weight")
+    e1, w1, r1 = run(False)
+    e2, w2, _ = run(False)
+    g, wg, rg = run(True)
+    assert r1 == 0 and rg == 2 * 6
+    # run-to-run spread of this step, measured over four separate processes (tools/traj_probe.py; proposals of a random-init RPN are decided by
+    # noise in the last bits of the library convolutions): loss_box_reg +-4 % from the first step on, the other terms +-2 %
+    for i in range(8):
+        for k in e1[i]:
+            noise = abs(e1[i][k] - e2[i][k])
+            tol = (8e-2 if k == "loss_box_reg" else 3e-2) * max(1.0, abs(e1[i][k]))
+            assert abs(g[i][k] - e1[i][k]) <= 5 * noise + tol, (i, k, e1[i][k], e2[i][k], g[i][k])
+    for n in WATCH:   # the weights after 8 updates: as close to the eager run's as a second eager run's are (x5) or 1e-3 of their scale
+        d_noise = float((w2[n] - w1[n]).norm() / w1[n].norm())
+        d = float((wg[n] - w1[n]).norm() / w1[n].norm())
+        assert d <= 5 * d_noise + 1e-3, (n, d, d_noise)

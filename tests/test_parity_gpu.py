@@ -187,6 +187,7 @@ def test_real_width_res5_bf16_kernels_vs_the_storage_rounding_oracle():
                 h = n[1](n[0](xx.to(torch.bfloat16)))
                 return n[2](h, mean_pool=True).flatten(1).float()
         y, gx, grads, sd = RW.run_res5(net, x, gy, device=DEV, mean_pool=fwd)
+        sd = {k: v.detach().clone() for k, v in sd.items()}     # (state_dict() hands out the live buffers: the block-wise pass below moves them again)
     finally:
         L.CONV_GEMM.update(saved)
         K.conv_gemm, K.conv_wgrad = real_gemm, real_wgrad
@@ -235,8 +236,9 @@ def test_real_width_res5_bf16_kernels_vs_the_storage_rounding_oracle():
 
 def test_real_width_box_predictor_bf16_vs_the_storage_rounding_oracle():
     """The box head at D = 1024 / 512 RoIs in the bf16 mode (five linear layers on coin_gemm_nt with bf16 stores, cosine logits, the fused
-    loss kernels) against the fp64 oracle that rounds at the same stores: logits, deltas and losses an order of magnitude closer than the
-    5 % smoke bound, head gradients to 1e-2 (relative L2)."""
+    loss kernels) against the fp64 oracle that rounds at the same stores: logits within 3e-2 (of values up to 100), deltas 2e-3, losses
+    **1e-4**, head gradients 1e-2 in relative L2 and at most a quarter of their distance to the plain fp64 oracle (measured: losses 1e-5,
+    weight gradients 1e-4 ... 5e-4) -- the 1e-4 bar of the fp32 goldens, carried over to the mode the benchmark runs."""
     import real_width as RW
     from e2e_util import _inst
     from golden_util import instances
@@ -264,10 +266,10 @@ def test_real_width_box_predictor_bf16_vs_the_storage_rounding_oracle():
     print("\n".join(f"head bf16 grad {n:20s} L2 vs storage-rounding oracle {a:.2e}   vs plain fp64 {b:.2e}" for n, a, b in rows))
     assert ds <= 3e-2 and ds <= 0.5 * ds_plain, (ds, ds_plain)
     assert RW.l2_err(deltas, ed) <= 2e-3
-    for k, v in el.items():
-        assert abs(float(losses[k]) - v) <= 5e-3 * max(1.0, abs(v)), (k, float(losses[k]), v, plain[2][k])
-    for n, a, b in rows:
-        assert a <= 3e-2 and a <= b + 1e-4, (n, a, b)
+    for k, v in el.items():     # measured 1e-5 (the plain oracle: 7e-4 on loss_cls)
+        assert abs(float(losses[k]) - v) <= 1e-4 * max(1.0, abs(v)), (k, float(losses[k]), v, plain[2][k])
+    for n, a, b in rows:        # measured 1e-4 ... 5e-3 (input gradient), a tenth of the distance to the plain oracle
+        assert a <= 1e-2 and a <= 0.25 * b, (n, a, b)
 
 
 def test_rn101_trunk_and_ckg512_on_device_vs_reference_and_fp64():
