@@ -803,7 +803,8 @@ static int wgrad_slices(int M, int tiles) {
 }
 
 extern "C" size_t coin_conv_wgrad_workspace_bytes(int M, int Cout, int Ktot) {
-  if (M <= 0 || Cout <= 0 || Ktot <= 0 || Cout % WB || Ktot % WB) return 0;
+  if (M <= 0 || Cout <= 0 || Ktot <= 0 || Cout % 128 || Ktot % 128) return 0;
+  if (Cout % WB || Ktot % WB) return coin_p8_tn_workspace_bytes(M, Cout, Ktot);   // odd multiples of 128: the persistent kernel only
   const size_t sliced = (size_t)wgrad_slices(M, (Cout / WB) * (Ktot / WB)) * Cout * (size_t)Ktot * sizeof(float);
   const size_t p8 = coin_p8_tn_workspace_bytes(M, Cout, Ktot);  // either kernel may be selected at launch
   return sliced > p8 ? sliced : p8;
@@ -812,12 +813,13 @@ extern "C" size_t coin_conv_wgrad_workspace_bytes(int M, int Cout, int Ktot) {
 extern "C" int coin_conv_wgrad_bf16(const void* GY, const void* X, int mode, int H, int W, int Cin, int M, int Cout, int Ktot, float* dW,
                                     void* workspace, void* stream) {
   if (!GY || !X || !dW || !workspace || M <= 0 || Cout <= 0 || Cin <= 0 || (mode != 0 && mode != 1)) return COIN_EINVAL;
-  if (Cout % WB || Cin % WB) return COIN_ESHAPE;
+  if (Cout % 128 || Cin % 128) return COIN_ESHAPE;
   if (mode == 0 ? Ktot != Cin : (Ktot != 9 * Cin || H <= 0 || W <= 0 || M % (H * W))) return COIN_EINVAL;
   if (((uintptr_t)GY & 15) || ((uintptr_t)X & 15) || ((uintptr_t)dW & 15) || ((uintptr_t)workspace & 15)) return COIN_EALIGN;
   const bool use_old = coin_conv_gemm_force_impl ? coin_conv_gemm_force_impl != 1 : false;   // lab builds only
   if (!use_old && coin_p8_tn_ok(M, Cout, Cin, Ktot, mode))
     return coin_p8_tn_launch(GY, X, mode, H, W, Cin, M, Cout, Ktot, dW, workspace, (hipStream_t)stream);
+  if (Cout % WB || Cin % WB) return COIN_ESHAPE;   // the sliced kernel below needs whole 256 x 256 tiles
   const int tco = Cout / WB, tk = Ktot / WB;
   const int slices = wgrad_slices(M, tco * tk);
   int m_chunk = (M + slices - 1) / slices;

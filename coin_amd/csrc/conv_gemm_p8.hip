@@ -729,23 +729,30 @@ template <bool GATHER3>
 __device__ __forceinline__ void tn_set_pos(TnCursor<GATHER3>& c, const TnArgs& p, int tile, int kt, int wave, int lane) {
   const int tco = tile / p.tiles_k, tk = tile - tco * p.tiles_k;
   const int co0 = tco * 256, k0 = tk * 256;
-  int tap = 0, ci0 = k0;
+  c.tile = tile;
+  c.kt = kt;
+  // Channel counts that are multiples of 128 only (layer2 of the backbone): the last co / k tile is half valid, and a 3x3 K-tile of
+  // 256 spans TWO taps when Cin = 128.  Handled per LANE: a lane's 16-byte chunk lies in one tap (chunks 0-15 / 16-31; the swizzle only
+  // touches the low four bits of the chunk index, so both of a lane's rows share the tap), chunks beyond Cout / Ktot get an offset
+  // outside the buffer and arrive as zeros -- the MFMA work of the missing half is wasted, no byte of it is fetched.
+  const int hi = (lane & 31) >> 4;          // chunk index bit 4
+  const int kl = k0 + hi * 128;             // first k of this lane's 128-channel half of the K-tile
+  int tap = 0, cib = kl;
   c.dy = c.dx = 0;
   if (GATHER3) {
-    tap = k0 / p.Cin;
-    ci0 = k0 - tap * p.Cin;
+    tap = kl / p.Cin;
+    cib = kl - tap * p.Cin;
     c.dy = tap / 3 - 1;
     c.dx = tap % 3 - 1;
   }
-  c.tile = tile;
-  c.kt = kt;
+  const bool g_ok = co0 + hi * 128 < p.Cout, x_ok = kl < p.Ktot;
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const int row = (wave * 2 + e) * 2 + (lane >> 5);
     const int lc = (lane & 31) ^ tn_swz(row);
     const long long m = (long long)kt * 64 + row;
-    c.go[e] = (unsigned)((m * p.Cout + co0 + lc * 8) * 2);
-    c.xo[e] = (unsigned)(((m + c.dy * p.W + c.dx) * p.Cin + ci0 + lc * 8) * 2 + p.x_bias);  // >= 0: the bias covers the largest negative shift
+    c.go[e] = g_ok ? (unsigned)((m * p.Cout + co0 + lc * 8) * 2) : TN_OOB;
+    c.xo[e] = x_ok ? (unsigned)(((m + c.dy * p.W + c.dx) * p.Cin + cib + (lc & 15) * 8) * 2 + p.x_bias) : TN_OOB;  // >= 0: the bias covers the largest negative shift
     c.rem[e] = GATHER3 ? (int)(m % (p.H * p.W)) : 0;
   }
 }
@@ -994,8 +1001,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const TnArgs p) {
 
 // dW[co][k] = sum of the partial tiles of tile (tco, tk) in a fixed order (XCD segment, then sub-range).  One workgroup per 4 rows
 // of a tile (thread = 4 consecutive columns of one row); the partial list is walked 4 at a time so that 4 loads are in flight.
-__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Ktot, int tiles_k, int ntiles, int nkt,
-                                                        int cpx) {
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Ktot, int tiles_k, int ntiles,
+                                                        int nkt, int cpx) {
   const int tile = blockIdx.x >> 6, row = (blockIdx.x & 63) * 4 + (threadIdx.x >> 6);
   const int tco = tile / tiles_k, tk = tile - tco * tiles_k;
   const int grid = 8 * cpx, full = ntiles / cpx, r = ntiles - full * cpx;
@@ -1020,7 +1027,8 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 #pragma unroll
     for (int u = 0; u < 4; ++u) a += v[u];
   }
-  *reinterpret_cast<f32x4*>(dw + (size_t)(tco * 256 + row) * Ktot + tk * 256 + c4) = a;
+  if (tco * 256 + row < Cout && tk * 256 + c4 < Ktot)   // half-valid edge tiles (channel counts that are odd multiples of 128)
+    *reinterpret_cast<f32x4*>(dw + (size_t)(tco * 256 + row) * Ktot + tk * 256 + c4) = a;
 }
 
 }  // namespace
@@ -1136,8 +1144,8 @@ int coin_p8_nt_launch(const void* A, int lda, int mode, int H, int W, int Cin, c
 }
 
 static void tn_plan(int M, int Cout, int Ktot, TnArgs& a, int& grid) {
-  a.ntiles = (Cout / 256) * (Ktot / 256);
-  a.tiles_k = Ktot / 256;
+  a.tiles_k = (Ktot + 255) / 256;
+  a.ntiles = ((Cout + 255) / 256) * a.tiles_k;
   a.nkt = (M + 63) / 64;  // pixels beyond M read a zero page
   a.cpx = p8_grid(1 << 30) / 8;
   if (a.cpx < 1) a.cpx = 1;
@@ -1145,7 +1153,7 @@ static void tn_plan(int M, int Cout, int Ktot, TnArgs& a, int& grid) {
 }
 
 bool coin_p8_tn_ok(int M, int Cout, int Cin, int Ktot, int mode) {
-  if (M <= 0 || Cout % 256 || Cin % 256) return false;
+  if (M <= 0 || Cout % 128 || Cin % 128) return false;
   if (((size_t)M + 64 + 256) * (size_t)(Cout > Cin ? Cout : Cin) * 2 >= 0x7f000000ull) return false;  // 32-bit buffer offsets, TN_OOB beyond them
   return mode == 0 ? Ktot == Cin : Ktot == 9 * Cin;
 }
@@ -1179,6 +1187,6 @@ int coin_p8_tn_launch(const void* GY, const void* X, int mode, int H, int W, int
     if (!set1) { (void)hipFuncSetAttribute((const void*)conv_wgrad_p8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, P_IMG); set1 = true; }
     conv_wgrad_p8_kernel<false><<<grid, 512, P_IMG, st>>>(a);
   }
-  tn_reduce_kernel<<<a.ntiles * 64, 256, 0, st>>>(a.slab, dW, Ktot, a.tiles_k, a.ntiles, a.nkt, a.cpx);
+  tn_reduce_kernel<<<a.ntiles * 64, 256, 0, st>>>(a.slab, dW, Cout, Ktot, a.tiles_k, a.ntiles, a.nkt, a.cpx);
   return coin_launch_status();
 }

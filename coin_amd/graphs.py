@@ -26,6 +26,10 @@ Rules the capture keeps (each one is there because its absence produced a wrong 
 * before a capture the stretch is run once, forward and backward, on the capturing thread (its MIOpen handle has never loaded the
   backward kernels of the library convolutions that remain in the stretch -- the eager backward ran on the engine's thread -- and loading
   a code object during a capture fails with miopenStatusUnknownError); the running statistics that run advances are put back;
+* a captured stretch contains NO library convolution (layers._no_library_conv_under_capture; the model code wraps its stretches in
+  `layers.conv_gemm_everywhere` and offers only stages whose widths the hand-written kernels serve): replayed, the library's
+  backward-weights kernel accumulated onto a workspace that nothing inside the graph had zeroed -- 2e-2 relative error at the first
+  replay, 1e28 as soon as the allocation pattern of the process changed (tools/miopen_graph_probe.py);
 * only passes whose shapes are fixed by construction are captured (a padded pass -- the C boxes of step_one / step_two, whose count
   changes every step -- stays eager);
 * BatchNorm running statistics and `num_batches_tracked` are updated by kernels inside the graph: replays update them in place;
@@ -54,6 +58,7 @@ WARM_CALLS = 2          # eager calls of a shape before it is captured
 MAX_GRAPHS = 3          # shapes per segment (real data: a few padded sizes); further shapes stay eager
 STATS = {"captures": 0, "replays": 0, "eager": 0, "busy": 0, "launch_ms": 0.0}   # launch_ms: host time spent inside hipGraphLaunch
 CAPTURE_MODE = {"fwd": "thread_local", "bwd": "thread_local"}   # other threads (image decoding) may touch the device meanwhile
+TRACE: Optional[list] = None   # diagnostics (tools/bb_bisect.py): a list here receives (node, incoming gradients, results) of every captured backward node
 
 
 _SEGMENTS: "weakref.WeakSet[GraphedSegment]" = weakref.WeakSet()   # weak: a dropped model must release its graphs' memory pools
@@ -63,15 +68,28 @@ def set_enabled(flag: bool) -> None:
     ENABLED["on"] = bool(flag) and os.environ.get("COIN_STEP_GRAPHS", "1") != "0"
 
 
+# One capture per step, and none in a step that replays.  A capture synchronises the device, releases the allocator's cache
+# (torch.cuda.graph.__enter__) and runs the stretch three times (dry run, forward capture, backward capture): a stretch that is ready
+# announces it one step ahead (`_WANT_NEXT`); in the announced step every already captured stretch runs eagerly (`defer`), the first
+# ready stretch captures, the others wait another step.  (Introduced while a corruption of the backbone stretch was being hunted --
+# which turned out to be the library's weight-gradient kernel inside the graph, see layers._no_library_conv_under_capture -- and kept:
+# it keeps the expensive step to one capture and a replay's pending backward away from the cache release.)
+_STEP = {"captured": False, "replayed": False, "defer": False}
+_WANT_NEXT: set = set()
+
+
 def step_done() -> None:
-    """End of an optimizer step: no backward is pending any more.  A segment whose forward ran under grad mode but whose output never
-    reached a backward (an exception, a discarded pass) would otherwise stay busy -- i.e. eager -- for ever."""
+    """End of an optimizer step (the trainers call it after `optimizer.step()`): no backward is pending any more -- a segment whose forward
+    ran under grad mode but whose output never reached a backward would otherwise stay busy, i.e. eager, for ever -- and the capture
+    schedule advances (see `_STEP`)."""
     for seg in list(_SEGMENTS):
         for ent in seg.graphs.values():
             ent.busy = False
+    _STEP["captured"], _STEP["replayed"], _STEP["defer"] = False, False, bool(_WANT_NEXT)
+    _WANT_NEXT.clear()
 
 
-def _backward_on_this_thread(roots: Sequence[torch.Tensor], root_grads: Sequence[torch.Tensor], wrt: Sequence[torch.Tensor]):
+def _backward_on_this_thread(roots: Sequence[torch.Tensor], root_grads: Sequence[torch.Tensor], wrt: Sequence[torch.Tensor], trace=None):
     """d(roots)/d(wrt) by calling the autograd nodes one by one ON THE CALLING THREAD, in dependency order -- what
     ``torch.autograd.grad(roots, wrt, root_grads, allow_unused=True)`` computes, without the engine.
 
@@ -80,7 +98,8 @@ def _backward_on_this_thread(roots: Sequence[torch.Tensor], root_grads: Sequence
     engine makes the default stream wait for an event of the capturing stream -- an illegal dependency that ended in a segmentation fault
     inside hipStreamEndCapture (torch 2.10 / ROCm 7.0, reproduced with a bare nn.Linear).  Here every node runs on the capturing thread
     and stream, accumulator nodes are never executed (their incoming gradient IS the result), no cross-stream event is created.
-    Runs with grad mode and autocast off, as the engine's worker threads do."""
+    Runs with grad mode and autocast off, as the engine's worker threads do.  `trace`: a list that receives (node, incoming gradients,
+    results) per executed node (diagnostics)."""
     import collections
 
     leaf = {id(t): i for i, t in enumerate(wrt)}
@@ -154,6 +173,8 @@ def _backward_on_this_thread(roots: Sequence[torch.Tensor], root_grads: Sequence
                     outs = n(*args)
                 if not isinstance(outs, (tuple, list)):
                     outs = (outs,)
+                if trace is not None:
+                    trace.append((n, args, outs))
             for k, (nxt, idx) in enumerate(edges):
                 if nxt is None:
                     continue
@@ -275,9 +296,15 @@ class GraphedSegment:
         if ent is None:
             n = self.seen.get(key, 0) + 1
             self.seen[key] = n
-            if n <= WARM_CALLS or len(self.graphs) >= MAX_GRAPHS:
+            if n < WARM_CALLS or len(self.graphs) >= MAX_GRAPHS:
                 STATS["eager"] += 1
                 return self.fn(*inputs)
+            if n == WARM_CALLS or _STEP["captured"] or _STEP["replayed"]:
+                # ready from the next call on -- or ready now, but another stretch was captured / replayed in this step: announce and wait
+                _WANT_NEXT.add((id(self), key))
+                STATS["eager"] += 1
+                return self.fn(*inputs)
+            _STEP["captured"] = True
             rng = torch.cuda.get_rng_state(inputs[0].device)   # a capture registers the generator with the graph and moves its offset: the
             try:                                                 # samplers' draws of the following eager code must not depend on it
                 ent = self._capture(inputs)
@@ -294,9 +321,10 @@ class GraphedSegment:
                 return self.fn(*inputs)
             self.graphs[key] = ent
             STATS["captures"] += 1
-        if ent.busy:
-            STATS["busy"] += 1
-            return self.fn(*inputs)
+        if ent.busy or _STEP["defer"]:
+            STATS["busy" if ent.busy else "eager"] += 1
+            return self.fn(*inputs)     # (defer: another stretch captures in this step, nothing may be replayed around it)
+        _STEP["replayed"] = True
         STATS["replays"] += 1
         outs = _Replay.apply(ent, len(inputs), *inputs, *ent.params)
         # until this call's backward has replayed, the graph's buffers hold the activations it will read: a second call must not replay
@@ -332,8 +360,12 @@ class GraphedSegment:
         torch.cuda.synchronize()
         ent.pool = torch.cuda.graph_pool_handle()
         ent.fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ent.fwd, pool=ent.pool, capture_error_mode=CAPTURE_MODE["fwd"]):
-            out = self.fn(*ent.static_in)
+        L.STRICT_CAPTURE[0] = True     # a library convolution inside the stretch fails the capture (layers._no_library_conv_under_capture)
+        try:
+            with torch.cuda.graph(ent.fwd, pool=ent.pool, capture_error_mode=CAPTURE_MODE["fwd"]):
+                out = self.fn(*ent.static_in)
+        finally:
+            L.STRICT_CAPTURE[0] = False
         ent.single = torch.is_tensor(out)
         outs = (out,) if ent.single else tuple(out)
         ent.outs = outs
@@ -345,8 +377,12 @@ class GraphedSegment:
             wrt_in = [i for i, s in enumerate(ent.static_in) if s.requires_grad]
             wrt = [ent.static_in[i] for i in wrt_in] + list(ent.params)
             ent.bwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ent.bwd, pool=ent.pool, capture_error_mode=CAPTURE_MODE["bwd"]):
-                grads = _backward_on_this_thread(req, ent.static_gout, wrt)
+            L.STRICT_CAPTURE[0] = True
+            try:
+                with torch.cuda.graph(ent.bwd, pool=ent.pool, capture_error_mode=CAPTURE_MODE["bwd"]):
+                    grads = _backward_on_this_thread(req, ent.static_gout, wrt, trace=TRACE)
+            finally:
+                L.STRICT_CAPTURE[0] = False
             for j, i in enumerate(wrt_in):
                 ent.grads_in[i] = grads[j]
             ent.grads_p = list(grads[len(wrt_in):])

@@ -282,8 +282,14 @@ _RPOOL_UNSERVED: set = set()
 _WGRAD_WS: dict = {}
 
 
-def conv_wgrad_ok(cout: int, cin: int) -> bool:
-    return cout % 256 == 0 and cin % 256 == 0
+def conv_wgrad_ok(cout: int, cin: int, m: Optional[int] = None) -> bool:
+    """Channel counts coin_conv_wgrad_bf16 serves: multiples of 256, or -- on the persistent kernel, whose 32-bit buffer offsets bound
+    the pixel count `m` -- odd multiples of 128 (half-valid edge tiles)."""
+    if cout % 128 or cin % 128:
+        return False
+    if cout % 256 == 0 and cin % 256 == 0:
+        return True
+    return m is None or (m + 320) * max(cout, cin) * 2 < 0x7F000000
 
 
 def conv_wgrad(gy: torch.Tensor, x: torch.Tensor, spatial: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
@@ -297,7 +303,7 @@ def conv_wgrad(gy: torch.Tensor, x: torch.Tensor, spatial: Optional[Tuple[int, i
     ktot = cin if spatial is None else 9 * cin
     nbytes = _lib.lib().coin_conv_wgrad_workspace_bytes(m, cout, ktot)
     if nbytes == 0:
-        raise CoinHipError("conv_wgrad: Cout and Cin must be multiples of 256")
+        raise CoinHipError("conv_wgrad: Cout and Cin must be multiples of 128")
     key = (gy.device, _stream().value, nbytes)
     ws = _WGRAD_WS.get(key)  # one slab buffer per (stream, size), reused (calls on one stream are ordered)
     if ws is None:

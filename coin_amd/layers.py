@@ -206,8 +206,23 @@ def compute_dtype_of(x: torch.Tensor) -> torch.dtype:
     return x.dtype
 
 
+def _no_library_conv_under_capture(what: str) -> None:
+    """The library's convolutions must not be recorded into a HIP graph on this stack: replayed, single MIOpen launches (forward 1x1 on
+    the res4 map, the backward-weights kernels of the 128-channel convolutions) produced garbage as soon as the process state differed
+    from the capture's (another allocation pattern, an empty_cache(), a bare replay) -- measured with tools/bb_bisect.py and
+    tools/miopen_graph_probe.py, DESIGN.md section 3.17.  A stretch that is to be captured keeps every convolution on the hand-written
+    kernels (`conv_gemm_everywhere`); anything else fails the capture loudly and the stretch stays eager."""
+    if STRICT_CAPTURE[0] and torch.cuda.is_current_stream_capturing():
+        raise CoinHipError(f"{what}: a library convolution inside a captured stretch")
+
+
+STRICT_CAPTURE = [False]   # set by coin_amd.graphs around its captures
+
+
 def conv2d(x: torch.Tensor, conv: torch.nn.Conv2d) -> torch.Tensor:
     """conv(x) with the weight (and bias) taken from their compute-dtype shadows."""
+    if x.is_cuda:
+        _no_library_conv_under_capture("conv2d")
     dt = compute_dtype_of(x)
     if x.dtype != dt:
         x = x.to(dt)
@@ -221,6 +236,31 @@ def conv2d(x: torch.Tensor, conv: torch.nn.Conv2d) -> torch.Tensor:
 # the epilogue), the weight gradient through coin_conv_wgrad_bf16 (channel counts that are multiples of 256; the library's
 # contraction otherwise).  bf16 compute mode only: the fp32 parity mode keeps the library's fp32 convolutions.
 CONV_GEMM = {"enabled": False, "min_rows": 32768, "wgrad": True}
+
+
+class conv_gemm_everywhere:
+    """Inside: every convolution the hand-written GEMM can serve takes it, whatever its row count (a stretch that is replayed as a HIP
+    graph must not contain library convolutions, see `_no_library_conv_under_capture`)."""
+
+    def __enter__(self):
+        self.prev = CONV_GEMM["min_rows"]
+        CONV_GEMM["min_rows"] = 0
+
+    def __exit__(self, *a):
+        CONV_GEMM["min_rows"] = self.prev
+        return False
+
+
+def library_free(convs) -> bool:
+    """True when forward, data gradient and weight gradient of every convolution in `convs` run on the hand-written kernels (bf16 mode,
+    under `conv_gemm_everywhere`)."""
+    for c in convs:
+        ks = c.kernel_size
+        if ks not in ((1, 1), (3, 3)) or c.stride != (1, 1) or c.padding != (ks[0] // 2, ks[1] // 2) or c.dilation != (1, 1) or c.groups != 1:
+            return False
+        if c.bias is not None or c.in_channels % 64 or c.out_channels % 64 or not K.conv_wgrad_ok(c.out_channels, c.in_channels):
+            return False
+    return bool(CONV_GEMM["enabled"] and CONV_GEMM["wgrad"])
 
 
 def _conv_gemm_ok(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
@@ -308,11 +348,12 @@ def _conv_gemm_grads(x, wq, gyn, ks, need_dx, need_dw, g_tap=None, param=None, t
             gx, _ = K.conv_gemm(gyn.reshape(n * h * w, co), wd, spatial=(h, w, co) if ks == 3 else None, residual=res)
         dx = gx.view(n, h, w, ci).permute(0, 3, 1, 2)
     if need_dw:
-        if CONV_GEMM["wgrad"] and K.conv_wgrad_ok(co, ci):
+        if CONV_GEMM["wgrad"] and K.conv_wgrad_ok(co, ci, n * h * w):
             xn = _as_nhwc(x)
             dw2 = K.conv_wgrad(gyn.reshape(n * h * w, co), xn.reshape(n * h * w, ci), spatial=(h, w, ci) if ks == 3 else None)
             dw = dw2.view(co, ks, ks, ci).permute(0, 3, 1, 2)  # fp32, already in the parameter's channels-last layout
         else:
+            _no_library_conv_under_capture("weight gradient")
             dw = torch.ops.aten.convolution_backward(gyn.permute(0, 3, 1, 2), x, wq, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
                                                      [False, True, False])[1].float()
     return dx, dw

@@ -212,6 +212,19 @@ class ModifiedResNet(nn.Module):
                 x = stage(x)
         return {"res4": x}
 
+    def forward_stages(self, x, first: int, last: int) -> torch.Tensor:
+        """Stages first .. last (1 = stem, 2 = layer1, 3 = layer2, 4 = layer3) applied to x, the frozen ones without a graph -- the
+        piecewise form of `forward` (the trainers capture layer3 as a HIP graph and run the stages before it eagerly)."""
+        frozen_prefix = min(self.freeze_at, 4)
+        stages = [self._stem, self.layer1, self.layer2, self.layer3]
+        for i in range(first, last + 1):
+            if i <= frozen_prefix and not x.requires_grad:
+                with torch.no_grad():
+                    x = stages[i - 1](x)
+            else:
+                x = stages[i - 1](x)
+        return x
+
     def forward_pyramid(self, x) -> Dict[str, torch.Tensor]:
         """res2 .. res5 (strides 4, 8, 16, 32): the bottom-up pathway of the FPN extension (coin_amd/modeling/fpn.py); layer4 runs on
         the whole map here instead of on RoI tiles."""

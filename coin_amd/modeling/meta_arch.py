@@ -163,23 +163,44 @@ class OpenVocabularyRCNN(nn.Module):
 
     def _backbone_features(self, images, frozen_out):
         """backbone(images) of the training forward.  C4 CLIP backbone on the GPU: the stages without trainable parameters run as before
-        (or arrive from the look-ahead), the trainable stages -- whose launch sequence depends on the padded batch shape only -- go through a
-        `GraphedSegment` (eager for the first calls of a shape, then one graph launch forward and one backward)."""
+        (or arrive from the look-ahead); the trainable stages go through a `GraphedSegment` (eager for the first calls of a shape, then
+        one graph launch forward and one backward) -- as far as every convolution of them runs on the hand-written kernels: the library's
+        convolutions must not be recorded into a graph on this stack (coin_amd.layers._no_library_conv_under_capture), so a stage with
+        a width those kernels do not serve, and every stage before it, stays eager."""
         bb = self.backbone
+        vis = getattr(getattr(bb, "encoder", None), "visual", None)
         if not (self.step_graphs and images.tensor.is_cuda and type(bb).__name__ == "CLIP_IMAGE" and hasattr(bb, "frozen_forward")
-                and list(bb.encoder.visual._out_features) == ["res4"]):
+                and list(vis._out_features) == ["res4"] and vis.freeze_at <= 3 and self.compute_dtype == torch.bfloat16):
             return bb(frozen_out, frozen_done=True) if frozen_out is not None else bb(images.tensor)
-        if frozen_out is None:
-            frozen_out = bb.frozen_forward(images.tensor)
         if self._seg_backbone is None:
             from ..graphs import GraphedSegment
 
-            vis = bb.encoder.visual
-            self._seg_backbone = GraphedSegment("backbone", lambda x: bb(x, frozen_done=True)["res4"],
-                                                lambda: [p for n, p in vis.named_parameters() if not n.startswith("layer4.")],
-                                                lambda: [b for n, b in vis.named_buffers() if not n.startswith("layer4.")])
-        vis = bb.encoder.visual
-        return {"res4": self._seg_backbone(frozen_out, key_extra=(bb.training, vis.layer2.training, vis.layer3.training, vis.freeze_at))}
+            first = 4 + 1   # stage numbers as in ModifiedResNet.forward_stages: 3 = layer2, 4 = layer3
+            for no in (4, 3):
+                stage = (vis.layer2, vis.layer3)[no - 3]
+                if no <= vis.freeze_at or not L.library_free([m for m in stage.modules() if isinstance(m, torch.nn.Conv2d)]):
+                    break
+                first = no
+            if first > 4:
+                self._seg_backbone = False
+            else:
+                mods = [(vis.layer2, vis.layer3)[no - 3] for no in range(first, 5)]
+
+                def stretch(x):
+                    with L.conv_gemm_everywhere():
+                        for m in mods:
+                            x = m(x)
+                        return x
+
+                self._seg_backbone = (first, GraphedSegment("backbone", stretch, lambda: [p for m in mods for p in m.parameters()],
+                                                            lambda: [b for m in mods for b in m.buffers()]))
+        if self._seg_backbone is False:
+            return bb(frozen_out, frozen_done=True) if frozen_out is not None else bb(images.tensor)
+        if frozen_out is None:
+            frozen_out = bb.frozen_forward(images.tensor)
+        first, seg = self._seg_backbone
+        x = vis.forward_stages(frozen_out, first=vis.freeze_at + 1, last=first - 1)     # trainable stages in front of the captured ones: eager
+        return {"res4": seg(x, key_extra=(bb.training, vis.layer2.training, vis.layer3.training, vis.freeze_at))}
 
     def preprocess_image(self, batched_inputs: List[Dict]) -> ImageList:
         imgs = [x["image"].to(self.pixel_mean.device, non_blocking=True).contiguous() for x in batched_inputs]

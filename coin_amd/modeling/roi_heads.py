@@ -143,9 +143,17 @@ class OpenVocabularyRes5ROIHeads(nn.Module):
             from ..graphs import GraphedSegment
 
             name = self.in_features[0]
-            seg = (weakref.ref(res5), GraphedSegment("roi_trunk", lambda feat, r: self._pooled_rows({name: feat}, r, res5, attnpool),
-                                                     lambda: list(res5.parameters()), lambda: list(res5.buffers())))
+
+            def trunk(feat, r):   # every convolution on the hand-written kernels: library launches must not be recorded into a graph
+                with L.conv_gemm_everywhere():
+                    return self._pooled_rows({name: feat}, r, res5, attnpool)
+
+            convs = [m for m in res5.modules() if isinstance(m, torch.nn.Conv2d)]
+            ok = self.compute_dtype == torch.bfloat16 and L.library_free(convs)
+            seg = (weakref.ref(res5), GraphedSegment("roi_trunk", trunk, lambda: list(res5.parameters()), lambda: list(res5.buffers())) if ok else None)
             self._trunk_segs[id(res5)] = seg
+        if seg[1] is None:   # a width the hand-written weight-gradient kernel does not serve
+            return self._pooled_rows(features, rois, res5, attnpool)
         return seg[1](features[self.in_features[0]], rois, key_extra=(res5.training, self.compute_dtype))
 
     def _pooled_rows(self, features, rois, res5, attnpool):
