@@ -403,6 +403,15 @@ def main():
                 roofline = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": tsrc, "alg_bytes_per_launch": units,
                             "device_kernels": ENTRY_KERNELS.get(name)}
+            if name in K.SHAPES and name in MFMA_ENTRIES:
+                # Since round 5 the launch mix of this entry point also holds the backbone's small maps (the convolutions of layer3 / layer2 that
+                # ran on the library before: a captured stretch must not contain library launches).  The round-4 mix -- launches
+                # of at least 32 768 rows + the long-K 3x3 exception -- is priced separately so that the figure stays comparable across rounds.
+                big = [(c, tot, fl) for t, (c, tot, fl) in K.SHAPES[name].items() if t[0] >= 32768 or (t[3] == 3 and t[0] >= 16384 and t[1] % 256 == 0 and t[2] % 2304 == 0)]
+                if big and sum(tot for _, tot, _ in big) > 0:
+                    ach4 = sum(c * fl for c, _, fl in big) / (sum(tot for _, tot, _ in big) * 1e-3) / 1e12
+                    roofline["round4_launch_mix"] = {"launches": sum(c for c, _, _ in big), "achieved": ach4, "frac": ach4 / MFMA_BF16_PEAK_TFLOPS,
+                                                     "ms_per_step": sum(tot for _, tot, _ in big) / tsteps}
             roofline["launches_timed"] = n
             roofline["kernel_timing_steps"] = min(args.steps, KERNEL_TIMING_STEPS)
             roofline["mean_launch_ms"] = ms

@@ -23,13 +23,15 @@ Rules the capture keeps (each one is there because its absence produced a wrong 
   twice per forward) runs eagerly, it would overwrite the activations the pending backward reads;
 * the data-gradient weight layouts (layers.dgrad_weight) are refreshed eagerly BEFORE a backward capture / replay: captured, the
   refresh would not execute while the host-side stamp says it did;
-* before a capture the stretch is run once, forward and backward, on the capturing thread (its MIOpen handle has never loaded the
-  backward kernels of the library convolutions that remain in the stretch -- the eager backward ran on the engine's thread -- and loading
-  a code object during a capture fails with miopenStatusUnknownError); the running statistics that run advances are put back;
+* before a capture the stretch is run once, forward and backward, on the capturing thread: every cache the stretch fills (GEMM
+  workspaces of the stream, data-gradient layouts, unit constants, the set of shapes the pooled-residual epilogue does not serve)
+  is filled by executed launches, never by recorded ones; the running statistics that run advances are put back.  (When the stretch
+  still contained library convolutions this run was also what kept MIOpen from loading a code object during the capture --
+  miopenStatusUnknownError, stream invalidated -- the eager backward having run on the engine's thread with another handle);
 * a captured stretch contains NO library convolution (layers._no_library_conv_under_capture; the model code wraps its stretches in
   `layers.conv_gemm_everywhere` and offers only stages whose widths the hand-written kernels serve): replayed, the library's
-  backward-weights kernel accumulated onto a workspace that nothing inside the graph had zeroed -- 2e-2 relative error at the first
-  replay, 1e28 as soon as the allocation pattern of the process changed (tools/miopen_graph_probe.py);
+  backward-weights launch depends on memory that is not the graph's -- 2e-2 relative error at the first replay of a single captured
+  call, 1e28 as soon as unrelated allocations have happened (tools/miopen_graph_probe.py, profiles/r5_miopen_graph_probe.log);
 * only passes whose shapes are fixed by construction are captured (a padded pass -- the C boxes of step_one / step_two, whose count
   changes every step -- stays eager);
 * BatchNorm running statistics and `num_batches_tracked` are updated by kernels inside the graph: replays update them in place;
@@ -341,10 +343,9 @@ class GraphedSegment:
         L.refresh_dgrad_layouts()
         wants_bwd = grad_mode and (bool(ent.params) or any(s.requires_grad for s in ent.static_in))
         if wants_bwd:
-            # Dry run of forward + backward ON THIS THREAD before anything is recorded.  In the eager steps the backward ran on the autograd
-            # engine's worker thread, so this thread's MIOpen handle has never loaded the backward kernels of the library convolutions that
-            # remain in the stretch: loading a code object during a capture fails (miopenStatusUnknownError, and the stream is left
-            # invalidated).  The running statistics the dry run advances are put back.
+            # Dry run of forward + backward ON THIS THREAD before anything is recorded: whatever the stretch caches on first use is then
+            # produced by executed launches (a cache entry filled under the capture would hold memory no kernel has written yet).
+            # The running statistics the dry run advances are put back.
             saved = [b.detach().clone() for b in self.buffers_fn()] if self.buffers_fn is not None else []
             out = self.fn(*ent.static_in)
             outs = (out,) if torch.is_tensor(out) else tuple(out)

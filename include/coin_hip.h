@@ -229,7 +229,9 @@ int coin_conv_gemm_stats_finalize(const float* partials, int M, int N, int64_t r
 
 /* Weight gradient of the same convolutions: dW[Cout][Ktot] (fp32, OVERWRITTEN) = gy[M,Cout]^T . Acol[M,Ktot] with Acol as in
  * coin_conv_gemm_bf16 (mode 0: Ktot = Cin; mode 1: Ktot = 9*Cin, (ky, kx, ci) = the channels-last weight layout).  gy and x are the
- * NHWC tensors of the forward pass (bf16, row strides Cout / Cin); Cout % 256 == 0 and Cin % 256 == 0.  Also the weight gradient of a
+ * NHWC tensors of the forward pass (bf16, row strides Cout / Cin); Cout % 128 == 0 and Cin % 128 == 0 (odd multiples of 128 -- half-valid
+ * edge tiles, a 3x3 K-tile that spans two taps -- on the persistent kernel only, whose 32-bit buffer offsets bound the pixel count:
+ * COIN_ESHAPE when (M + 320) * max(Cout, Cin) * 2 >= 0x7f000000).  Also the weight gradient of a
  * linear layer (mode 0: dW[N,K] = dZ[M,N]^T . X[M,K]).  The contraction over the M pixels is cut into per-XCD segments whose fp32
  * partial tiles go to `workspace` (coin_conv_wgrad_workspace_bytes) and are summed in a fixed order (no atomics: bit-reproducible). */
 size_t coin_conv_wgrad_workspace_bytes(int M, int Cout, int Ktot);

@@ -1,4 +1,7 @@
-mkdir -p gpurun_out/r5ab
-LAB_SHAPES="l2.x.conv1 l2.x.conv2 l2.x.conv3 l4.0.conv1" timeout 300 ./tools/gemm_lab wbench 20 > gpurun_out/r5ab/lab_wbench.log 2>&1; cat gpurun_out/r5ab/lab_wbench.log | cut -c1-330
-timeout 1500 python -m pytest tests/test_graphs_gpu.py -q -m gpu > gpurun_out/r5ab/pytest_graphs.log 2>&1; tail -5 gpurun_out/r5ab/pytest_graphs.log
-timeout 2400 python -m pytest tests -x -q -m gpu --deselect tests/test_graphs_gpu.py > gpurun_out/r5ab/pytest_all.log 2>&1; tail -5 gpurun_out/r5ab/pytest_all.log
+mkdir -p gpurun_out/r5af
+timeout 600 ./tools/gemm_lab wcheck > gpurun_out/r5af/lab_wcheck.log 2>&1; tail -3 gpurun_out/r5af/lab_wcheck.log | cut -c1-220
+LAB_SHAPES="l2.x.conv1 l2.x.conv2 l2.x.conv3 l4.0.conv1 l3.x.conv2 rpn.conv" timeout 300 ./tools/gemm_lab wbench 20 > gpurun_out/r5af/lab_wbench.log 2>&1; sed 's/, "sliced_ms".*/}/' gpurun_out/r5af/lab_wbench.log | cut -c1-330
+timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "wgrad or fan_in" > gpurun_out/r5af/pytest_wgrad.log 2>&1; tail -2 gpurun_out/r5af/pytest_wgrad.log
+timeout 1500 python -m pytest tests/test_graphs_gpu.py -q -m gpu > gpurun_out/r5af/pytest_graphs.log 2>&1; tail -4 gpurun_out/r5af/pytest_graphs.log
+timeout 600 python bench.py > gpurun_out/r5af/bench.log 2>&1; tail -1 gpurun_out/r5af/bench.log | cut -c1-250
+COIN_STEP_GRAPHS=0 timeout 600 python bench.py > gpurun_out/r5af/bench_eager.log 2>&1; tail -1 gpurun_out/r5af/bench_eager.log | cut -c1-250
