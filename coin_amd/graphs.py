@@ -189,7 +189,7 @@ def _backward_on_this_thread(roots: Sequence[torch.Tensor], root_grads: Sequence
 
 
 class _Entry:
-    __slots__ = ("fwd", "bwd", "static_in", "outs", "out_req", "static_gout", "grads_in", "grads_p", "params", "busy", "pool", "single")
+    __slots__ = ("fwd", "bwd", "static_in", "outs", "out_req", "static_gout", "grads_in", "grads_p", "params", "busy", "pool", "single", "workspaces")
 
 
 def _has_grad_hooks(p: torch.Tensor) -> bool:
@@ -342,23 +342,40 @@ class GraphedSegment:
         ent.params = [p for p in self.params_fn() if p.requires_grad] if grad_mode else []
         L.refresh_dgrad_layouts()
         wants_bwd = grad_mode and (bool(ent.params) or any(s.requires_grad for s in ent.static_in))
+        # Dry run of forward (+ backward) ON THIS THREAD before anything is recorded: whatever the stretch caches on first use is then
+        # produced by executed launches (a cache entry filled under the capture would hold memory no kernel has written yet), and a
+        # library convolution in the stretch is noticed HERE -- refusing before the capture starts, not in the middle of one (a capture
+        # abandoned half way left the process in a state in which a later test aborted).  The running statistics the dry run advances
+        # are put back.
+        saved = [b.detach().clone() for b in self.buffers_fn()] if self.buffers_fn is not None else []
+        lib0 = L.LIBRARY_CONV_CALLS[0]
+        out = self.fn(*ent.static_in)
         if wants_bwd:
-            # Dry run of forward + backward ON THIS THREAD before anything is recorded: whatever the stretch caches on first use is then
-            # produced by executed launches (a cache entry filled under the capture would hold memory no kernel has written yet).
-            # The running statistics the dry run advances are put back.
-            saved = [b.detach().clone() for b in self.buffers_fn()] if self.buffers_fn is not None else []
-            out = self.fn(*ent.static_in)
             outs = (out,) if torch.is_tensor(out) else tuple(out)
             req = [o for o in outs if o.requires_grad]
             if req:
                 _backward_on_this_thread(req, [torch.zeros_like(o) for o in req], [s for s in ent.static_in if s.requires_grad] + list(ent.params))
-            del out, outs, req
-            if self.buffers_fn is not None:
-                with torch.no_grad():
-                    for b, s in zip(self.buffers_fn(), saved):
-                        b.copy_(s)
-            L.refresh_dgrad_layouts()
+            del outs, req
+        del out
+        if self.buffers_fn is not None:
+            with torch.no_grad():
+                for b, s in zip(self.buffers_fn(), saved):
+                    b.copy_(s)
+        L.refresh_dgrad_layouts()
+        if L.LIBRARY_CONV_CALLS[0] != lib0:
+            raise K.CoinHipError(f"{L.LIBRARY_CONV_CALLS[0] - lib0} library convolution(s) inside a captured stretch")
         torch.cuda.synchronize()
+        # the graphs own the workspaces their kernels are recorded with: nothing inherited from an earlier capture on the (shared) capture
+        # stream, and what this capture allocates leaves the stream's cache with it (kernels.take_stream_workspaces)
+        cap = K.capture_stream_value()
+        K.take_stream_workspaces(cap)
+        try:
+            self._record(ent, grad_mode)
+        finally:
+            ent.workspaces = K.take_stream_workspaces(cap)
+        return ent
+
+    def _record(self, ent: _Entry, grad_mode: bool) -> None:
         ent.pool = torch.cuda.graph_pool_handle()
         ent.fwd = torch.cuda.CUDAGraph()
         L.STRICT_CAPTURE[0] = True     # a library convolution inside the stretch fails the capture (layers._no_library_conv_under_capture)
@@ -387,4 +404,3 @@ class GraphedSegment:
             for j, i in enumerate(wrt_in):
                 ent.grads_in[i] = grads[j]
             ent.grads_p = list(grads[len(wrt_in):])
-        return ent

@@ -279,6 +279,27 @@ _GEMM_WS: dict = {}
 _RPOOL_UNSERVED: set = set()
 
 
+def capture_stream_value() -> int:
+    """Raw handle of the stream torch.cuda.graph captures on (created here if no capture has happened yet)."""
+    if torch.cuda.graph.default_capture_stream is None:
+        torch.cuda.graph.default_capture_stream = torch.cuda.Stream()
+    return int(torch.cuda.graph.default_capture_stream.cuda_stream)
+
+
+def take_stream_workspaces(stream_value: int) -> list:
+    """Remove and return the cached workspaces of one stream (the GEMM split-K slabs, the weight-gradient slabs, the window-attention
+    scratch).  A HIP graph must OWN the workspaces its kernels were recorded with: the caches are keyed by stream and every capture runs
+    on the same capture stream, so a later capture that needed a larger buffer used to replace -- and thereby free -- the one an earlier
+    graph's kernels still point at; when that buffer lived in the pool of a graph that no longer existed, the next empty_cache() unmapped
+    it and the earlier graph's replay ended in a GPU memory access fault (round 5, full test suite).  coin_amd.graphs and the teacher's
+    capture call this before a capture (nothing inherited) and after it (the entries move into the graph's own record)."""
+    out = []
+    for cache in (_GEMM_WS, _WGRAD_WS, _WATTN_WS):
+        for k in [k for k in cache if int(k[1] or 0) == int(stream_value)]:
+            out.append(cache.pop(k))
+    return out
+
+
 _WGRAD_WS: dict = {}
 
 

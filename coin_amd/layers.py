@@ -211,12 +211,16 @@ def _no_library_conv_under_capture(what: str) -> None:
     the res4 map, the backward-weights kernels of the 128-channel convolutions) produced garbage as soon as the process state differed
     from the capture's (another allocation pattern, an empty_cache(), a bare replay) -- measured with tools/bb_bisect.py and
     tools/miopen_graph_probe.py, DESIGN.md section 3.17.  A stretch that is to be captured keeps every convolution on the hand-written
-    kernels (`conv_gemm_everywhere`); anything else fails the capture loudly and the stretch stays eager."""
+    kernels (`conv_gemm_everywhere`).  Every library convolution is counted here: coin_amd.graphs compares the count across the dry run
+    that precedes a capture and refuses the capture when it moved (the stretch then stays eager, with a warning); reaching one UNDER a
+    capture raises as a last resort."""
+    LIBRARY_CONV_CALLS[0] += 1
     if STRICT_CAPTURE[0] and torch.cuda.is_current_stream_capturing():
         raise CoinHipError(f"{what}: a library convolution inside a captured stretch")
 
 
 STRICT_CAPTURE = [False]   # set by coin_amd.graphs around its captures
+LIBRARY_CONV_CALLS = [0]   # library convolutions issued so far (coin_amd.graphs compares it across the dry run that precedes a capture)
 
 
 def conv2d(x: torch.Tensor, conv: torch.nn.Conv2d) -> torch.Tensor:

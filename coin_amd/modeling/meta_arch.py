@@ -318,7 +318,7 @@ class OpenVocabularyRCNN(nn.Module):
                 self._invalidate_derived()
                 return None
             self._graphs[key] = ent
-        static_in, g, boxes, probs = ent
+        static_in, g, boxes, probs = ent[:4]
         static_in.copy_(x)
         g.replay()
         return boxes, probs
@@ -338,9 +338,14 @@ class OpenVocabularyRCNN(nn.Module):
         torch.cuda.synchronize()
         self._invalidate_derived()   # -> shadow refreshes + prompt transformer are captured: every replay re-derives them
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):   # loader threads may touch the device meanwhile
-            boxes, probs = self._inference_core(static_in, sizes, branch)
-        return static_in, g, boxes, probs
+        cap = K.capture_stream_value()
+        K.take_stream_workspaces(cap)    # the graph owns the workspaces its kernels are recorded with (kernels.take_stream_workspaces)
+        try:
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # loader threads may touch the device meanwhile
+                boxes, probs = self._inference_core(static_in, sizes, branch)
+        finally:
+            ws = K.take_stream_workspaces(cap)
+        return static_in, g, boxes, probs, ws
 
     def _inference_finish(self, begun, do_postprocess=True):
         from .fast_rcnn import fast_rcnn_inference_single_image

@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM-traffic counters of the bench's own launch mix (run on the GPU box):  bash tools/pmc_bench.sh <tag>
-# Two passes over a short bench run; per-kernel totals go to gpurun_out/prof_<tag>/pmc_bench_<COUNTER>.csv
+# Two passes over a short bench run (3 steps, no warm-up: a stretch is captured at its 4th call, so every launch here is an eager one of the same kernels); per-kernel totals go to gpurun_out/prof_<tag>/pmc_bench_<COUNTER>.csv
 set -u
 tag=${1:-r1}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
@@ -8,7 +8,7 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcb_$ctr
-  timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmcb_$ctr -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary > /tmp/pmcb_$ctr.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmcb_$ctr -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 0 --no-cpu-baseline --no-secondary > /tmp/pmcb_$ctr.log 2>&1
   f=$(find /tmp/pmcb_$ctr -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py "$f" "$out/pmc_bench_$ctr.csv" | grep -E "bn_bwd|roi_align|conv_gemm" ; else echo "no counter csv for $ctr"; tail -5 /tmp/pmcb_$ctr.log; fi
 done
