@@ -1020,14 +1020,49 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
   const float* __restrict__ base = slab + (size_t)idx * grid * 65536 + row * 256 + c4;
   const int n = 8 * nsub;  // candidate partials, order: x-major, then sub
   f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // A tile of a launch with few tiles is cut into up to 8 * cpx pieces (two tiles -> 128 partials each): walked 16 at a time there, so that
-  // the list costs 8 memory latencies instead of 32 (the 128-channel layers: 64 of their 85 us were this loop); same summation order.
-  if (n > 8) {
-    for (int q0 = 0; q0 < n; q0 += 16) {
+  for (int q0 = 0; q0 < n; q0 += 4) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = q0 + u, x = q / nsub, sub = q - x * nsub;
+      const int b = (j0 + sub * jstep) * 8 + x;
+      int t, kb, ke;
+      const bool ok = q < n && tn_item(b, idx, ntiles, nkt, cpx, t, kb, ke);
+      v[u] = ok ? *reinterpret_cast<const f32x4*>(base + (size_t)b * 65536) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a += v[u];
+  }
+  *reinterpret_cast<f32x4*>(dw + (size_t)(tco * 256 + row) * Ktot + tk * 256 + c4) = a;
+}
+
+// The same reduction for launches with FEW tiles (every tile then is a leftover tile cut into 8 * (cpx / r) pieces: two tiles -> 128 partials
+// each).  One workgroup per ROW of a tile; its four waves take every fourth partial of the list (16 loads in flight per lane) and their
+// sums are combined in wave order through LDS: a fixed order again, 4x the rows in flight and a quarter of the dependent latencies per
+// thread (the 128-channel layers: the reduction took 50 us of a 76 us launch with the kernel above, rocprofv3 of tools/gemm_lab wbench).
+__global__ __launch_bounds__(256) void tn_reduce_wide_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Ktot, int tiles_k, int ntiles,
+                                                             int nkt, int cpx) {
+  __shared__ f32x4 part[3][64];
+  const int tile = blockIdx.x >> 8, row = blockIdx.x & 255;
+  const int tco = tile / tiles_k, tk = tile - tco * tiles_k;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c4 = lane * 4;
+  if (tco * 256 + row >= Cout) return;                      // whole workgroup: no barrier is reached
+  const bool col_ok = tk * 256 + c4 < Ktot;
+  const int grid = 8 * cpx, full = ntiles / cpx, r = ntiles - full * cpx;
+  const bool whole = tile < full * cpx;
+  const int idx = whole ? tile / cpx : full;
+  const int j0 = whole ? tile % cpx : tile - full * cpx;
+  const int nsub = whole ? 1 : cpx / r, jstep = whole ? 0 : r;
+  const float* __restrict__ base = slab + (size_t)idx * grid * 65536 + row * 256 + c4;
+  const int n = 8 * nsub;
+  f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (col_ok) {
+    for (int q0 = wave; q0 < n; q0 += 64) {
       f32x4 v[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
-        const int q = q0 + u, x = q / nsub, sub = q - x * nsub;
+        const int q = q0 + 4 * u, x = q / nsub, sub = q - x * nsub;
         const int b = (j0 + sub * jstep) * 8 + x;
         int t, kb, ke;
         const bool ok = q < n && tn_item(b, idx, ntiles, nkt, cpx, t, kb, ke);
@@ -1036,22 +1071,15 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 #pragma unroll
       for (int u = 0; u < 16; ++u) a += v[u];
     }
-  } else {
-    for (int q0 = 0; q0 < n; q0 += 4) {
-      f32x4 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int q = q0 + u, x = q / nsub, sub = q - x * nsub;
-        const int b = (j0 + sub * jstep) * 8 + x;
-        int t, kb, ke;
-        const bool ok = q < n && tn_item(b, idx, ntiles, nkt, cpx, t, kb, ke);
-        v[u] = ok ? *reinterpret_cast<const f32x4*>(base + (size_t)b * 65536) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) a += v[u];
-    }
   }
-  *reinterpret_cast<f32x4*>(dw + (size_t)(tco * 256 + row) * Ktot + tk * 256 + c4) = a;
+  if (wave) part[wave - 1][lane] = a;
+  __syncthreads();
+  if (wave == 0 && col_ok) {
+    a += part[0][lane];
+    a += part[1][lane];
+    a += part[2][lane];
+    *reinterpret_cast<f32x4*>(dw + (size_t)(tco * 256 + row) * Ktot + tk * 256 + c4) = a;
+  }
 }
 
 }  // namespace
@@ -1210,6 +1238,9 @@ int coin_p8_tn_launch(const void* GY, const void* X, int mode, int H, int W, int
     if (!set1) { (void)hipFuncSetAttribute((const void*)conv_wgrad_p8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, P_IMG); set1 = true; }
     conv_wgrad_p8_kernel<false><<<grid, 512, P_IMG, st>>>(a);
   }
-  tn_reduce_kernel<<<a.ntiles * 64, 256, 0, st>>>(a.slab, dW, Cout, Ktot, a.tiles_k, a.ntiles, a.nkt, a.cpx);
+  if (a.ntiles < a.cpx && a.cpx / a.ntiles >= 2)   // every tile is a leftover tile cut into >= 16 pieces
+    tn_reduce_wide_kernel<<<a.ntiles * 256, 256, 0, st>>>(a.slab, dW, Cout, Ktot, a.tiles_k, a.ntiles, a.nkt, a.cpx);
+  else
+    tn_reduce_kernel<<<a.ntiles * 64, 256, 0, st>>>(a.slab, dW, Cout, Ktot, a.tiles_k, a.ntiles, a.nkt, a.cpx);
   return coin_launch_status();
 }

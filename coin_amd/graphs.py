@@ -32,6 +32,11 @@ Rules the capture keeps (each one is there because its absence produced a wrong 
   `layers.conv_gemm_everywhere` and offers only stages whose widths the hand-written kernels serve): replayed, the library's
   backward-weights launch depends on memory that is not the graph's -- 2e-2 relative error at the first replay of a single captured
   call, 1e28 as soon as unrelated allocations have happened (tools/miopen_graph_probe.py, profiles/r5_miopen_graph_probe.log);
+* a graph OWNS the workspaces its kernels were recorded with (kernels.take_stream_workspaces): the per-stream workspace caches are
+  emptied for the capture stream before a capture and again after it, the entries moving into the graph's record.  Inherited from an
+  earlier capture, such a buffer was replaced -- freed -- by the next capture that needed a larger one while this graph's kernels still
+  pointed at it; harmless while the pool it lived in existed, a GPU memory access fault once that pool's graph had been destroyed and
+  empty_cache() returned the block to the driver;
 * only passes whose shapes are fixed by construction are captured (a padded pass -- the C boxes of step_one / step_two, whose count
   changes every step -- stays eager);
 * BatchNorm running statistics and `num_batches_tracked` are updated by kernels inside the graph: replays update them in place;
@@ -226,6 +231,11 @@ class _Replay(torch.autograd.Function):
                 s.zero_()
             elif s.data_ptr() != g.data_ptr():
                 s.copy_(g)
+        for p, g in zip(ent.params, ent.grads_p):
+            # gradient accumulation over several passes without zero_grad(): a p.grad that IS this graph's static buffer (assigned by the
+            # previous pass, below) holds the sum so far and is about to be overwritten -- move the sum out of the buffer first
+            if g is not None and p.grad is not None and p.grad.data_ptr() == g.data_ptr():
+                p.grad = p.grad.clone()
         t0 = time.perf_counter()
         ent.bwd.replay()
         STATS["launch_ms"] += (time.perf_counter() - t0) * 1e3

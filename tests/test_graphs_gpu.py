@@ -92,6 +92,41 @@ def test_graphed_segment_equals_the_eager_launches_bit_for_bit_over_steps(monkey
     assert all(e.workspaces for e in seg.graphs.values())
 
 
+def test_gradients_accumulate_over_two_replayed_passes_without_zero_grad(monkeypatch):
+    """Without gradient hooks the backward graph's static buffers BECOME p.grad; a second pass before zero_grad() must add to the first
+    pass's gradients, not overwrite them with its own (the buffer is replaced by a copy of the running sum before the replay)."""
+    from coin_amd import graphs as G
+    from coin_amd import layers as L
+
+    monkeypatch.setitem(L.CONV_GEMM, "enabled", True)
+    monkeypatch.setitem(L.CONV_GEMM, "min_rows", 0)
+    monkeypatch.setitem(L.CONV_GEMM, "wgrad", True)
+    monkeypatch.setitem(G.ENABLED, "on", True)
+    G.step_done()
+    a, b = _blocks(17), _blocks(17)
+    a.eval(), b.eval()   # frozen statistics: the passes do not interact through the running averages
+    seg = G.GraphedSegment("test_accum", lambda x: b(x), lambda: list(b.parameters()), lambda: list(b.buffers()))
+    gen = torch.Generator(device="cuda").manual_seed(8)
+    mk = lambda: torch.randn(8, 1024, 14, 14, device="cuda", generator=gen).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        for _ in range(3):   # warm-up + capture
+            seg(mk().requires_grad_(True)).float().sum().backward()
+            G.step_done()
+        assert len(seg.graphs) == 1
+        for m in (a, b):
+            for p in m.parameters():
+                p.grad = None
+        r0 = G.STATS["replays"]
+        for _ in range(2):
+            x = mk()
+            seg(x.clone().requires_grad_(True)).float().sum().backward()
+            G.step_done()
+            a(x.clone().requires_grad_(True)).float().sum().backward()
+        assert G.STATS["replays"] == r0 + 2
+    for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+        assert torch.equal(pa.grad, pb.grad), (n, float((pa.grad - pb.grad).abs().max()))
+
+
 def test_a_library_convolution_inside_a_stretch_fails_the_capture_and_the_stretch_stays_eager(monkeypatch):
     """The library's convolutions are not replay-safe on this stack (tools/miopen_graph_probe.py: a captured backward-weights launch gives
     2e-2 error at the first replay and 1e28 once unrelated allocations have happened): a stretch that contains one must
