@@ -41,8 +41,10 @@ Rules the capture keeps (each one is there because its absence produced a wrong 
   changes every step -- stays eager);
 * BatchNorm running statistics and `num_batches_tracked` are updated by kernels inside the graph: replays update them in place;
 * parameter gradients: the backward graph writes them into static buffers.  Without gradient hooks on a parameter (single GPU) the
-  static buffer itself becomes ``p.grad`` (stable pointers: the optimizer's device table is uploaded once); with hooks (the
-  data-parallel reducer) they are returned to autograd, which accumulates and fires the hooks as usual.
+  static buffer itself becomes ``p.grad`` (stable pointers: the optimizer's device table is uploaded once) -- valid until the stretch's
+  next replay, forward or backward; a p.grad that is still the buffer at that point (gradient accumulation without zero_grad) is
+  replaced by a copy first; with hooks (the data-parallel reducer) they are returned to autograd, which accumulates and fires the
+  hooks as usual.
 
 ``cfg.AMD.STEP_GRAPHS`` (default on) / ``COIN_STEP_GRAPHS=0`` switch the mechanism; a failed capture warns once and leaves the segment
 eager for good (same kernels either way).
@@ -231,11 +233,7 @@ class _Replay(torch.autograd.Function):
                 s.zero_()
             elif s.data_ptr() != g.data_ptr():
                 s.copy_(g)
-        for p, g in zip(ent.params, ent.grads_p):
-            # gradient accumulation over several passes without zero_grad(): a p.grad that IS this graph's static buffer (assigned by the
-            # previous pass, below) holds the sum so far and is about to be overwritten -- move the sum out of the buffer first
-            if g is not None and p.grad is not None and p.grad.data_ptr() == g.data_ptr():
-                p.grad = p.grad.clone()
+        _detach_static_grads(ent)
         t0 = time.perf_counter()
         ent.bwd.replay()
         STATS["launch_ms"] += (time.perf_counter() - t0) * 1e3
@@ -251,6 +249,16 @@ class _Replay(torch.autograd.Function):
             else:
                 gp.append(g)
         return (None, None) + gin + tuple(gp)
+
+
+def _detach_static_grads(ent: _Entry) -> None:
+    """Gradient accumulation over several passes without zero_grad(): a p.grad that IS this graph's static buffer (assigned by the previous
+    pass's backward) holds the sum so far.  The buffer lives in the pool the two graphs share -- the NEXT FORWARD replay may use the same
+    memory for its temporaries, the next backward replay overwrites it -- so the sum is moved out before either runs.  (In the usual loop
+    p.grad is None here: the optimizer consumed it and zero_grad() dropped it.)"""
+    for p, g in zip(ent.params, ent.grads_p):
+        if g is not None and p.grad is not None and p.grad.data_ptr() == g.data_ptr():
+            p.grad = p.grad.clone()
 
 
 def _recover_from_failed_capture() -> None:
@@ -338,6 +346,7 @@ class GraphedSegment:
             return self.fn(*inputs)     # (defer: another stretch captures in this step, nothing may be replayed around it)
         _STEP["replayed"] = True
         STATS["replays"] += 1
+        _detach_static_grads(ent)
         outs = _Replay.apply(ent, len(inputs), *inputs, *ent.params)
         # until this call's backward has replayed, the graph's buffers hold the activations it will read: a second call must not replay
         ent.busy = ent.bwd is not None and any(o.requires_grad for o in outs)

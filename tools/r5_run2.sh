@@ -1,6 +1,6 @@
-mkdir -p gpurun_out/r5ag
-timeout 600 ./tools/gemm_lab wcheck > gpurun_out/r5ag/lab_wcheck.log 2>&1; grep -c OK gpurun_out/r5ag/lab_wcheck.log; tail -1 gpurun_out/r5ag/lab_wcheck.log
-LAB_SHAPES="l2.x.conv1 l2.x.conv2 l2.x.conv3 l4.0.conv1 l3.x.conv2 rpn.conv" timeout 300 ./tools/gemm_lab wbench 20 > gpurun_out/r5ag/lab_wbench.log 2>&1; sed 's/, "sliced_ms".*/}/' gpurun_out/r5ag/lab_wbench.log | cut -c1-330
-timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "wgrad or fan_in" > gpurun_out/r5ag/pytest_wgrad.log 2>&1; tail -2 gpurun_out/r5ag/pytest_wgrad.log
-timeout 1500 python -m pytest tests/test_graphs_gpu.py -q -m gpu > gpurun_out/r5ag/pytest_graphs.log 2>&1; tail -4 gpurun_out/r5ag/pytest_graphs.log
-timeout 600 python bench.py --no-cpu-baseline --no-secondary > gpurun_out/r5ag/bench.log 2>&1; tail -1 gpurun_out/r5ag/bench.log | cut -c1-250
+mkdir -p gpurun_out/r5final2
+timeout 3000 python -m pytest tests -x -q -m gpu > gpurun_out/r5final2/pytest_gpu.log 2>&1; echo "full suite rc=$?"; grep -i -m3 "fault\|abort" gpurun_out/r5final2/pytest_gpu.log; tail -3 gpurun_out/r5final2/pytest_gpu.log | cut -c1-200
+python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" > gpurun_out/r5final2/smoke.log 2>&1; tail -1 gpurun_out/r5final2/smoke.log
+bash tools/pmc_bench.sh r5final2 > gpurun_out/r5final2/pmc.log 2>&1; tail -2 gpurun_out/r5final2/pmc.log | cut -c1-200
+bash tools/profile_bench.sh r5final2 > gpurun_out/r5final2/profile.log 2>&1; head -3 gpurun_out/prof_r5final2/steady_top.txt
+timeout 900 python bench.py > gpurun_out/r5final2/bench.log 2>&1; tail -1 gpurun_out/r5final2/bench.log | cut -c1-250
