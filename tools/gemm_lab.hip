@@ -68,7 +68,8 @@ struct Shape {
 static const Shape kShapes[] = {{"l4.0.conv1", 2048, 14, 14, 1024, 512, 1}, {"l4.0.conv2", 2048, 14, 14, 512, 512, 3}, {"l4.0.conv3", 2048, 7, 7, 512, 2048, 1},
                                 {"l4.0.down", 2048, 7, 7, 1024, 2048, 1},   {"l4.1.conv1", 2048, 7, 7, 2048, 512, 1},  {"l4.1.conv2", 2048, 7, 7, 512, 512, 3},
                                 {"rpn.conv", 4, 50, 83, 1024, 1024, 3},     {"l3.x.conv2", 4, 50, 83, 256, 256, 3},    // backbone-resolution convolutions
-                                {"l2.x.conv2", 4, 100, 167, 128, 128, 3},   {"l2.x.conv1", 4, 100, 167, 512, 128, 1},  {"l2.x.conv3", 4, 100, 167, 128, 512, 1}};  // N = 128: a half-width column tile (round 5)
+                                {"l2.x.conv2", 4, 100, 167, 128, 128, 3},   {"l2.x.conv1", 4, 100, 167, 512, 128, 1},  {"l2.x.conv3", 4, 100, 167, 128, 512, 1},
+                                {"l3.x.conv1", 4, 50, 83, 1024, 256, 1},    {"l3.x.conv3", 4, 50, 83, 256, 1024, 1}};   // layer3's 1x1 convolutions: on this kernel since the stretch is captured  // N = 128: a half-width column tile (round 5)
 
 static void* g_ws = nullptr;
 static size_t g_ws_bytes = 0;
@@ -217,12 +218,12 @@ static void bench_shape(const Shape& sh, int iters, int rounds) {
     fill(B, bn, 0x9876u + dir, 0.05f);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    constexpr int NV = 5;
-    const int impls[NV] = {1, 2, 1, 2, 1};   // 2 = the round-2 kernels (256x256x32 where N % 256 == 0, else the 256x128 kernel that served N = 128 until round 5)
-    const bool stats[NV] = {false, false, true, true, false};
-    const int splits[NV] = {-1, -1, -1, -1, 0};
-    const int stags[NV] = {-1, -1, -1, -1, -1};
-    const char* names[NV] = {"p8", "r2", "p8+stats", "r2+stats", "p8nosplit"};
+    constexpr int NV = 6;
+    const int impls[NV] = {1, 2, 1, 2, 1, 1};   // 2 = the round-2 kernels (256x256x32 where N % 256 == 0, else the 256x128 kernel that served N = 128 until round 5)
+    const bool stats[NV] = {false, false, true, true, false, false};
+    const int splits[NV] = {-1, -1, -1, -1, 0, 1};
+    const int stags[NV] = {-1, -1, -1, -1, -1, -1};
+    const char* names[NV] = {"p8", "r2", "p8+stats", "r2+stats", "p8nosplit", "p8split"};
     std::vector<float> best(NV, 1e30f), med[NV];
     for (int r = 0; r < rounds; ++r)
       for (int v = 0; v < NV; ++v) {
