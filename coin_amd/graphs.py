@@ -43,8 +43,9 @@ Rules the capture keeps (each one is there because its absence produced a wrong 
 * parameter gradients: the backward graph writes them into static buffers.  Without gradient hooks on a parameter (single GPU) the
   static buffer itself becomes ``p.grad`` (stable pointers: the optimizer's device table is uploaded once) -- valid until the stretch's
   next replay, forward or backward; a p.grad that is still the buffer at that point (gradient accumulation without zero_grad) is
-  replaced by a copy first; with hooks (the data-parallel reducer) they are returned to autograd, which accumulates and fires the
-  hooks as usual.
+  replaced by a copy first.  Post-accumulate hooks (the data-parallel reducer) fire as usual -- the engine runs the accumulator node
+  for the undefined gradient the replay returns, and that node calls its post hooks with p.grad already in place; a parameter with a
+  tensor hook, or one that already holds a gradient, gets its gradient through autograd.
 
 ``cfg.AMD.STEP_GRAPHS`` (default on) / ``COIN_STEP_GRAPHS=0`` switch the mechanism; a failed capture warns once and leaves the segment
 eager for good (same kernels either way).
@@ -199,10 +200,6 @@ class _Entry:
     __slots__ = ("fwd", "bwd", "static_in", "outs", "out_req", "static_gout", "grads_in", "grads_p", "params", "busy", "pool", "single", "workspaces")
 
 
-def _has_grad_hooks(p: torch.Tensor) -> bool:
-    return bool(getattr(p, "_post_accumulate_grad_hooks", None)) or bool(getattr(p, "_backward_hooks", None))
-
-
 class _Replay(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ent: _Entry, n_in: int, *args):
@@ -243,15 +240,18 @@ class _Replay(torch.autograd.Function):
         for p, g in zip(ent.params, ent.grads_p):
             if g is None:
                 gp.append(None)
-            elif p.grad is None and not _has_grad_hooks(p):
-                p.grad = g          # the static buffer itself: no accumulate copy, a stable address for the optimizer's table
+            elif p.grad is None and not getattr(p, "_backward_hooks", None):
+                # The static buffer itself becomes p.grad: no accumulate copy, a stable address for the optimizer's table.  Post-accumulate
+                # hooks (the data-parallel reducer's arrival counter) still fire: the engine runs the parameter's accumulator node for
+                # the undefined gradient returned here, and that node calls its post hooks whether or not a gradient arrived (torch 2.10;
+                # pinned by tests/test_graphs_cpu.py) -- with p.grad already in place, which is all the reducer's hook reads.  (Calling the
+                # hooks from here as well delivered every parameter twice: the reducer's second-gradient guard caught it.)
+                p.grad = g
                 gp.append(None)
             else:
-                # through autograd (gradient hooks: the data-parallel reducer; or an existing p.grad to add to).  A fresh alias, not the
-                # object `ent` holds, so that the accumulator may adopt it instead of cloning it; `_detach_static_grads` covers a p.grad
-                # that is still this buffer at the next replay.  (Firing the reducer's post-accumulate hooks from here instead -- no
-                # accumulator node at all -- was tried and raised the reducer's "second gradient" guard in the benchmark's step; 1-rank
-                # RCCL A/B with this path: 33.2 ms against 32.7 ms eager and 31.9 ms without a process group, same box.)
+                # through autograd (a tensor hook, or an existing p.grad to add to).  A fresh alias, not the object `ent` holds, so that
+                # the accumulator may adopt it instead of cloning it; `_detach_static_grads` covers a p.grad that is still this buffer
+                # at the next replay
                 gp.append(g.detach())
         return (None, None) + gin + tuple(gp)
 

@@ -64,3 +64,29 @@ def test_engine_free_backward_through_the_tiny_detectors_backbone():
         assert (r is None) == (g is None)
         if r is not None:
             torch.testing.assert_close(g, r, rtol=1e-5, atol=1e-6)
+
+
+def test_a_post_accumulate_hook_fires_for_an_undefined_gradient_with_the_directly_assigned_grad_in_place():
+    """What coin_amd.graphs._Replay.backward relies on in data-parallel mode: it assigns the backward graph's static buffer to p.grad and
+    returns None for the parameter; the engine still runs the parameter's accumulator node, whose post-accumulate hooks (the reducer's
+    arrival counter) then see the assigned gradient -- exactly once."""
+    import torch
+
+    seen = []
+    p = torch.nn.Parameter(torch.ones(3))
+    p.register_post_accumulate_grad_hook(lambda q: seen.append(None if q.grad is None else q.grad.clone()))
+
+    class Direct(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.w = w
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            ctx.w.grad = torch.full((3,), 5.0)
+            return g * 2, None
+
+    x = torch.ones(3, requires_grad=True)
+    Direct.apply(x, p).sum().backward()
+    assert len(seen) == 1 and torch.equal(seen[0], torch.full((3,), 5.0)) and torch.equal(p.grad, torch.full((3,), 5.0))
