@@ -86,7 +86,9 @@ def main():
     in_order = [round(g, 1) for g in groups]
     groups.sort()
     print(json.dumps({"config": args.config, "workload": "targetDET " + ("step_two" if args.step_two else "step_one") + (" (reference-shaped samplers)" if args.reference_samplers else "") + (" (teacher on the main stream)" if args.no_teacher_stream else "") + (" (no teacher prefetch)" if args.no_prefetch else ""), "images_per_step": args.images, "ms_per_step": dt * 1e3, "median_group_ms_per_step": groups[len(groups) // 2], "fastest_group_ms_per_step": groups[0], "groups_ms_per_step_in_order": in_order,
-                      "student_views_per_s": args.images / dt, "losses": {k: round(float(v), 4) for k, v in rec.items()}}))
+                      "student_views_per_s": args.images / dt, "losses": {k: round(float(v), 4) for k, v in rec.items()},
+                      "final_loss": float(sum(float(v) for v in rec.values())), "steps": args.steps, "warmup": args.warmup,
+                      "step_graphs": dict(__import__("coin_amd.graphs", fromlist=["STATS"]).STATS)}))
 
 
 if __name__ == "__main__":
