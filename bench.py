@@ -247,8 +247,10 @@ def run_secondary_targetdet(steps: int = 24, warmup: int = 8, images: int = 3, t
     `CoinTrainer.train()` issues them: teacher inference on the weak views, A/B/C matching against the cached cloud boxes, student
     step on the strong views.  tools/bench_targetdet.py (groups of 4 steps, a device synchronize between groups only) in a CHILD PROCESS
     of its own, as the reference runs the two trainings as two jobs: measured in this process, after the pre-train trainer had lived in
-    it, the same step took 64 ms instead of 53 (same box, back to back, five runs of each, round 5) -- the streams the first trainer
-    created stay in the process and the second trainer's streams then share hardware queues; a fresh process does not inherit that."""
+    it, the same step took 64 ms instead of 53 (same box, back to back, five runs of each, round 5) .  Not understood in full: streams that
+    the first trainer used stay in the process, and creating three used side streams before the trainer in the stand-alone tool
+    reproduced the 64 ms once (equal groups) and not on a second, noisier box (`PRE_STREAMS=3 tools/bench_targetdet.py`); more hardware
+    queues (GPU_MAX_HW_QUEUES 16 / 24) did not change the picture.  A fresh process gives the stand-alone figure every time."""
     import subprocess
 
     env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "COIN_RANK_CPUSET")}   # a job of its own

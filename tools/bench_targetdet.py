@@ -61,6 +61,12 @@ def main():
     args = ap.parse_args()
     import torch
 
+    if os.environ.get("PRE_STREAMS"):   # experiment: side streams created (and used once) before the trainer exists, as a trainer that lived in the process earlier leaves them
+        keep = [torch.cuda.Stream() for _ in range(int(os.environ["PRE_STREAMS"]))]
+        for st in keep:
+            with torch.cuda.stream(st):
+                torch.zeros(1024, device="cuda").add_(1)
+        torch.cuda.synchronize()
     tr = build_trainer(args.config, args.images, args.step_two, reference_samplers=args.reference_samplers, teacher_stream=not args.no_teacher_stream,
                        extra=["AMD.TEACHER_PREFETCH", not args.no_prefetch])
     for _ in range(args.warmup):
