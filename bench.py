@@ -347,6 +347,17 @@ def main():
     host_enqueue_ms = bare[len(bare) // 2]
     ktimes = K.timing_end()
     loss = float(sum(rec.values()))
+    # AFTER the timed region: the same call with the device idle at its start (a synchronize before every step), i.e. what the host needs
+    # to enqueue a step when it never has to wait for the device -- free-running, `host_enqueue_ms` includes such waits (a graph replay
+    # blocks while the previous launch of that graph is still running), so it reads like the step time on a device-bound rank
+    idle_ms = []
+    for _ in range(5):
+        sync()
+        th = time.perf_counter()
+        trainer.run_step()
+        idle_ms.append((time.perf_counter() - th) * 1e3)
+    sync()
+    host_enqueue_idle_ms = sorted(idle_ms)[len(idle_ms) // 2]
     per_rank = [[dt, loss, host_enqueue_ms]]
     affinities = [affinity]
     if world > 1:   # every rank's wall time, final loss and host enqueue time: the line reports the slowest rank (value) and the spread
@@ -419,6 +430,7 @@ def main():
                        # median wall time per step the host spent enqueueing (run_step call to return, un-instrumented steps): a rank whose
                        # figure is close to ms_per_step is host-bound, one well below it is device-bound
                        "host_enqueue_ms": [round(r[2], 2) for r in per_rank],
+                       "host_enqueue_device_idle_ms_rank0": round(host_enqueue_idle_ms, 2),   # 5 extra steps after the timed region, see above
                        "rank_affinity": affinities,
                        # coin_amd/graphs.py: captured (shape, segment) pairs, graph replays / eager calls of the two graphed stretches so far
                        "step_graphs": dict(G.STATS, enabled=G.ENABLED["on"]),
