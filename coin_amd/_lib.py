@@ -61,7 +61,8 @@ SIGNATURES = {
     "coin_conv_gemm_bf16": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P],
     "coin_conv_gemm_bf16_ws": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P, _Z, _P],
     "coin_conv_gemm_bf16_rpool": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P],
-    "coin_conv_gemm_stats_finalize": [_P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P, _P],
+    "coin_conv_gemm_stats_finalize": [_P, _I, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P],
+    "coin_conv_gemm_stats_tile_rows": [_I, _I, _I, _I, _I, _I, _I],
     "coin_conv_wgrad_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "coin_window_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "coin_window_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
@@ -92,7 +93,7 @@ SIGNATURES = {
     "coin_ema_update": [_P, _I, _L, _F, _P],
 }
 
-ABI_VERSION = 2   # == COIN_ABI_VERSION of include/coin_hip.h (tests/test_abi.py); lib() refuses any other library
+ABI_VERSION = 3   # == COIN_ABI_VERSION of include/coin_hip.h (tests/test_abi.py); lib() refuses any other library
 
 _lib = None
 
@@ -128,6 +129,12 @@ def lib() -> ctypes.CDLL:
         l = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover - depends on the host
         raise CoinHipError(f"cannot load {LIB_PATH}: {e}") from e
+    # first of all: a stale build lacks the symbols newer ABI versions added (a bare AttributeError from ctypes) and would be passed
+    # shifted arguments by the prototypes that changed
+    l.coin_abi_version.restype = c_int
+    if l.coin_abi_version() != ABI_VERSION:
+        raise CoinHipError(f"{LIB_PATH} implements C-ABI version {l.coin_abi_version()}, this package binds version {ABI_VERSION}: "
+                           "rebuild it (`make -C coin_amd/csrc`)")
     for name, argtypes in SIGNATURES.items():
         fn = getattr(l, name)
         fn.argtypes = argtypes
@@ -142,11 +149,7 @@ def lib() -> ctypes.CDLL:
     l.coin_conv_gemm_workspace_bytes.restype = ctypes.c_size_t
     l.coin_window_attn_bwd_workspace_bytes.argtypes = [c_int, c_int]
     l.coin_window_attn_bwd_workspace_bytes.restype = ctypes.c_size_t
-    l.coin_abi_version.restype = c_int
     l.coin_clear_last_error.restype = c_int
-    if l.coin_abi_version() != ABI_VERSION:   # a stale build: ctypes would pass shifted arguments to changed prototypes
-        raise CoinHipError(f"{LIB_PATH} implements C-ABI version {l.coin_abi_version()}, this package binds version {ABI_VERSION}: "
-                           "rebuild it (`make -C coin_amd/csrc`)")
     l.coin_build_arch.restype = c_char_p
     _lib = l
     return l

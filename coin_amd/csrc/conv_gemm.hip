@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   *reinterpret_cast<f32x4*>(dw + i) = a;
 }
 
-// mean / rstd (+ running statistics) from the per-row-tile pivoted partials: tile t holds n_t = clamp(rows - 256 t, 0, 256) values
+// mean / rstd (+ running statistics) from the per-row-tile pivoted partials: tile t holds n_t = clamp(rows - tile_rows t, 0, tile_rows) values
 // per channel as (pivot p, S1 = sum(x - p), S2 = sum((x - p)^2)) -> (mean_t, M2_t) -> Chan's pairwise update, in a fixed order.
 // Block = 16 channels x 64 tile lanes (thread = channel c16 + 16 * tile lane): a thread folds tiles lane, lane + 64, ... (a serial
 // chain of ~tiles/64 dependent updates; the [401 408, 512] res5 outputs have 1568 tiles), then one thread per channel folds the 64
@@ -607,7 +607,7 @@ template <int CPB, int SF_U>
 __global__ __launch_bounds__(1024) void conv_stats_finalize_kernel(const float* __restrict__ part, int tiles_m, int N, int64_t rows,
                                                                     float eps, float momentum, float* __restrict__ mean,
                                                                     float* __restrict__ rstd, float* __restrict__ running_mean,
-                                                                    float* __restrict__ running_var, int64_t* __restrict__ nbt) {
+                                                                    float* __restrict__ running_var, int64_t* __restrict__ nbt, int tile_rows) {
   constexpr int TL = 1024 / CPB;
   __shared__ float red[TL][3][CPB];
   if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;   // nn.BatchNorm2d's counter rides along (it was a launch of its own)
@@ -627,8 +627,8 @@ __global__ __launch_bounds__(1024) void conv_stats_finalize_kernel(const float* 
 #pragma unroll
       for (int u = 0; u < SF_U; ++u) {
         const int t = t0 + TL * u;
-        const int64_t left = rows - (int64_t)t * GM;
-        nb[u] = t < tiles_m ? (float)(left <= 0 ? 0 : (left < GM ? left : GM)) : 0.f;
+        const int64_t left = rows - (int64_t)t * tile_rows;
+        nb[u] = t < tiles_m ? (float)(left <= 0 ? 0 : (left < tile_rows ? left : tile_rows)) : 0.f;
         const float* __restrict__ p = part + (size_t)(t < tiles_m ? t : 0) * 3 * N + c;
         pv[u] = p[0];
         s1[u] = p[N];
@@ -676,17 +676,40 @@ __global__ __launch_bounds__(1024) void conv_stats_finalize_kernel(const float* 
 }  // namespace
 
 #ifdef COIN_LAB
-int coin_conv_gemm_force_impl = 0;  // lab hook (tools/gemm_lab.hip): 0 = default, 1 = p8, 2 = sq, 3 = rect
+int coin_conv_gemm_no_s4 = 0;       // lab hook: 1 = the round-5 dispatch (no small-map core) for same-box A/B runs of the whole step
+extern "C" void coin_lab_set_no_s4(int v) { coin_conv_gemm_no_s4 = v; }   // (tools/ab_bench.py; exported by the lab library only)
+int coin_conv_gemm_force_impl = 0;  // lab hook (tools/gemm_lab.hip): 0 = default, 1 = p8, 2 = sq, 3 = rect, 4 = s4 (128 x 128 x 32)
 #else
-static constexpr int coin_conv_gemm_force_impl = 0;   // the product library has no implementation switch
+static constexpr int coin_conv_gemm_force_impl = 0, coin_conv_gemm_no_s4 = 0;   // the product library has no implementation switch
 #endif
 
 extern "C" size_t coin_conv_gemm_stats_bytes(int M, int N) {
   if (M <= 0 || N <= 0) return 0;
-  return (size_t)((M + GM - 1) / GM) * 3 * (size_t)N * sizeof(float);
+  return (size_t)((M + 127) / 128) * 3 * (size_t)N * sizeof(float);   // enough for either tile height (128-row tiles: the small-map core)
 }
 
-extern "C" size_t coin_conv_gemm_workspace_bytes(int M, int N, int K) { return coin_p8_nt_workspace_bytes(M, N, K); }
+extern "C" size_t coin_conv_gemm_workspace_bytes(int M, int N, int K) {
+  const size_t p8 = coin_p8_nt_workspace_bytes(M, N, K), s4 = coin_s4_nt_workspace_bytes(M, N, K);
+  return p8 > s4 ? p8 : s4;
+}
+
+// Which core serves a launch: 1 = the persistent 256 x 256 x 64 kernel, 4 = the 128 x 128 x 32 small-map kernel, 0 = the round-2 kernels.
+// One function for the dispatch and for coin_conv_gemm_stats_tile_rows, so that the caller's reading of the partials cannot disagree
+// with the kernel that wrote them.
+static int conv_gemm_pick(int lda, int mode, int Cin, int ldb, int M, int N, int K) {
+  if (coin_conv_gemm_force_impl) {
+    if (coin_conv_gemm_force_impl == 4) return coin_s4_nt_ok(M, N, K, mode, Cin, lda, ldb) ? 4 : 0;
+    if (coin_conv_gemm_force_impl == 1) return coin_p8_nt_ok(M, N, K, mode, Cin, lda, ldb) ? 1 : 0;
+    return 0;
+  }
+  if (!coin_conv_gemm_no_s4 && coin_s4_nt_wanted(M, N, K) && coin_s4_nt_ok(M, N, K, mode, Cin, lda, ldb)) return 4;
+  if (coin_p8_nt_ok(M, N, K, mode, Cin, lda, ldb)) return 1;
+  return 0;
+}
+
+extern "C" int coin_conv_gemm_stats_tile_rows(int lda, int mode, int Cin, int ldb, int M, int N, int K) {
+  return conv_gemm_pick(lda, mode, Cin, ldb, M, N, K) == 4 ? 128 : 256;
+}
 
 extern "C" int coin_conv_gemm_bf16(const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb, void* C, int ldc,
                                    const void* R, int ldr, int M, int N, int K, float* stats, int64_t stats_rows, void* stream) {
@@ -712,7 +735,11 @@ extern "C" int coin_conv_gemm_bf16_rpool(const void* A, int lda, int mode, int H
     if (H <= 0 || W <= 0 || Cin <= 0 || M % (H * W)) return COIN_EINVAL;
     if (Cin % GK || K != 9 * Cin) return COIN_ESHAPE;
   }
-  if (coin_conv_gemm_force_impl > 1 || !coin_p8_nt_ok(M, N, K, mode, Cin, lda, ldb)) return COIN_ESHAPE;
+  const int pick = conv_gemm_pick(lda, mode, Cin, ldb, M, N, K);
+  if (pick == 4)
+    return coin_s4_nt_launch(A, lda, mode, H, W, Cin, B, ldb, C, ldc, R, ldr, M, N, K, nullptr, 0, ((uintptr_t)workspace & 15) ? nullptr : workspace,
+                             workspace_bytes, (hipStream_t)stream, out_h, out_w);
+  if (pick != 1) return COIN_ESHAPE;
   return coin_p8_nt_launch(A, lda, mode, H, W, Cin, B, ldb, C, ldc, R, ldr, M, N, K, nullptr, 0, ((uintptr_t)workspace & 15) ? nullptr : workspace,
                            workspace_bytes, (hipStream_t)stream, out_h, out_w);
 }
@@ -737,12 +764,16 @@ extern "C" int coin_conv_gemm_bf16_ws(const void* A, int lda, int mode, int H, i
   const bf16_t* a = (const bf16_t*)A;
   const bf16_t* b = (const bf16_t*)B;
   bf16_t* c = (bf16_t*)C;
-  // the persistent 8-phase core where the shape fits it; lab builds can force "sq" (the 256x256x32 kernel of round 2) / "rect" (256x128x64)
-  const int impl = coin_conv_gemm_force_impl ? coin_conv_gemm_force_impl - 1 : 0;
-  if (impl == 0 && coin_p8_nt_ok(M, N, K, mode, Cin, lda, ldb))
+  // the small-map core / the persistent 8-phase core where the shape fits them; lab builds can force "sq" (the 256x256x32 kernel of
+  // round 2) / "rect" (256x128x64)
+  const int pick = conv_gemm_pick(lda, mode, Cin, ldb, M, N, K);
+  if (pick == 4)
+    return coin_s4_nt_launch(A, lda, mode, H, W, Cin, B, ldb, C, ldc, R, ldr, M, N, K, stats, (long long)stats_rows,
+                             ((uintptr_t)workspace & 15) ? nullptr : workspace, workspace_bytes, st);
+  if (pick == 1)
     return coin_p8_nt_launch(A, lda, mode, H, W, Cin, B, ldb, C, ldc, R, ldr, M, N, K, stats, (long long)stats_rows,
                              ((uintptr_t)workspace & 15) ? nullptr : workspace, workspace_bytes, st);
-  const int force_rect = impl == 2;
+  const int force_rect = coin_conv_gemm_force_impl == 3;
   if (N % QN == 0 && !force_rect) {
     const int tm = (M + QM - 1) / QM, tn = N / QN;
     const size_t lds = (size_t)QNSTAGE * QSTAGE_BYTES;
@@ -783,15 +814,15 @@ extern "C" int coin_conv_gemm_bf16_ws(const void* A, int lda, int mode, int H, i
   return coin_launch_status();
 }
 
-extern "C" int coin_conv_gemm_stats_finalize(const float* partials, int M, int N, int64_t rows, float eps, float momentum, float* mean,
+extern "C" int coin_conv_gemm_stats_finalize(const float* partials, int M, int N, int64_t rows, int tile_rows, float eps, float momentum, float* mean,
                                              float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream) {
-  if (!partials || !mean || !rstd || M <= 0 || N <= 0 || rows <= 0 || rows > M) return COIN_EINVAL;
+  if (!partials || !mean || !rstd || M <= 0 || N <= 0 || rows <= 0 || rows > M || (tile_rows != 128 && tile_rows != 256)) return COIN_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return COIN_EINVAL;
   // 8 channels x 128 tile lanes per workgroup, 8 tiles per round (tools/statsfin_bench.py, us per call incl. the wrapper's ~8 us floor:
   // [401408, 512] 16.3, [100352, 2048] 11.4, [100352, 512] 8.3; 16 channels x 64 lanes: 24.6 / 14.9 / 14.4; 4 x 256: 20.5 / 20.9 / 8.4)
-  const int tiles = (M + GM - 1) / GM;
+  const int tiles = (M + tile_rows - 1) / tile_rows;
   conv_stats_finalize_kernel<8, 8><<<(N + 7) / 8, 1024, 0, (hipStream_t)stream>>>(partials, tiles, N, rows, eps, momentum, mean, rstd, running_mean,
-                                                                                 running_var, num_batches_tracked);
+                                                                                 running_var, num_batches_tracked, tile_rows);
   return coin_launch_status();
 }
 

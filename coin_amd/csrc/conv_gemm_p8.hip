@@ -25,6 +25,7 @@
 #include <stdlib.h>
 #include "common.h"
 #include "conv_gemm_p8.h"
+#include "conv_gemm_dev.h"
 
 // Lab switches (tools/gemm_lab: zero-page DMA, epilogue off, s_memtime stamps, split-K / stagger overrides) exist only in objects
 // compiled with -DCOIN_LAB (tools/build_lab.sh); in the product library every P8_DBG() below is the constant 0 and no switch is linked.
@@ -43,31 +44,6 @@ constexpr int P_HALF = 128 * PK * 2;   // 16 KiB
 constexpr int P_KT = 4 * P_HALF;       // A-lo | A-hi | B-lo | B-hi
 constexpr int P_IMG = 2 * P_KT;        // epilogue image: 128 rows x 256 B
 constexpr int P_LDS = P_IMG + 128 * 256;
-
-// Range-checked buffer LDS-DMA of 16 bytes per lane: address = base + voff (per lane) + soff (wave-uniform); an offset at or beyond
-// `bytes` writes zeros.  (A plain function on purpose: called with these builtins directly, the function TEMPLATES below are rejected
-// by the host pass of hipcc 7.2 with a bare "substitution failure".)
-__device__ __forceinline__ void blds16(const void* base, unsigned bytes, unsigned voff, unsigned soff, void* lds_wave_base) {
-  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
-}
-
-#define P8_SCHED() __builtin_amdgcn_sched_barrier(0)
-// raw barrier (no counter is waited for: LDS-DMA stays in flight across it) + a compiler-level memory fence
-#define P8_BAR()                      \
-  do {                                \
-    asm volatile("" ::: "memory");    \
-    __builtin_amdgcn_s_barrier();     \
-    asm volatile("" ::: "memory");    \
-  } while (0)
-// epilogue barrier: this wave's LDS accesses are complete, then the workgroup barrier; global loads / stores / DMA are NOT waited for
-#define P8_LDS_SYNC()                                   \
-  do {                                                  \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-    __builtin_amdgcn_s_barrier();                       \
-    asm volatile("" ::: "memory");                      \
-    P8_SCHED();                                         \
-  } while (0)
 
 // XCD-aware order of the persistent walk: logical item `it` (block b = it % G in round it / G) -> position in the tile list such
 // that the blocks of one XCD (equal b % 8) work on neighbouring positions (which share operand panels) in every round.
@@ -122,7 +98,6 @@ __device__ __forceinline__ P8Items p8_items(const P8Args& p, int b, int G, int n
 // ---------------------------------------------------------------------------------------------------------------- NT kernel
 // LDS image of a half-tile: 128 rows x 128 B; one DMA instruction writes 8 rows; 16-byte chunk c of row r sits at chunk c ^ (r & 7)
 // (applied on the SOURCE address; the fragment reads apply the same XOR): conflict-free ds_read_b128 for the 16x16x32 operands.
-constexpr unsigned P8_OOB = 0x80000000u;  // a buffer offset beyond every operand (host: sizes < 2^31): the range-checked DMA writes zeros
 
 template <bool GATHER3>
 struct NtCursor {
@@ -204,39 +179,6 @@ __device__ __forceinline__ void nt_stage(const NtCursor<GATHER3>& c, const P8Arg
   }
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// 8 bf16 -> 4 pairs of floats (element 2k in .x, 2k + 1 in .y): one shift / one mask per element, exact
-__device__ __forceinline__ void p8_pairs(const bf16x8& v, f32x2 (&o)[4]) {
-  const uint4 u = __builtin_bit_cast(uint4, v);
-  const unsigned w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    o[k].x = __builtin_bit_cast(float, w[k] << 16);
-    o[k].y = __builtin_bit_cast(float, w[k] & 0xffff0000u);
-  }
-}
-
-// t[i] <- sum of t[i] over lanes l, l ^ 16, l ^ 32, l ^ 48 (the four 16-lane rows of the wave), in every lane.
-// v_permlane32_swap vdst, src: lanes 32-63 of vdst <-> lanes 0-31 of src;  v_permlane16_swap: odd rows of vdst <-> even rows of src.
-// With vdst = src = x the two results add up to the pair sums.  (`s_nop 1`: a vector-ALU write of a swap operand needs two wait
-// states before the swap reads it; inline asm is not covered by the compiler's hazard recogniser.)
-__device__ __forceinline__ void p8_rows_sum(float (&t)[8]) {
-  float u[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) u[i] = t[i];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(t[i]), "+v"(u[i]));
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    t[i] += u[i];
-    u[i] = t[i];
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(t[i]), "+v"(u[i]));
-#pragma unroll
-  for (int i = 0; i < 8; ++i) t[i] += u[i];
-}
-
 // Epilogue of one output tile: four 128 x 128 quadrants through the 32 KiB image -> whole 256-byte rows (+ residual, + statistics of
 // the stored values).  Workgroup-wide (all 512 threads, aligned); `img` = 32 KiB of LDS.
 template <bool STATS>
@@ -286,20 +228,7 @@ __device__ __forceinline__ void p8_epilogue(const P8Args& p, f32x4 (&acc)[2][2][
           int grow = m0 + ah * 128 + q * 32 + rsub;
           grow = grow < p.M ? grow : p.M - 1;
           size_t rrow = (size_t)grow;
-          if (p.rp_w) {   // wave-uniform: pooled residual
-            // magic = ceil(2^32 / d): umulhi(x, magic) is floor(x / d) or one more (the excess x * (magic * d - 2^32) / (d * 2^32) is
-            // below 1 for every 32-bit x) -- the fix-up makes both quotients exact for every map size (round-4 ADVICE: without it
-            // [2, 200, 336] maps lost the last pixel of an image)
-            int n = (int)__umulhi((unsigned)grow, p.rp_magic_hw);
-            n -= (unsigned)n * (unsigned)(p.rp_h * p.rp_w) > (unsigned)grow ? 1 : 0;
-            const int rem = grow - n * (p.rp_h * p.rp_w);
-            int h = (int)__umulhi((unsigned)rem, p.rp_magic_w);
-            h -= h * p.rp_w > rem ? 1 : 0;
-            const int w = rem - h * p.rp_w;
-            const int oh = h >> 1, ow = w >> 1, OH = p.rp_h >> 1, OW = p.rp_w >> 1;
-            rscale[q] = (oh < OH && ow < OW) ? 0.25f : 0.f;
-            rrow = ((size_t)n * OH + (oh < OH ? oh : OH - 1)) * OW + (ow < OW ? ow : OW - 1);
-          }
+          if (p.rp_w) rrow = p8_pooled_row(grow, p.rp_h, p.rp_w, p.rp_magic_hw, p.rp_magic_w, rscale[q]);   // wave-uniform: pooled residual
           rr[q] = *reinterpret_cast<const bf16x8*>(p.R + rrow * p.ldr + gcol);
         }
       }

@@ -245,7 +245,10 @@ def conv_gemm(a: torch.Tensor, w: torch.Tensor, spatial: Optional[Tuple[int, int
         raise CoinHipError("conv_gemm: `residual` must be a bf16 [M, N] matrix with contiguous rows")
     part = None
     if stats_rows is not None:
-        part = torch.empty(_lib.lib().coin_conv_gemm_stats_bytes(m, n) // 4, dtype=torch.float32, device=a.device)
+        # row tiles of 256 (the persistent core) or 128 rows (the small-map core): the partials tensor is sized for the kernel that
+        # will run -- the query IS the library's dispatch function -- and `conv_stats_finalize` reads the tile height off its length
+        tr = _lib.lib().coin_conv_gemm_stats_tile_rows(a.stride(0), mode, cin, w.stride(0), m, n, k)
+        part = torch.empty(((m + tr - 1) // tr) * 3 * n, dtype=torch.float32, device=a.device)
     wsb = _lib.lib().coin_conv_gemm_workspace_bytes(m, n, k)   # fp32 partial tiles of the split-K tail round (0: not needed for this shape)
     ws = None
     if wsb:
@@ -430,11 +433,16 @@ def _nbt(t: Optional[torch.Tensor]):
 def conv_stats_finalize(part: torch.Tensor, m: int, n: int, rows: int, eps: float, momentum: float,
                         running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None,
                         num_batches_tracked: Optional[torch.Tensor] = None):
-    """Per-channel batch mean / rstd (+ in-place running statistics, + the module's batch counter) from `conv_gemm`'s partials."""
+    """Per-channel batch mean / rstd (+ in-place running statistics, + the module's batch counter) from `conv_gemm`'s partials
+    ([row tiles, 3, n] floats; the tile height -- 128 or 256 rows -- follows from the tensor's length, see `conv_gemm`)."""
     _dev(part, running_mean, running_var, _nbt(num_batches_tracked))
+    tiles = part.numel() // (3 * n)
+    if tiles * 3 * n != part.numel() or tiles not in ((m + 127) // 128, (m + 255) // 256):
+        raise CoinHipError(f"conv_stats_finalize: {part.numel()} floats are not the partials of a [{m}, {n}] output")
+    tile_rows = 256 if tiles == (m + 255) // 256 else 128   # (m <= 128: one tile either way)
     mean = torch.empty(n, dtype=torch.float32, device=part.device)
     rstd = torch.empty(n, dtype=torch.float32, device=part.device)
-    check(_lib.lib().coin_conv_gemm_stats_finalize(_p(part), m, n, int(rows), float(eps), float(momentum), _p(mean), _p(rstd), _p(running_mean),
+    check(_lib.lib().coin_conv_gemm_stats_finalize(_p(part), m, n, int(rows), tile_rows, float(eps), float(momentum), _p(mean), _p(rstd), _p(running_mean),
                                                    _p(running_var), _p(num_batches_tracked), _stream()), "coin_conv_gemm_stats_finalize")
     return mean, rstd
 

@@ -31,7 +31,7 @@ extern "C" {
 
 /* Bumped whenever a prototype below changes (2: round 4's signature changes -- coin_sgd_step gate, coin_bn_* ReLU mask, coin_anchor_match
  * candidate sets, ... -- and round 5's additions).  The Python binding refuses a library whose version differs (coin_amd/_lib.py). */
-#define COIN_ABI_VERSION 2
+#define COIN_ABI_VERSION 3
 
 enum { COIN_F32 = 0, COIN_BF16 = 1 };
 enum { COIN_NCHW = 0, COIN_NHWC = 1 };
@@ -198,12 +198,16 @@ int coin_cosine_logits_bwd(const float* d_scores, const void* feats, int ldf, co
  * The data-gradient is the same contraction with the weight re-laid as [Cin][flipped tap][Cout].
  * R (optional, bf16 [M,N], row stride ldr): C = bf16(bf16(Aop.B^T) + R) -- the other branch's gradient where a Bottleneck's input
  *   fans out to conv1 and to the identity path (coin/modeling/utils.py:77-90): the sum autograd would form with a separate pass.
- * stats (optional): per (256-row tile, column) statistics of the STORED bf16 outputs over rows < stats_rows, as
+ * stats (optional): per (row tile, column) statistics of the STORED bf16 outputs over rows < stats_rows, as
  *   stats[tile][0][n] = pivot (the tile's first row), [1][n] = sum(x - pivot), [2][n] = sum((x - pivot)^2);
- *   coin_conv_gemm_stats_bytes(M, N) bytes.  coin_conv_gemm_stats_finalize turns them into the train-mode BatchNorm
+ *   coin_conv_gemm_stats_bytes(M, N) bytes (enough for either tile height).  A row tile is 256 rows on the persistent 256 x 256 core and
+ *   128 rows on the small-map core (ABI 3; conv_gemm_s4.hip: launches whose 256 x 256 tiling has fewer than three rounds of tiles for
+ *   the chip, and every N < 256): coin_conv_gemm_stats_tile_rows, called with the launch's own arguments, says which -- it is the
+ *   dispatch function itself.  coin_conv_gemm_stats_finalize(tile_rows) turns the partials into the train-mode BatchNorm
  *   statistics (mean, 1/sqrt(var + eps), running statistics as nn.BatchNorm2d) in a fixed summation order: the separate
  *   statistics pass over the activation (coin_bn_stats) is not needed after a convolution run through this entry point. */
 size_t coin_conv_gemm_stats_bytes(int M, int N);
+int coin_conv_gemm_stats_tile_rows(int lda, int mode, int Cin, int ldb, int M, int N, int K);
 int coin_conv_gemm_bf16(const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb,
                         void* C, int ldc, const void* R, int ldr, int M, int N, int K, float* stats, int64_t stats_rows,
                         void* stream);
@@ -219,11 +223,11 @@ int coin_conv_gemm_bf16_ws(const void* A, int lda, int mode, int H, int W, int C
  * output pixel (n, h, w) of the grid [M / (out_h * out_w), out_h, out_w]; R: [M / (out_h * out_w) * (out_h / 2) * (out_w / 2), N] bf16 (floor
  * pooling: pixels whose h / 2 or w / 2 falls off the pooled map add nothing).  R = the gradient of `AvgPool2d(2)` applied to the tensor whose
  * data gradient this GEMM produces: the downsample branch of the CLIP Bottleneck (coin/modeling/utils.py:60-75, 84-88: `avgpool` +
- * `downsample`) -- the pool's backward pass folded into the residual add.  COIN_ESHAPE when the persistent kernel does not serve the shape
- * (N % 256, K % 64 ...): the caller then materialises the pool gradient (coin_avgpool2_bwd) and passes it as a plain residual. */
+ * `downsample`) -- the pool's backward pass folded into the residual add.  COIN_ESHAPE when neither the persistent nor the small-map kernel
+ * serves the shape (K % 64, N % 8 ...): the caller then materialises the pool gradient (coin_avgpool2_bwd) and passes it as a plain residual. */
 int coin_conv_gemm_bf16_rpool(const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb, void* C, int ldc, const void* R,
                               int ldr, int out_h, int out_w, int M, int N, int K, void* workspace, size_t workspace_bytes, void* stream);
-int coin_conv_gemm_stats_finalize(const float* partials, int M, int N, int64_t rows, float eps, float momentum,
+int coin_conv_gemm_stats_finalize(const float* partials, int M, int N, int64_t rows, int tile_rows, float eps, float momentum,
                                   float* mean, float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                   void* stream);
 

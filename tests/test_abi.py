@@ -97,7 +97,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.coin_mil_ce_fwd_bwd(None, 9, None, None, None, 4, 9, 1, 1, None, None, None) == -1
     assert lib.coin_nms_batched(None, None, 1, 20000, 0.5, 10, None, None, None, None) == -1
     assert lib.coin_conv_gemm_bf16(None, 64, 0, 0, 0, 0, None, 64, None, 8, None, 0, 256, 8, 64, None, 0, None) == -1
-    assert lib.coin_conv_gemm_stats_bytes(401408, 512) == 1568 * 3 * 512 * 4
+    assert lib.coin_conv_gemm_stats_bytes(401408, 512) == 3136 * 3 * 512 * 4   # sized for 128-row tiles (ABI 3)
     assert lib.coin_weight_dgrad_layout(None, 3, 8, None) == -1 and lib.coin_weight_dgrad_layout(None, 0, 0, None) == 0
     assert lib.coin_roi_align_fwd_levels(None, 4, 1, 8, None, None, 1, 7, 7, 0, 1, None, 1, None) == -1
     assert lib.coin_roi_align_bwd_level(None, 1, 8, 4, 4, None, None, 0, 1, 7, 7, 0.25, 0, 1, None, 1, None) == -1

@@ -229,11 +229,19 @@ def test_conv_gemm_3x3_vs_torch(K, nb, h, w, cin, cout):
 
 
 @pytest.mark.parametrize("nb,h,w,cin,cout,ks", [(2048, 14, 14, 1024, 512, 1), (2048, 14, 14, 512, 512, 3), (2048, 7, 7, 512, 2048, 1),
-                                                (2048, 7, 7, 2048, 512, 1), (2048, 7, 7, 512, 512, 3)])
+                                                (2048, 7, 7, 2048, 512, 1), (2048, 7, 7, 512, 512, 3),
+                                                # round 6: the backbone's maps of the benchmark (res4 50 x 83, res3 100 x 167, layer2's first block at
+                                                # 200 x 333) and of the targetDET step (41 x 83): the launches of the captured backbone stretch --
+                                                # most of them on the 128 x 128 small-map core (128-row statistics tiles), the long-K ones on the
+                                                # persistent kernel
+                                                (4, 50, 83, 1024, 256, 1), (4, 50, 83, 256, 256, 3), (4, 50, 83, 256, 1024, 1), (4, 50, 83, 512, 1024, 1),
+                                                (4, 100, 167, 512, 128, 1), (4, 100, 167, 128, 128, 3), (4, 100, 167, 128, 512, 1), (4, 100, 167, 256, 256, 3),
+                                                (4, 100, 167, 512, 256, 1), (2, 200, 333, 128, 128, 3), (2, 200, 333, 256, 128, 1), (3, 41, 83, 256, 256, 3),
+                                                (3, 41, 83, 1024, 256, 1), (4, 50, 83, 1024, 1024, 3)])
 def test_conv_gemm_at_the_timed_shapes_vs_fp64_on_sampled_pixels(K, nb, h, w, cin, cout, ks):
-    """coin_conv_gemm_bf16 at the benchmark's own res5 launch shapes (2048 RoIs: M = 401 408 / 100 352 pixels): 4096 random output
-    pixels against an fp64 evaluation of the same bf16 operands (forward and data gradient), and the fused BatchNorm statistics
-    against fp64 statistics of the stored output."""
+    """coin_conv_gemm_bf16 at the benchmark's own launch shapes (res5: 2048 RoIs, M = 401 408 / 100 352 pixels; the trainable backbone
+    stages: M = 16 600 ... 266 400): 4096 random output pixels against an fp64 evaluation of the same bf16 operands (forward and data
+    gradient), and the fused BatchNorm statistics against fp64 statistics of the stored output."""
     g = torch.Generator(device="cuda").manual_seed(nb + cin + ks)
     x = (torch.randn((nb, h, w, cin), generator=g, device="cuda") * 0.7).to(torch.bfloat16)
     wt = (torch.randn((cout, ks, ks, cin), generator=g, device="cuda") * (2.0 / (cin * ks * ks)) ** 0.5).to(torch.bfloat16)

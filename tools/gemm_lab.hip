@@ -69,12 +69,17 @@ static const Shape kShapes[] = {{"l4.0.conv1", 2048, 14, 14, 1024, 512, 1}, {"l4
                                 {"l4.0.down", 2048, 7, 7, 1024, 2048, 1},   {"l4.1.conv1", 2048, 7, 7, 2048, 512, 1},  {"l4.1.conv2", 2048, 7, 7, 512, 512, 3},
                                 {"rpn.conv", 4, 50, 83, 1024, 1024, 3},     {"l3.x.conv2", 4, 50, 83, 256, 256, 3},    // backbone-resolution convolutions
                                 {"l2.x.conv2", 4, 100, 167, 128, 128, 3},   {"l2.x.conv1", 4, 100, 167, 512, 128, 1},  {"l2.x.conv3", 4, 100, 167, 128, 512, 1},
-                                {"l3.x.conv1", 4, 50, 83, 1024, 256, 1},    {"l3.x.conv3", 4, 50, 83, 256, 1024, 1}};   // layer3's 1x1 convolutions: on this kernel since the stretch is captured  // N = 128: a half-width column tile (round 5)
+                                {"l3.x.conv1", 4, 50, 83, 1024, 256, 1},    {"l3.x.conv3", 4, 50, 83, 256, 1024, 1},
+                                {"l2.0.conv2", 4, 200, 333, 128, 128, 3},   {"l2.0.conv1", 4, 200, 333, 256, 128, 1},  {"l3.0.conv1", 4, 100, 167, 512, 256, 1},
+                                {"l3.0.conv2", 4, 100, 167, 256, 256, 3},   {"l2.0.down", 4, 100, 167, 256, 512, 1},   {"l3.0.down", 4, 50, 83, 512, 1024, 1}};   // layer3's 1x1 convolutions: on this kernel since the stretch is captured  // N = 128: a half-width column tile (round 5)
 
 static void* g_ws = nullptr;
 static size_t g_ws_bytes = 0;
 static int g_split = -1;   // coin_p8_splitk for the next p8 launches
 static int g_stag = -1;    // coin_p8_stagger for the next p8 launches
+static int g_s4split = -1; // coin_s4_split for the next s4 launches
+static int g_s4st = 0;     // coin_s4_stages
+static int g_s4wg = 0;     // coin_s4_maxwg
 
 static int run_gemm(int impl, const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb, void* C, int ldc, const void* R, int ldr,
                     int M, int N, int K, float* stats, int64_t stats_rows) {
@@ -85,10 +90,16 @@ static int run_gemm(int impl, const void* A, int lda, int mode, int H, int W, in
     g_ws_bytes = need;
   }
   coin_conv_gemm_force_impl = impl;
+  coin_s4_split = g_s4split;
+  coin_s4_stages = g_s4st;
+  coin_s4_maxwg = g_s4wg;
   coin_p8_splitk = g_split;
   coin_p8_stagger = g_stag >= 0 ? g_stag : (getenv("LAB_STAG") ? atoi(getenv("LAB_STAG")) : -1);
   const int rc = coin_conv_gemm_bf16_ws(A, lda, mode, H, W, Cin, B, ldb, C, ldc, R, ldr, M, N, K, stats, stats_rows, g_ws, g_ws_bytes, nullptr);
   coin_conv_gemm_force_impl = 0;
+  coin_s4_split = -1;
+  coin_s4_stages = 0;
+  coin_s4_maxwg = 0;
   coin_p8_splitk = -1;
   coin_p8_stagger = -1;
   return rc;
@@ -112,7 +123,9 @@ static double ref_elem(const std::vector<bf16raw>& A, const std::vector<bf16raw>
   return s;
 }
 
+static int g_cand = 1, g_base = 2;   // check_case: implementation under test / the one it is compared with bit by bit
 static int check_case(const char* name, int M, int N, int K, int mode, int H, int W, int Cin, bool with_r, int64_t stats_rows, int grid_note) {
+  const int tr1 = g_cand == 4 ? 128 : 256;
   const int lda = mode == 0 ? K : Cin;
   const size_t an = (size_t)M * lda, bn = (size_t)N * K, cn = (size_t)M * N;
   void *A, *B, *C0, *C1, *R = nullptr;
@@ -124,10 +137,11 @@ static int check_case(const char* name, int M, int N, int K, int mode, int H, in
   float *S0 = nullptr, *S1 = nullptr;
   const size_t sb = coin_conv_gemm_stats_bytes(M, N);
   if (stats_rows > 0) { CK(hipMalloc(&S0, sb)); CK(hipMalloc(&S1, sb)); CK(hipMemset(S0, 0, sb)); CK(hipMemset(S1, 0, sb)); }
-  int rc0 = run_gemm(2, A, lda, mode, H, W, Cin, B, K, C0, N, R, N, M, N, K, S0, stats_rows);
-  g_split = grid_note;   // 1: split-K tail forced on wherever it is possible
-  int rc1 = run_gemm(1, A, lda, mode, H, W, Cin, B, K, C1, N, R, N, M, N, K, S1, stats_rows);
+  int rc0 = run_gemm(g_base, A, lda, mode, H, W, Cin, B, K, C0, N, R, N, M, N, K, S0, stats_rows);
+  if (g_cand == 4) g_s4split = grid_note; else g_split = grid_note;   // p8: 1 = split-K tail forced on wherever it is possible; s4: K pieces per tile
+  int rc1 = run_gemm(g_cand, A, lda, mode, H, W, Cin, B, K, C1, N, R, N, M, N, K, S1, stats_rows);
   g_split = -1;
+  g_s4split = -1;
   CK(hipDeviceSynchronize());
   if (rc0 || rc1) { printf("CHECK %s: launch rc %d %d\n", name, rc0, rc1); return 1; }
   std::vector<bf16raw> h0(cn), h1(cn);
@@ -165,8 +179,8 @@ static int check_case(const char* name, int M, int N, int K, int mode, int H, in
   if (stats_rows > 0) {
     float *m0, *r0, *m1, *r1;
     CK(hipMalloc(&m0, N * 4)); CK(hipMalloc(&r0, N * 4)); CK(hipMalloc(&m1, N * 4)); CK(hipMalloc(&r1, N * 4));
-    coin_conv_gemm_stats_finalize(S0, M, N, stats_rows, 1e-5f, 0.1f, m0, r0, nullptr, nullptr, nullptr, nullptr);
-    coin_conv_gemm_stats_finalize(S1, M, N, stats_rows, 1e-5f, 0.1f, m1, r1, nullptr, nullptr, nullptr, nullptr);
+    coin_conv_gemm_stats_finalize(S0, M, N, stats_rows, 256, 1e-5f, 0.1f, m0, r0, nullptr, nullptr, nullptr, nullptr);
+    coin_conv_gemm_stats_finalize(S1, M, N, stats_rows, tr1, 1e-5f, 0.1f, m1, r1, nullptr, nullptr, nullptr, nullptr);
     CK(hipDeviceSynchronize());
     std::vector<float> a(N), b(N), c(N), d(N);
     CK(hipMemcpy(a.data(), m0, N * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), m1, N * 4, hipMemcpyDeviceToHost));
@@ -260,6 +274,76 @@ static void bench_shape(const Shape& sh, int iters, int rounds) {
       std::sort(med[v].begin(), med[v].end());
       const float m = med[v][med[v].size() / 2];
       printf(", \"%s_ms\": %.4f, \"%s_TF\": %.1f, \"%s_best_TF\": %.1f", names[v], m, names[v], flop / m / 1e9, names[v], flop / best[v] / 1e9);
+    }
+    printf("}\n");
+    fflush(stdout);
+    hipFree(A); hipFree(B); hipFree(C); hipFree(S);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+  }
+}
+
+// the small-map core against the kernels that served these shapes until round 5 (p8 where N >= 256, the 256 x 128 kernel for N = 128)
+static void bench_s4(const Shape& sh, int iters, int rounds) {
+  const int M = sh.nb * sh.h * sh.w, mode = sh.ks == 3 ? 1 : 0;
+  for (int dir = 0; dir < 2; ++dir) {
+    const int Cin = dir == 0 ? sh.ci : sh.co, N = dir == 0 ? sh.co : sh.ci, K = sh.ks * sh.ks * Cin;
+    const size_t an = (size_t)M * Cin, bn = (size_t)N * K, cn = (size_t)M * N;
+    void *A, *B, *C;
+    float* S;
+    CK(hipMalloc(&A, an * 2)); CK(hipMalloc(&B, bn * 2)); CK(hipMalloc(&C, cn * 2));
+    CK(hipMalloc(&S, coin_conv_gemm_stats_bytes(M, N)));
+    fill(A, an, 0x1234u + dir, 1.0f);
+    fill(B, bn, 0x9876u + dir, 0.05f);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    constexpr int NV = 14;
+    const int old_impl = N >= 256 ? 1 : 3;
+    const int impls[NV] = {old_impl, old_impl, 4, 4, 0, 4, 4, 4, 4, 4, 4, 4, 4, 4};
+    const bool stats[NV] = {false, true, false, true, true, false, false, false, false, false, false, false, false, false};
+    const int splits[NV] = {-1, -1, -1, -1, -1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+    const int stages[NV] = {0, 0, 0, 0, 0, 2, 12, 13, 14, 12, 12, 12, 12, 2};
+    const int maxwg[NV] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int dbgs[NV] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 2, 4, 7, 7};
+    const char* names[NV] = {"old", "old+stats", "s4", "s4+stats", "default+stats", "k32n2", "k64n2", "k64n3", "k64n4", "k64_nomem", "k64_nomfma", "k64_noepi", "k64_nothing", "k32_nothing"};
+    std::vector<float> med[NV];
+    for (int r = 0; r < rounds; ++r)
+      for (int v = 0; v < NV; ++v) {
+        if (dir == 1 && stats[v]) continue;
+        g_s4split = splits[v];
+        g_s4st = stages[v];
+        g_s4wg = maxwg[v];
+        coin_s4_debug = dbgs[v];
+        run_gemm(impls[v], A, Cin, mode, sh.h, sh.w, Cin, B, K, C, N, nullptr, 0, M, N, K, stats[v] ? S : nullptr, M);  // warm
+        float ms = 0;
+        if (g_cold) {
+          for (int i = 0; i < iters; ++i) {
+            flush_caches();
+            CK(hipEventRecord(e0));
+            run_gemm(impls[v], A, Cin, mode, sh.h, sh.w, Cin, B, K, C, N, nullptr, 0, M, N, K, stats[v] ? S : nullptr, M);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            ms += time_ms(e0, e1) / iters;
+          }
+        } else {
+          CK(hipEventRecord(e0));
+          for (int i = 0; i < iters; ++i) run_gemm(impls[v], A, Cin, mode, sh.h, sh.w, Cin, B, K, C, N, nullptr, 0, M, N, K, stats[v] ? S : nullptr, M);
+          CK(hipEventRecord(e1));
+          CK(hipEventSynchronize(e1));
+          ms = time_ms(e0, e1) / iters;
+        }
+        med[v].push_back(ms);
+      }
+    g_s4split = -1;
+    g_s4st = 0;
+    g_s4wg = 0;
+    coin_s4_debug = 0;
+    const double flop = 2.0 * M * (double)N * K;
+    printf("{\"shape\": \"%s\", \"dir\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d", sh.name, dir == 0 ? "fwd" : "dgrad", M, N, K);
+    for (int v = 0; v < NV; ++v) {
+      if (med[v].empty()) continue;
+      std::sort(med[v].begin(), med[v].end());
+      const float m = med[v][med[v].size() / 2];
+      printf(", \"%s_us\": %.1f, \"%s_TF\": %.0f", names[v], m * 1e3, names[v], flop / m / 1e9);
     }
     printf("}\n");
     fflush(stdout);
@@ -455,6 +539,35 @@ int main(int argc, char** argv) {
     fails += check_case("N=384 1x1 tail rows + R", 256 * 20 + 50, 384, 256, 0, 0, 0, 0, true, 0, 0);
     fails += check_case("N=640 splitK forced", 256 * 103 + 9, 640, 2048, 0, 0, 0, 0, false, 256 * 103 + 9, 1);
     printf("CHECK total failures: %d\n", fails);
+  }
+  if (!strcmp(what, "scheck") || !strcmp(what, "all")) {
+    // round 6: the 128 x 128 x 32 small-map core (impl 4) against the persistent kernel (impl 1) -- same K order, same MFMA: whole tiles
+    // must have the SAME BITS (differing=0); K pieces (last argument > 1) differ by fp32 summation order only -- and against fp64
+    g_cand = 4; g_base = 1;
+    fails += check_case("s4 l3.conv1 1x1 + stats", 4 * 50 * 83, 256, 1024, 0, 0, 0, 0, false, 4 * 50 * 83, 1);
+    fails += check_case("s4 l3.conv3 1x1 + stats", 4 * 50 * 83, 1024, 256, 0, 0, 0, 0, false, 4 * 50 * 83, 1);
+    fails += check_case("s4 l3.conv3 dgrad + R", 4 * 50 * 83, 256, 1024, 0, 0, 0, 0, true, 0, 1);
+    fails += check_case("s4 l3.conv2 3x3 + stats", 4 * 50 * 83, 256, 2304, 1, 50, 83, 256, false, 4 * 50 * 83, 1);
+    fails += check_case("s4 l3.conv2 3x3 split 2 + stats prefix", 4 * 50 * 83, 256, 2304, 1, 50, 83, 256, false, 3 * 50 * 83, 2);
+    fails += check_case("s4 l3.conv2 3x3 split 4 + R", 4 * 50 * 83, 256, 2304, 1, 50, 83, 256, true, 0, 4);
+    fails += check_case("s4 l2.conv3 1x1 K=128", 4 * 100 * 167, 512, 128, 0, 0, 0, 0, false, 4 * 100 * 167, 1);
+    fails += check_case("s4 l2 1x1 tail rows + R", 128 * 37 + 50, 384, 256, 0, 0, 0, 0, true, 0, 1);
+    fails += check_case("s4 one tile", 100, 256, 512, 0, 0, 0, 0, true, 100, 1);
+    fails += check_case("s4 3x3 Cin=64 7x7 tail", 49 * 77, 256, 9 * 64, 1, 7, 7, 64, false, 49 * 70, 1);
+    fails += check_case("s4 default policy 3x3", 4 * 50 * 83, 256, 2304, 1, 50, 83, 256, false, 4 * 50 * 83, -1);
+    g_base = 3;   // N = 128 / N % 128 != 0: the persistent kernel does not serve them -- against the round-2 256 x 128 kernel
+    fails += check_case("s4 l2.conv2 3x3 N=128 + stats", 4 * 100 * 167, 128, 1152, 1, 100, 167, 128, false, 4 * 100 * 167, 1);
+    fails += check_case("s4 l2.conv1 1x1 N=128 + R", 4 * 100 * 167, 128, 512, 0, 0, 0, 0, true, 0, 1);
+    fails += check_case("s4 N=64 1x1 + stats", 4 * 100 * 167, 64, 256, 0, 0, 0, 0, false, 4 * 100 * 167, 1);
+    fails += check_case("s4 N=192 3x3 + R + stats prefix", 3 * 23 * 31, 192, 9 * 64, 1, 23, 31, 64, true, 2 * 23 * 31, 1);
+    g_cand = 1; g_base = 2;
+    printf("SCHECK total failures: %d\n", fails);
+  }
+  if (!strcmp(what, "sbench")) {
+    for (const Shape& s : kShapes) {
+      if (getenv("LAB_SHAPES") && !strstr(getenv("LAB_SHAPES"), s.name)) continue;
+      bench_s4(s, iters, g_cold ? 2 : 5);
+    }
   }
   if (!strcmp(what, "wcheck") || !strcmp(what, "all")) {
     fails += check_wgrad("1x1 small", 64 * 50 + 17, 256, 256, 0, 0, 0);
