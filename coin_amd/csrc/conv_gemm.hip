@@ -835,10 +835,12 @@ static int wgrad_slices(int M, int tiles) {
 
 extern "C" size_t coin_conv_wgrad_workspace_bytes(int M, int Cout, int Ktot) {
   if (M <= 0 || Cout <= 0 || Ktot <= 0 || Cout % 128 || Ktot % 128) return 0;
-  if (Cout % WB || Ktot % WB) return coin_p8_tn_workspace_bytes(M, Cout, Ktot);   // odd multiples of 128: the persistent kernel only
+  const size_t s4 = coin_s4_tn_workspace_bytes(M, Cout, Ktot);
+  const size_t p8 = coin_p8_tn_workspace_bytes(M, Cout, Ktot);  // any of the kernels may be selected at launch
+  const size_t both = s4 > p8 ? s4 : p8;
+  if (Cout % WB || Ktot % WB) return both;   // odd multiples of 128: not the sliced kernel
   const size_t sliced = (size_t)wgrad_slices(M, (Cout / WB) * (Ktot / WB)) * Cout * (size_t)Ktot * sizeof(float);
-  const size_t p8 = coin_p8_tn_workspace_bytes(M, Cout, Ktot);  // either kernel may be selected at launch
-  return sliced > p8 ? sliced : p8;
+  return sliced > both ? sliced : both;
 }
 
 extern "C" int coin_conv_wgrad_bf16(const void* GY, const void* X, int mode, int H, int W, int Cin, int M, int Cout, int Ktot, float* dW,
@@ -847,7 +849,10 @@ extern "C" int coin_conv_wgrad_bf16(const void* GY, const void* X, int mode, int
   if (Cout % 128 || Cin % 128) return COIN_ESHAPE;
   if (mode == 0 ? Ktot != Cin : (Ktot != 9 * Cin || H <= 0 || W <= 0 || M % (H * W))) return COIN_EINVAL;
   if (((uintptr_t)GY & 15) || ((uintptr_t)X & 15) || ((uintptr_t)dW & 15) || ((uintptr_t)workspace & 15)) return COIN_EALIGN;
-  const bool use_old = coin_conv_gemm_force_impl ? coin_conv_gemm_force_impl != 1 : false;   // lab builds only
+  const bool use_old = coin_conv_gemm_force_impl ? (coin_conv_gemm_force_impl != 1 && coin_conv_gemm_force_impl != 4) : false;   // lab builds only
+  if (!use_old && coin_s4_tn_ok(M, Cout, Cin, Ktot, mode) &&
+      (coin_conv_gemm_force_impl == 4 || (coin_conv_gemm_force_impl == 0 && !coin_conv_gemm_no_s4 && coin_s4_tn_wanted(M, Cout, Cin))))
+    return coin_s4_tn_launch(GY, X, mode, H, W, Cin, M, Cout, Ktot, dW, workspace, (hipStream_t)stream);
   if (!use_old && coin_p8_tn_ok(M, Cout, Cin, Ktot, mode))
     return coin_p8_tn_launch(GY, X, mode, H, W, Cin, M, Cout, Ktot, dW, workspace, (hipStream_t)stream);
   if (Cout % WB || Cin % WB) return COIN_ESHAPE;   // the sliced kernel below needs whole 256 x 256 tiles

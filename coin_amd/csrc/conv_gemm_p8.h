@@ -20,6 +20,11 @@ COIN_HIDDEN size_t coin_s4_nt_workspace_bytes(int M, int N, int K);
 COIN_HIDDEN int coin_s4_nt_launch(const void* A, int lda, int mode, int H, int W, int Cin, const void* B, int ldb, void* C, int ldc, const void* R,
                                   int ldr, int M, int N, int K, float* stats, long long stats_rows, void* workspace, size_t workspace_bytes,
                                   hipStream_t st, int rp_h = 0, int rp_w = 0);
+COIN_HIDDEN bool coin_s4_tn_ok(int M, int Cout, int Cin, int Ktot, int mode);
+COIN_HIDDEN bool coin_s4_tn_wanted(int M, int Cout, int Cin);
+COIN_HIDDEN size_t coin_s4_tn_workspace_bytes(int M, int Cout, int Ktot);
+COIN_HIDDEN int coin_s4_tn_launch(const void* GY, const void* X, int mode, int H, int W, int Cin, int M, int Cout, int Ktot, float* dW, void* workspace,
+                                  hipStream_t st);
 #ifdef COIN_LAB   // development switches of tools/gemm_lab: not part of the product library (built without -DCOIN_LAB)
 COIN_HIDDEN extern int coin_conv_gemm_force_impl;
 COIN_HIDDEN extern int coin_p8_debug;
@@ -30,4 +35,5 @@ COIN_HIDDEN extern int coin_s4_split;
 COIN_HIDDEN extern int coin_s4_stages;
 COIN_HIDDEN extern int coin_s4_maxwg;
 COIN_HIDDEN extern int coin_s4_debug;
+COIN_HIDDEN extern int coin_s4_tn_wpc;
 #endif

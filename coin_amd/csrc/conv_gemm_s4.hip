@@ -493,3 +493,248 @@ int coin_s4_nt_launch(const void* A, int lda, int mode, int H, int W, int Cin, c
   }
   return coin_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------- TN (weight gradient)
+// dW[co][k] = sum over pixels m of gy[m][co] * xcol[m][k] for the same small maps: output tile 128 co x 128 k (one tap: Cin % 128 == 0),
+// K-tile = 32 pixels, 4 waves x (64 x 64), two stages of (G | X) = 2 x 8 KiB: 32 KiB of LDS, up to four workgroups per CU.
+// Why a second tile size here: the persistent kernel cuts the pixels over ALL its 256 workgroups and every workgroup writes a whole
+// 256 x 256 fp32 partial tile -- 64 MB of partials (written, then read by the reduction) for a [1024 x 256] gradient whose operands
+// are 42 MB; with 128 x 128 tiles and `wpc` workgroups per CU the partials are wpc x 16 MB, and a layer with 16 or 36 such tiles cuts the
+// pixels 16 or 7 times instead of 64.
+// Both operands are pixel-major: a K-tile is [32 pixels][128 channels] = 256-byte rows (one DMA instruction = 4 rows) and the MFMA
+// fragments (8 consecutive pixels of one channel per lane) come through ds_read_b64_tr_b16.  16-byte chunk c of row r sits at
+// chunk c ^ (((r & 3) << 1) | (((r >> 3) & 1) << 3)): the 8 rows a 32-lane half reads per transposed read (rows q, q + 8: 32 bytes each)
+// fall into 8 different 32-byte bank groups.
+// Work item = (pixel piece s, tile): pieces are dealt to the XCDs in contiguous ranges, so the workgroups of one XCD walk the same pixels
+// at the same time and share the gy / x rows through its L2.  A piece stores its fp32 accumulators in thread-private order;
+// conv_wgrad_s4_reduce_kernel sums the pieces of a tile in a fixed order (four interleaved chains joined in chain order: bit-reproducible).
+namespace {
+
+struct TsArgs {
+  const bf16_t* GY;
+  const bf16_t* X;
+  float* slab;
+  int M, Cout, Cin, Ktot, H, W;
+  int tiles_k, ntiles, nkt, S;
+  unsigned magic_w;   // ceil(2^32 / W)
+  int hw, r32;        // H * W, 32 % hw
+  unsigned g_bytes, x_bytes, x_bias;
+};
+
+constexpr unsigned TS_OOB = 0x80000000u;
+constexpr int TS_TILE = 32 * 256;       // 8 KiB: 32 pixels x 128 channels
+constexpr int TS_STAGE = 2 * TS_TILE;   // G | X
+
+__device__ __forceinline__ int ts_swz(int row) { return ((row & 3) << 1) | (((row >> 3) & 1) << 3); }
+
+typedef short ts16x4 __attribute__((ext_vector_type(4)));
+typedef short ts16x8 __attribute__((ext_vector_type(8)));
+
+// 8 consecutive pixels (rows r .. r + 3 and r + 4 .. r + 7: 1024 bytes on) of one channel per lane.  Inline asm: the intrinsic makes
+// hipcc drain every LDS-DMA in flight (see conv_gemm_p8.hip tn_frag); the consumers sit behind an explicit `s_waitcnt lgkmcnt(0)`.
+__device__ __forceinline__ bf16x8 ts_frag(unsigned adr) {
+  ts16x4 a, b;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a) : "v"(adr) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(b) : "v"(adr) : "memory");
+  const ts16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool GATHER3>
+__global__ __launch_bounds__(256, 4) void conv_wgrad_s4_kernel(const TsArgs p) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int nwg = gridDim.x;
+  int item;
+  {
+    const int q = nwg >> 3, r = nwg & 7, x = blockIdx.x & 7, i = blockIdx.x >> 3;
+    item = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  const int s = item / p.ntiles, tile = item - s * p.ntiles;
+  const int tco = tile / p.tiles_k, tk = tile - tco * p.tiles_k;
+  const int co0 = tco * 128, k0 = tk * 128;
+  const int kb = (int)((long long)s * p.nkt / p.S), ke = (int)((long long)(s + 1) * p.nkt / p.S);
+  int dy = 0, dx = 0, cib = k0;
+  if (GATHER3) {
+    const int tap = k0 / p.Cin;
+    cib = k0 - tap * p.Cin;
+    dy = tap / 3 - 1;
+    dx = tap % 3 - 1;
+  }
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.GY), 0, p.g_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.X) - p.x_bias), 0, p.x_bytes, 0x00020000);
+
+  // this lane's two rows (pixels) of a K-tile per operand: instruction (wave * 2 + e) covers rows 4 * (wave * 2 + e) .. + 3
+  unsigned go[2], xo[2];
+  int rem[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int row = (wave * 2 + e) * 4 + (lane >> 4);
+    const int lc = (lane & 15) ^ ts_swz(row);
+    const long long m = (long long)kb * 32 + row;
+    go[e] = (unsigned)((m * p.Cout + co0 + lc * 8) * 2);
+    xo[e] = (unsigned)(((m + dy * p.W + dx) * p.Cin + cib + lc * 8) * 2 + p.x_bias);   // >= 0: the bias covers the largest negative shift
+    rem[e] = GATHER3 ? (int)(m % p.hw) : 0;
+  }
+  auto stage = [&](int slot) {   // stages the K-tile the offsets point at, then advances them by one K-tile
+    char* dg = lds + slot * TS_STAGE + wave * 2048;
+    char* dxp = dg + TS_TILE;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void*)(dg + e * 1024), 16, go[e], 0, 0, 0);
+      unsigned off = xo[e];
+      if (GATHER3) {
+        const int oy = (int)__umulhi((unsigned)rem[e], p.magic_w);
+        const int ox = rem[e] - oy * p.W;
+        off = ((unsigned)(oy + dy) < (unsigned)p.H && (unsigned)(ox + dx) < (unsigned)p.W) ? off : TS_OOB;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(dxp + e * 1024), 16, off, 0, 0, 0);
+      go[e] += 64u * p.Cout;
+      xo[e] += 64u * p.Cin;
+      if (GATHER3) {
+        const int r = rem[e] + p.r32;
+        rem[e] = r >= p.hw ? r - p.hw : r;
+      }
+    }
+  };
+
+  // transposed-read addresses inside a stage: lane group g4 = lane >> 4 takes pixels 8 g4 .. 8 g4 + 7; per read the lane supplies the
+  // address of row 8 g4 + q4 (+ 4 for the second read), columns 4 p4 .. 4 p4 + 3 of the fragment's 16 channels
+  const int g4 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+  const int trow = 8 * g4 + q4, tsw = ts_swz(trow);
+  const unsigned lds0 = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char*)lds;
+  unsigned g_adr[4], x_adr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    g_adr[i] = lds0 + trow * 256 + (((wr * 8 + i * 2 + (p4 >> 1)) ^ tsw) << 4) + (p4 & 1) * 8;
+    x_adr[i] = lds0 + TS_TILE + trow * 256 + (((wc * 8 + i * 2 + (p4 >> 1)) ^ tsw) << 4) + (p4 & 1) * 8;
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (kb < ke) stage(0);
+  unsigned sofs = 0;
+  for (int kt = kb; kt < ke; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    P8_BAR();
+    if (kt + 1 < ke) stage(sofs ? 0 : 1);
+    bf16x8 gf[4], xf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xf[j] = ts_frag(x_adr[j] + sofs);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gf[i] = ts_frag(g_adr[i] + sofs);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    P8_SCHED();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[j], gf[i], acc[i][j], 0, 0, 0);   // lane = co, regs = 4 consecutive k
+    __builtin_amdgcn_s_setprio(0);
+    P8_SCHED();
+    sofs ^= (unsigned)TS_STAGE;
+  }
+  // fp32 partial tile in thread-private order (float4 index q * 256 + thread): coalesced 16-byte stores
+  f32x4* __restrict__ sl = reinterpret_cast<f32x4*>(p.slab) + ((size_t)s * p.ntiles + tile) * (16 * 256) + threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sl[(i * 4 + j) * 256] = acc[i][j];
+}
+
+// dW tile = sum of its S partial tiles.  One workgroup per (tile, accumulator q = i * 4 + j, quarter of the 256 threads' slots): its four
+// waves take the pieces w, w + 4, ... (8 loads in flight per lane), the four chains are joined in wave order through LDS -- a fixed order.
+__global__ __launch_bounds__(256) void conv_wgrad_s4_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Ktot, int tiles_k,
+                                                                    int ntiles, int S) {
+  __shared__ f32x4 part[3][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int quarter = blockIdx.x & 3, q = (blockIdx.x >> 2) & 15, tile = blockIdx.x >> 6;
+  const int tid = quarter * 64 + lane;   // the main kernel's thread whose accumulator q this lane sums
+  const f32x4* __restrict__ base = reinterpret_cast<const f32x4*>(slab) + (size_t)tile * (16 * 256) + q * 256 + tid;
+  const size_t pstride = (size_t)ntiles * (16 * 256);
+  f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int s0 = wave; s0 < S; s0 += 32) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s = s0 + 4 * u;
+      v[u] = s < S ? base[(size_t)s * pstride] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += v[u];
+  }
+  if (wave) part[wave - 1][lane] = a;
+  __syncthreads();
+  if (wave == 0) {
+    a += part[0][lane];
+    a += part[1][lane];
+    a += part[2][lane];
+    const int mw = tid >> 6, ml = tid & 63;   // the main kernel's wave / lane
+    const int wr = mw >> 1, wc = mw & 1, fr = ml & 15, fq = ml >> 4, i = q >> 2, j = q & 3;
+    const int tco = tile / tiles_k, tk = tile - tco * tiles_k;
+    const int row = tco * 128 + wr * 64 + i * 16 + fr, col = tk * 128 + wc * 64 + j * 16 + fq * 4;
+    *reinterpret_cast<f32x4*>(dw + (size_t)row * Ktot + col) = a;
+  }
+}
+
+}  // namespace
+
+#ifdef COIN_LAB
+int coin_s4_tn_wpc = 0;   // lab hook: workgroups per CU the pixel split aims at (0 = default)
+#else
+static constexpr int coin_s4_tn_wpc = 0;
+#endif
+
+bool coin_s4_tn_ok(int M, int Cout, int Cin, int Ktot, int mode) {
+  if (M <= 0 || Cout % 128 || Cin % 128) return false;
+  if (((size_t)M + 64 + 2048) * (size_t)(Cout > Cin ? Cout : Cin) * 2 >= 0x7f000000ull) return false;  // 32-bit buffer offsets
+  return mode == 0 ? Ktot == Cin : Ktot == 9 * Cin;
+}
+
+static void ts_plan(int M, int Cout, int Ktot, TsArgs& a) {
+  a.tiles_k = Ktot / 128;
+  a.ntiles = (Cout / 128) * a.tiles_k;
+  a.nkt = (M + 31) / 32;
+  const int wpc = coin_s4_tn_wpc > 0 ? coin_s4_tn_wpc : 2;
+  int S = (wpc * s4_cus() + a.ntiles - 1) / a.ntiles;
+  const int max_s = (a.nkt + 3) / 4;   // at least four K-tiles (128 pixels) per piece
+  S = S > max_s ? max_s : S;
+  a.S = S < 1 ? 1 : S;
+}
+
+// Dispatch rule (tools/gemm_lab wbench, profiles/r6_lab_s4.log): the persistent kernel's fixed cost is its partials -- 256 workgroups x
+// 256 KiB = 64 MB written and read back whatever the shape -- so it wins only where the operands are several times that: res5
+// ([100 352 x 2048 x 512]: 214 against 281 us here; operands 514 MB).  Below ~160 MB of operands this kernel wins everywhere measured:
+// layer3 [16 600 x 256 x 1024] 40 -> 22.5 us, layer2 [66 800 x 128 x 1152] 63 -> 35, [266 400 x 128 x 1152] 178 -> 98, the RPN head's
+// [16 600 x 1024 x 9216] 420 -> 336, the box head's [2048 x 1024 x 2048] 35 -> 25.
+bool coin_s4_tn_wanted(int M, int Cout, int Cin) { return (long long)M * (Cout + Cin) * 2 <= 160LL << 20; }
+
+size_t coin_s4_tn_workspace_bytes(int M, int Cout, int Ktot) {
+  if (M <= 0 || Cout % 128 || Ktot % 128) return 0;
+  TsArgs a;
+  ts_plan(M, Cout, Ktot, a);
+  return (size_t)a.ntiles * a.S * 65536;
+}
+
+int coin_s4_tn_launch(const void* GY, const void* X, int mode, int H, int W, int Cin, int M, int Cout, int Ktot, float* dW, void* workspace, hipStream_t st) {
+  TsArgs a;
+  ts_plan(M, Cout, Ktot, a);
+  a.GY = (const bf16_t*)GY; a.X = (const bf16_t*)X; a.slab = (float*)workspace;
+  a.M = M; a.Cout = Cout; a.Cin = Cin; a.Ktot = Ktot; a.H = mode ? H : 1; a.W = mode ? W : 1;
+  a.magic_w = (unsigned)((0x100000000ull + (unsigned)a.W - 1) / (unsigned)a.W);
+  a.hw = a.H * a.W; a.r32 = 32 % a.hw;
+  a.x_bias = mode ? (unsigned)(W + 1) * Cin * 2 : 0;
+  a.g_bytes = (unsigned)((size_t)M * Cout * 2);
+  a.x_bytes = (unsigned)((size_t)M * Cin * 2 + a.x_bias);
+  const int grid = a.ntiles * a.S;
+  if (mode == 1) conv_wgrad_s4_kernel<true><<<grid, 256, 2 * TS_STAGE, st>>>(a);
+  else conv_wgrad_s4_kernel<false><<<grid, 256, 2 * TS_STAGE, st>>>(a);
+  conv_wgrad_s4_reduce_kernel<<<a.ntiles * 64, 256, 0, st>>>(a.slab, dW, Cout, Ktot, a.tiles_k, a.ntiles, a.S);
+  return coin_launch_status();
+}

@@ -279,7 +279,11 @@ def test_conv_gemm_at_the_timed_shapes_vs_fp64_on_sampled_pixels(K, nb, h, w, ci
 @pytest.mark.parametrize("nb,h,w,cin,cout,ks", [(40, 7, 7, 256, 256, 1), (9, 14, 14, 512, 256, 1), (33, 7, 7, 256, 512, 3), (6, 14, 14, 256, 256, 3), (700, 7, 7, 512, 256, 1),
                                                 # odd multiples of 128 (the backbone's layer2): half-valid edge tiles, a 3x3 K-tile that spans two taps
                                                 (2, 50, 83, 512, 128, 1), (2, 50, 83, 128, 512, 1), (2, 50, 83, 128, 128, 3), (3, 23, 31, 128, 384, 3),
-                                                (3, 23, 31, 384, 128, 3), (1, 9, 11, 128, 128, 1)])
+                                                (3, 23, 31, 384, 128, 3), (1, 9, 11, 128, 128, 1),
+                                                # round 6: the backbone's maps at the benchmark's size -- the 128 x 128 small-map kernel (every
+                                                # launch whose operands are below 160 MB), incl. the RPN head's width and the box head's rows
+                                                (4, 50, 83, 256, 1024, 1), (4, 50, 83, 1024, 256, 1), (4, 50, 83, 256, 256, 3), (4, 100, 167, 128, 128, 3),
+                                                (1, 25, 40, 1024, 1024, 3), (2048, 1, 1, 2048, 1024, 1)])
 def test_conv_wgrad_vs_fp64(K, nb, h, w, cin, cout, ks):
     """coin_conv_wgrad_bf16 (transposed-LDS-read MFMA contraction over the pixels, sliced, slabs summed in order) vs the fp64 weight
     gradient of F.conv2d on the same bf16 tensors; two runs agree bit for bit."""

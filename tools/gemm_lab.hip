@@ -71,7 +71,8 @@ static const Shape kShapes[] = {{"l4.0.conv1", 2048, 14, 14, 1024, 512, 1}, {"l4
                                 {"l2.x.conv2", 4, 100, 167, 128, 128, 3},   {"l2.x.conv1", 4, 100, 167, 512, 128, 1},  {"l2.x.conv3", 4, 100, 167, 128, 512, 1},
                                 {"l3.x.conv1", 4, 50, 83, 1024, 256, 1},    {"l3.x.conv3", 4, 50, 83, 256, 1024, 1},
                                 {"l2.0.conv2", 4, 200, 333, 128, 128, 3},   {"l2.0.conv1", 4, 200, 333, 256, 128, 1},  {"l3.0.conv1", 4, 100, 167, 512, 256, 1},
-                                {"l3.0.conv2", 4, 100, 167, 256, 256, 3},   {"l2.0.down", 4, 100, 167, 256, 512, 1},   {"l3.0.down", 4, 50, 83, 512, 1024, 1}};   // layer3's 1x1 convolutions: on this kernel since the stretch is captured  // N = 128: a half-width column tile (round 5)
+                                {"l3.0.conv2", 4, 100, 167, 256, 256, 3},   {"l2.0.down", 4, 100, 167, 256, 512, 1},   {"l3.0.down", 4, 50, 83, 512, 1024, 1},
+                                {"head.fc1", 2048, 1, 1, 2048, 1024, 1},    {"head.fc2", 2048, 1, 1, 1024, 1024, 1}};   // layer3's 1x1 convolutions: on this kernel since the stretch is captured  // N = 128: a half-width column tile (round 5)
 
 static void* g_ws = nullptr;
 static size_t g_ws_bytes = 0;
@@ -353,8 +354,11 @@ static void bench_s4(const Shape& sh, int iters, int rounds) {
 }
 
 // ---------------------------------------------------------------------------------------------------- weight gradient
+static int g_wcand = 1;   // check_wgrad: the implementation under test (1 = persistent, 4 = the 128 x 128 small-map kernel)
+static int g_wpc = 0;     // coin_s4_tn_wpc
 static int run_wgrad(int impl, const void* GY, const void* X, int mode, int H, int W, int Cin, int M, int Cout, int Ktot, float* dW, void* ws) {
   coin_conv_gemm_force_impl = impl;
+  coin_s4_tn_wpc = g_wpc;
   const int rc = coin_conv_wgrad_bf16(GY, X, mode, H, W, Cin, M, Cout, Ktot, dW, ws, nullptr);
   coin_conv_gemm_force_impl = 0;
   return rc;
@@ -366,6 +370,7 @@ static int check_wgrad(const char* name, int M, int Cout, int Cin, int mode, int
   void *GY, *X, *ws;
   float *W0, *W1;
   CK(hipMalloc(&GY, gn * 2)); CK(hipMalloc(&X, xn * 2)); CK(hipMalloc(&W0, wn * 4)); CK(hipMalloc(&W1, wn * 4));
+  coin_s4_tn_wpc = g_wpc;
   CK(hipMalloc(&ws, coin_conv_wgrad_workspace_bytes(M, Cout, Ktot)));
   fill(GY, gn, 0x4242u, 0.05f);
   fill(X, xn, 0x1717u, 1.0f);
@@ -373,7 +378,7 @@ static int check_wgrad(const char* name, int M, int Cout, int Cin, int mode, int
   const bool odd = (Cout % 256) || (Cin % 256);   // odd multiples of 128: only the persistent kernel serves them (checked against fp64 alone)
   const int rc0 = odd ? 0 : run_wgrad(2, GY, X, mode, H, W, Cin, M, Cout, Ktot, W0, ws);
   CK(hipDeviceSynchronize());
-  const int rc1 = run_wgrad(1, GY, X, mode, H, W, Cin, M, Cout, Ktot, W1, ws);
+  const int rc1 = run_wgrad(g_wcand, GY, X, mode, H, W, Cin, M, Cout, Ktot, W1, ws);
   CK(hipDeviceSynchronize());
   if (rc0 || rc1) { printf("WCHECK %s: launch rc %d %d\n", name, rc0, rc1); return 1; }
   std::vector<float> h0(wn), h1(wn);
@@ -423,16 +428,21 @@ static void bench_wgrad(const Shape& sh, int iters, int rounds) {
   void *GY, *X, *ws;
   float* dW;
   CK(hipMalloc(&GY, gn * 2)); CK(hipMalloc(&X, xn * 2)); CK(hipMalloc(&dW, wn * 4));
+  coin_s4_tn_wpc = 4;   // the largest pixel split the variants below ask for
   CK(hipMalloc(&ws, coin_conv_wgrad_workspace_bytes(M, sh.co, Ktot)));
+  coin_s4_tn_wpc = 0;
   fill(GY, gn, 0x4242u, 0.05f);
   fill(X, xn, 0x1717u, 1.0f);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  const int impls[2] = {1, 2};
-  const char* names[2] = {"p8", "sliced"};
-  std::vector<float> med[2];
+  constexpr int NW = 5;
+  const int impls[NW] = {1, 4, 4, 4, 0};
+  const int wpcs[NW] = {0, 1, 2, 4, 0};
+  const char* names[NW] = {"p8", "s4w1", "s4w2", "s4w4", "default"};
+  std::vector<float> med[NW];
   for (int r = 0; r < rounds; ++r)
-    for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < NW; ++v) {
+      g_wpc = wpcs[v];
       run_wgrad(impls[v], GY, X, mode, sh.h, sh.w, sh.ci, M, sh.co, Ktot, dW, ws);
       float ms = 0;
       if (g_cold) {
@@ -453,9 +463,10 @@ static void bench_wgrad(const Shape& sh, int iters, int rounds) {
       }
       med[v].push_back(ms);
     }
+  g_wpc = 0;
   const double flop = 2.0 * M * (double)sh.co * Ktot;
   printf("{\"shape\": \"%s\", \"dir\": \"wgrad\", \"M\": %d, \"Cout\": %d, \"Ktot\": %d", sh.name, M, sh.co, Ktot);
-  for (int v = 0; v < 2; ++v) {
+  for (int v = 0; v < NW; ++v) {
     std::sort(med[v].begin(), med[v].end());
     const float m = med[v][med[v].size() / 2];
     printf(", \"%s_ms\": %.4f, \"%s_TF\": %.1f", names[v], m, names[v], flop / m / 1e9);
@@ -562,6 +573,26 @@ int main(int argc, char** argv) {
     fails += check_case("s4 N=192 3x3 + R + stats prefix", 3 * 23 * 31, 192, 9 * 64, 1, 23, 31, 64, true, 2 * 23 * 31, 1);
     g_cand = 1; g_base = 2;
     printf("SCHECK total failures: %d\n", fails);
+  }
+  if (!strcmp(what, "swcheck") || !strcmp(what, "all")) {
+    g_wcand = 4;   // the 128 x 128 weight-gradient kernel against the sliced kernel (multiples of 256) and fp64 samples
+    for (int wpc : {1, 2, 4}) {
+      g_wpc = wpc;
+      fails += check_wgrad("s4 1x1 small", 64 * 50 + 17, 256, 256, 0, 0, 0);
+      fails += check_wgrad("s4 l3.conv3 1x1 1024<-256", 4 * 50 * 83, 1024, 256, 0, 0, 0);
+      fails += check_wgrad("s4 l3.conv2 3x3 256<-256", 4 * 50 * 83, 256, 256, 1, 50, 83);
+      fails += check_wgrad("s4 3x3 tiny", 49 * 2, 256, 256, 1, 7, 7);
+      fails += check_wgrad("s4 l2.conv1 1x1 128<-512", 4 * 100 * 166, 128, 512, 0, 0, 0);
+      fails += check_wgrad("s4 l2.conv3 1x1 512<-128", 4 * 100 * 166, 512, 128, 0, 0, 0);
+      fails += check_wgrad("s4 l2.conv2 3x3 128<-128", 4 * 100 * 166, 128, 128, 1, 100, 166);
+      fails += check_wgrad("s4 3x3 384<-128 small", 3 * 23 * 31, 384, 128, 1, 23, 31);
+      fails += check_wgrad("s4 3x3 128<-384 small", 3 * 23 * 31, 128, 384, 1, 23, 31);
+      fails += check_wgrad("s4 1x1 128<-128 tiny", 77, 128, 128, 0, 0, 0);
+      fails += check_wgrad("s4 box head 1024<-2048", 2048, 1024, 2048, 0, 0, 0);
+    }
+    g_wpc = 0;
+    g_wcand = 1;
+    printf("SWCHECK total failures: %d\n", fails);
   }
   if (!strcmp(what, "sbench")) {
     for (const Shape& s : kShapes) {
