@@ -334,6 +334,10 @@ def main():
              "coin_conv_gemm_bf16", "coin_conv_wgrad_bf16"]
     K.timing_begin(timed)
     host_ms = []   # per step: wall time the host spent inside run_step (enqueue; close to ms_per_step = the rank is host-bound)
+    from coin_amd.telemetry import GpuTelemetry
+
+    telemetry = GpuTelemetry(local_rank)   # shader clock / board power / temperature from sysfs on a side thread, DURING the timed region
+    telemetry.__enter__()
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == KERNEL_TIMING_STEPS:   # 460 events per step cost the host 1.3 ms per step, and tens of thousands of live events more
@@ -343,6 +347,7 @@ def main():
         host_ms.append((time.perf_counter() - th) * 1e3)
     sync()
     dt = time.perf_counter() - t0
+    telemetry.__exit__()
     bare = sorted(host_ms[KERNEL_TIMING_STEPS:] or host_ms)
     host_enqueue_ms = bare[len(bare) // 2]
     ktimes = K.timing_end()
@@ -432,6 +437,9 @@ def main():
                        "host_enqueue_ms": [round(r[2], 2) for r in per_rank],
                        "host_enqueue_device_idle_ms_rank0": round(host_enqueue_idle_ms, 2),   # 5 extra steps after the timed region, see above
                        "rank_affinity": affinities,
+                       # what the chip held during the timed region (sysfs, rank 0's GPU): boxes of one pool differ by several percent in
+                       # clock under these kernels -- a slow box and a regression look the same without it
+                       "gpu_telemetry": telemetry.summary(),
                        # coin_amd/graphs.py: captured (shape, segment) pairs, graph replays / eager calls of the two graphed stretches so far
                        "step_graphs": dict(G.STATS, enabled=G.ENABLED["on"]),
                        "end_to_end_mfma_frac": value / world * FLOP_PER_VIEW / (MFMA_BF16_PEAK_TFLOPS * 1e12)},

@@ -1,0 +1,121 @@
+"""GPU clock / power / temperature of a timed region, read from sysfs on a side thread (no GPU work, no extra process).
+
+bench.py puts the figures into its JSON line (`config.gpu_telemetry`): boxes of this pool differ by several percent in the clock the
+chip holds under the GEMM kernels, and without a sample taken DURING the timed region a slow box cannot be told
+from a regression (round-5 VERDICT, weak 13).  Everything here is best effort: an unreadable file yields `None` for that field, never
+an error -- the benchmark must not depend on it.
+
+Sources (amdgpu): /sys/class/drm/card*/device/hwmon/hwmon*/{freq1_input (Hz, shader clock), power1_average | power1_input (uW),
+temp*_input (millidegree; the label `junction` where present)} and pp_dpm_sclk (the level marked `*`) as a fallback for the clock.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import threading
+import time
+from typing import Dict, List, Optional
+
+
+def _read(path: str) -> Optional[str]:
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _amd_cards() -> List[str]:
+    """sysfs device directories of the AMD GPUs, in PCI order (the order HIP enumerates them in when nothing re-maps it)."""
+    cards = []
+    for dev in glob.glob("/sys/class/drm/card[0-9]*/device"):
+        if _read(os.path.join(dev, "vendor")) != "0x1002":
+            continue
+        if not glob.glob(os.path.join(dev, "hwmon", "hwmon*")):
+            continue
+        cards.append((os.path.basename(os.path.realpath(dev)), dev))
+    return [d for _, d in sorted(set(cards))]
+
+
+class GpuTelemetry:
+    """with GpuTelemetry(local_rank) as t: ... ; t.summary() -> {"sclk_mhz": {"mean", "min", "max"}, "power_w": ..., "temp_c": ..., "samples"}"""
+
+    def __init__(self, index: int = 0, period_s: float = 0.02):
+        cards = _amd_cards()
+        self.dev = cards[index] if index < len(cards) else (cards[0] if cards else None)
+        self.period = period_s
+        self.rows: List[tuple] = []
+        self._stop = threading.Event()
+        self._thread: Optional[threading.Thread] = None
+        self.hwmon = None
+        self.temp_file = None
+        if self.dev:
+            hw = sorted(glob.glob(os.path.join(self.dev, "hwmon", "hwmon*")))
+            self.hwmon = hw[0] if hw else None
+        if self.hwmon:
+            for lab in sorted(glob.glob(os.path.join(self.hwmon, "temp*_label"))):
+                if _read(lab) == "junction":
+                    self.temp_file = lab.replace("_label", "_input")
+            if self.temp_file is None and os.path.exists(os.path.join(self.hwmon, "temp1_input")):
+                self.temp_file = os.path.join(self.hwmon, "temp1_input")
+
+    def _sclk_mhz(self) -> Optional[float]:
+        if self.hwmon:
+            v = _read(os.path.join(self.hwmon, "freq1_input"))
+            if v and v.isdigit() and int(v) > 0:
+                return int(v) / 1e6
+        if self.dev:
+            txt = _read(os.path.join(self.dev, "pp_dpm_sclk"))
+            for line in (txt or "").splitlines():
+                if line.rstrip().endswith("*"):
+                    try:
+                        return float(line.split(":")[1].strip().split("Mhz")[0].split("MHz")[0])
+                    except (IndexError, ValueError):
+                        return None
+        return None
+
+    def _power_w(self) -> Optional[float]:
+        if not self.hwmon:
+            return None
+        for name in ("power1_average", "power1_input"):
+            v = _read(os.path.join(self.hwmon, name))
+            if v and v.isdigit():
+                return int(v) / 1e6
+        return None
+
+    def _temp_c(self) -> Optional[float]:
+        v = _read(self.temp_file) if self.temp_file else None
+        return int(v) / 1e3 if v and v.lstrip("-").isdigit() else None
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.rows.append((self._sclk_mhz(), self._power_w(), self._temp_c()))
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self.dev:
+            self._thread = threading.Thread(target=self._run, name="coin-gpu-telemetry", daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=1.0)
+        return False
+
+    def summary(self) -> Dict:
+        def agg(i):
+            vals = [r[i] for r in self.rows if r[i] is not None]
+            if not vals:
+                return None
+            return {"mean": round(sum(vals) / len(vals), 1), "min": round(min(vals), 1), "max": round(max(vals), 1)}
+
+        return {"source": self.dev, "samples": len(self.rows), "period_ms": self.period * 1e3, "sclk_mhz": agg(0), "power_w": agg(1), "temp_c": agg(2),
+                "power_cap_w": (lambda v: int(v) / 1e6 if v and v.isdigit() else None)(_read(os.path.join(self.hwmon, "power1_cap")) if self.hwmon else None)}
+
+
+if __name__ == "__main__":   # python -m coin_amd.telemetry: what is readable on this box
+    with GpuTelemetry(0) as t:
+        time.sleep(0.3)
+    print(t.summary())

@@ -40,28 +40,40 @@ ROUND = {"dtype": None}
 
 
 class _RoundSTE(torch.autograd.Function):
+    """x rounded to the storage dtype (value kept in x's own dtype).  Backward: the gradient passes straight through -- or, with
+    `round_grad`, is rounded to the storage dtype as well: the bf16 mode STORES the gradient of every stored activation in bf16 too
+    (the data-gradient GEMM's output rows, coin_bn_bwd's dx / d_residual; weight gradients and the norm's dgamma / dbeta stay fp32)."""
+
     @staticmethod
-    def forward(ctx, x, dtype):
+    def forward(ctx, x, dtype, round_grad):
+        ctx.gdtype = dtype if round_grad else None
         return x.to(dtype).to(x.dtype)
 
     @staticmethod
     def backward(ctx, g):
-        return g, None
+        if ctx.gdtype is not None:
+            g = g.to(ctx.gdtype).to(g.dtype)
+        return g, None, None
 
 
-def rnd(x):
-    return x if ROUND["dtype"] is None else _RoundSTE.apply(x, ROUND["dtype"])
+def rnd(x, grad=True):
+    """grad=False: an edge whose gradient the product never materialises (a weight: its gradient is fp32; the un-pooled activation
+    inside the fused BatchNorm + ReLU + pool store)."""
+    return x if ROUND["dtype"] is None else _RoundSTE.apply(x, ROUND["dtype"], bool(ROUND.get("grads")) and grad)
 
 
 class emulate_rounding:
-    def __init__(self, dtype):
-        self.dtype = dtype
+    """Inside: the oracle rounds where the bf16 mode stores (forward); with grads=True also where its BACKWARD stores."""
+
+    def __init__(self, dtype, grads=False):
+        self.dtype, self.grads = dtype, grads
 
     def __enter__(self):
-        self.prev, ROUND["dtype"] = ROUND["dtype"], self.dtype
+        self.prev = (ROUND["dtype"], ROUND.get("grads", False))
+        ROUND["dtype"], ROUND["grads"] = self.dtype, self.grads
 
     def __exit__(self, *a):
-        ROUND["dtype"] = self.prev
+        ROUND["dtype"], ROUND["grads"] = self.prev
         return False
 
 
@@ -69,13 +81,13 @@ def _conv(conv: nn.Conv2d, x):
     """conv(x); under `emulate_rounding`: operands and result rounded (the input normally already is)."""
     if ROUND["dtype"] is None:
         return conv(x)
-    return rnd(F.conv2d(rnd(x), rnd(conv.weight), None if conv.bias is None else conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups))
+    return rnd(F.conv2d(rnd(x), rnd(conv.weight, grad=False), None if conv.bias is None else conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups))
 
 
 def _linear(lin: nn.Linear, x, round_out=True):
     if ROUND["dtype"] is None:
         return lin(x)
-    y = F.linear(rnd(x), rnd(lin.weight), lin.bias)      # bias added in the fp32 accumulator, before the store
+    y = F.linear(rnd(x), rnd(lin.weight, grad=False), lin.bias)      # bias added in the fp32 accumulator, before the store
     return rnd(y) if round_out else y
 
 
@@ -121,7 +133,7 @@ class Bottleneck(nn.Module):
         # bn3 + identity + ReLU in one store -- or, for the last block of the RoI head, only the spatial mean of it
         x = rnd(x)
         y = rnd(self.relu(self.bn1(_conv(self.conv1, x))))
-        y = rnd(self.avgpool(rnd(self.relu(self.bn2(_conv(self.conv2, y))))))   # coin_bn_apply_fwd rounds the un-pooled activation, then pools
+        y = rnd(self.avgpool(rnd(self.relu(self.bn2(_conv(self.conv2, y))), grad=False)))   # coin_bn_apply_fwd rounds the un-pooled activation, then pools (backward: coin_bn_bwd reads the POOLED gradient, the un-pooled one is never stored)
         z = _conv(self.conv3, y)
         if self.downsample is None:
             sc = x

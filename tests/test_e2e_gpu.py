@@ -57,8 +57,11 @@ def test_step_two_fp32_vs_reference_golden():
 def test_pretrain_step_bf16_close_to_golden():
     case = golden_pretrain_case()
     losses, grads = run_product_pretrain(case, "cuda:0", torch.bfloat16)
+    print({k: (round(float(losses[k]), 5), round(ref, 5), f"{abs(float(losses[k]) - ref) / max(1.0, abs(ref)):.1e}") for k, ref in case["ref_losses"].items()})
+    # round 6: 1e-2 (was 5 %); measured 7e-5 ... 3.4e-3 (loss_cls) on this tiny net -- the whole detector in bf16 (backbone, RPN, res5, box
+    # head on the hand-written kernels; the text transformer under torch autocast) against the REFERENCE's fp32 golden losses
     for k, ref in case["ref_losses"].items():
-        assert np.isfinite(float(losses[k])) and abs(float(losses[k]) - ref) < 0.05 * max(1.0, abs(ref)), (k, float(losses[k]), ref)
+        assert np.isfinite(float(losses[k])) and abs(float(losses[k]) - ref) < 1e-2 * max(1.0, abs(ref)), (k, float(losses[k]), ref)
 
 
 def test_full_size_trainer_steps_bf16_and_fp32_agree():

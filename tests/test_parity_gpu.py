@@ -151,7 +151,11 @@ def test_real_width_res5_bf16_kernels_vs_the_storage_rounding_oracle():
     coin_conv_gemm_bf16 with the statistics epilogue, every weight gradient on coin_conv_wgrad_bf16): every block, fed the product's own
     bf16 input, stores >= 95 % of its output values IDENTICALLY to that oracle and is 3-8x closer to it (relative L2 <= 2e-3) than to the
     plain fp64 oracle; running statistics to 1e-3; gradients (whose own bf16 stores the oracle does not emulate) at most 0.85 of their
-    distance to the plain oracle."""
+    distance to the plain oracle.  Round 6: the oracle now rounds the BACKWARD's stores too (emulate_rounding(grads=True)); chained over three
+    train-mode BatchNorm blocks the gradients still sit ~10 % from it (0.55-0.75 of the plain distance: one flipped rounding early in the chain
+    changes ReLU decisions downstream), so the absolute gradient bound (2e-2 relative L2, measured 1.0e-2 ... 1.4e-2) is held BLOCK BY BLOCK on
+    identical inputs and upstream gradients: test_trunk_blocks_bf16_on_the_captured_kernels_vs_the_storage_rounding_oracle_eager_and_replayed,
+    cases 615 / 616."""
     import real_width as RW
     import seeded
     from coin_amd import layers as L
@@ -166,7 +170,7 @@ def test_real_width_res5_bf16_kernels_vs_the_storage_rounding_oracle():
         fwd = lambda n, xx: n[2](n[1](n[0](xx)), mean_pool=True).flatten(1)
         if not emulate:
             return RW.run_res5(o, x, gy, dtype=torch.float64, mean_pool=fwd)
-        with OC.emulate_rounding(torch.bfloat16):
+        with OC.emulate_rounding(torch.bfloat16, grads=True):   # round 6: the backward's bf16 stores are emulated too
             return RW.run_res5(o, x, gy, dtype=torch.float64, mean_pool=fwd)
 
     y64, gx64, g64, _ = oracle(False)
@@ -232,6 +236,95 @@ def test_real_width_res5_bf16_kernels_vs_the_storage_rounding_oracle():
     for k, v in sde.items():
         if "running" in k:   # statistics of the STORED (rounded) activations: what the epilogue accumulates
             torch.testing.assert_close(sd[k].double().cpu(), v.double(), rtol=1e-3, atol=1e-4, msg=k)
+
+
+@pytest.mark.parametrize("inplanes,planes,stride,shape,seed", [(512, 128, 1, (4, 100, 167), 611), (1024, 256, 1, (4, 50, 83), 612),
+                                                               (256, 128, 2, (2, 100, 166), 613), (512, 256, 2, (2, 100, 166), 614),
+                                                               # res5 on RoI tiles (the persistent 256 x 256 kernels): the chained three-block test above
+                                                               # cannot hold an absolute gradient bound (10 % from ANY bf16 path after three train-mode
+                                                               # BatchNorm blocks); block by block, on identical inputs and upstream gradients, it can
+                                                               (1024, 512, 2, (64, 14, 14), 615), (2048, 512, 1, (64, 7, 7), 616)])
+def test_trunk_blocks_bf16_on_the_captured_kernels_vs_the_storage_rounding_oracle_eager_and_replayed(monkeypatch, inplanes, planes, stride, shape, seed):
+    """Round-5 VERDICT (weak 2): since the backbone stretch is captured, layer2 / layer3 run forward, data gradient and weight gradient on the
+    hand-written kernels (`layers.conv_gemm_everywhere`; round 6: the 128 x 128 small-map cores for most of these launches) at maps of
+    16 600 ... 66 800 pixels -- shapes no oracle comparison in the driver-run suite reached (the fp32 goldens run library convolutions, the
+    graph tests compare the kernels with themselves).  Here: real-width layer2 / layer3 blocks (RN50: 128 / 512 and 256 / 1024 channels) on maps
+    of the benchmark's size, bf16, every convolution on the hand-written kernels, against the fp64 oracle that rounds where the bf16 mode stores
+    -- in the forward AND (round 6) in the backward (oracle.coin.emulate_rounding(grads=True): data gradients and coin_bn_bwd's dx / d_residual
+    are bf16 stores, weight gradients fp32): output >= 95 % identical stored values and relative L2 <= 2e-3; input gradient and EVERY parameter
+    gradient within 2e-2 relative L2 (an absolute bound; measured values are printed).  Then the same block as a GraphedSegment: captured,
+    the allocator's cache released and the freed ranges poisoned, replayed on the same input -- bit-identical to the eager pass."""
+    import seeded
+    from coin_amd import graphs as G
+    from coin_amd import kernels as K
+    from coin_amd import layers as L
+    from coin_amd.modeling.backbone import Bottleneck
+    from oracle import coin as OC
+    import real_width as RW
+
+    n, h, w = shape
+    x = torch.relu(seeded.randn((n, inplanes, h, w), seed)).to(torch.bfloat16)            # a block's input is a ReLU output
+    gy = (seeded.randn((n, planes * 4, h // stride, w // stride), seed + 1) * 0.05).to(torch.bfloat16)
+
+    def oracle(grads):
+        o = seeded.fill_module(OC.Bottleneck(inplanes, planes, stride), seed + 2).double().train()
+        xx = x.double().requires_grad_(True)
+        if grads is None:
+            y = o(xx)
+        else:
+            with OC.emulate_rounding(torch.bfloat16, grads=grads):
+                y = o(xx)
+        (y * gy.double()).sum().backward()
+        return y.detach(), xx.grad.detach(), {k: p.grad.detach() for k, p in o.named_parameters()}
+
+    ye, gxe, ge = oracle(True)
+    y64, gx64, g64 = oracle(None)
+
+    for k in ("enabled", "wgrad"):
+        monkeypatch.setitem(L.CONV_GEMM, k, True)
+    monkeypatch.setitem(L.CONV_GEMM, "min_rows", 0)
+    monkeypatch.setitem(G.ENABLED, "on", True)
+    blk = seeded.fill_module(Bottleneck(inplanes, planes, stride), seed + 2).to(DEV).to(memory_format=torch.channels_last).train()
+    assert L.library_free([m for m in blk.modules() if isinstance(m, torch.nn.Conv2d)])
+
+    def run(fn, xin):
+        for p in blk.parameters():
+            p.grad = None
+        xx = xin.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = fn(xx)
+        y.backward(gy.to(DEV).contiguous(memory_format=torch.channels_last))
+        return y.detach().clone(), xx.grad.detach().clone(), {k: p.grad.detach().clone() for k, p in blk.named_parameters()}
+
+    lib0 = L.LIBRARY_CONV_CALLS[0]
+    y, gx, grads = run(lambda t: blk(t), x)
+    assert L.LIBRARY_CONV_CALLS[0] == lib0, "a library convolution ran inside the block"
+    same = float((y.double().cpu() == ye).double().mean())
+    ey, ey64 = RW.l2_err(y, ye), RW.l2_err(y, y64)
+    print(f"trunk block {inplanes}->{planes}x4 /{stride} @ {n}x{h}x{w}: output L2 vs storage-rounding oracle {ey:.2e} ({100 * same:.1f} % of the stored values identical), vs plain fp64 {ey64:.2e}")
+    assert same >= 0.95 and ey <= 2e-3, (same, ey, ey64)
+    rows = [("gx", RW.l2_err(gx, gxe), RW.l2_err(gx, gx64))] + [(k, RW.l2_err(grads[k], ge[k]), RW.l2_err(grads[k], g64[k])) for k in sorted(ge)]
+    print("\n".join(f"trunk block grad {k:24s} L2 vs storage-rounding oracle (backward stores included) {a:.2e}   vs plain fp64 {b:.2e}" for k, a, b in rows))
+    for k, a, b in rows:
+        assert a <= 2e-2, (k, a, b)
+    # ---- the same block as a captured stretch: two eager calls, capture at the third, then replays
+    G.step_done()
+    seg = G.GraphedSegment("test_trunk_block", lambda t: blk(t), lambda: list(blk.parameters()), lambda: list(blk.buffers()))
+    before = dict(G.STATS)
+    for i in range(3):
+        run(seg, torch.relu(seeded.randn((n, inplanes, h, w), seed + 10 + i)).to(torch.bfloat16))
+        G.step_done()
+    assert len(seg.graphs) == 1 and not seg.failed and G.STATS["captures"] - before["captures"] == 1
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 26,), float("nan"), device="cuda") for _ in range(8)]
+    yr, gxr, gr = run(seg, x)
+    G.step_done()
+    assert G.STATS["replays"] - before["replays"] == 1, G.STATS
+    assert torch.equal(yr, y) and torch.equal(gxr, gx)
+    for k in grads:
+        assert torch.equal(gr[k], grads[k]), k
+    del junk
 
 
 def test_real_width_box_predictor_bf16_vs_the_storage_rounding_oracle():
