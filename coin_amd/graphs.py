@@ -260,7 +260,7 @@ class _no_hooks_inside:
 
 
 class _Entry:
-    __slots__ = ("fwd", "bwd", "static_in", "outs", "out_req", "static_gout", "grads_in", "grads_p", "params", "busy", "pool", "single", "workspaces")
+    __slots__ = ("fwd", "bwd", "static_in", "outs", "out_req", "static_gout", "grads_in", "grads_p", "params", "busy", "pool", "single", "workspaces", "ptrs")
 
 
 class _Replay(torch.autograd.Function):
@@ -383,6 +383,8 @@ class GraphedSegment:
         ent = self.graphs.get(key)
         if ent is None:
             n = self.seen.get(key, 0) + 1
+            if len(self.seen) > 64 and key not in self.seen:   # variable-size data: the table of seen shapes stays bounded
+                self.seen.pop(next(iter(self.seen)))
             self.seen[key] = n
             if n < WARM_CALLS or len(self.graphs) >= MAX_GRAPHS:
                 STATS["eager"] += 1
@@ -412,6 +414,14 @@ class GraphedSegment:
         if ent.busy or _STEP["defer"]:
             STATS["busy" if ent.busy else "eager"] += 1
             return self.fn(*inputs)     # (defer: another stretch captures in this step, nothing may be replayed around it)
+        if not self._fresh(ent):
+            # a parameter / buffer of the stretch lives in another storage than at capture (load_state_dict with assign, `.data =`, a
+            # module moved): the recorded kernels point at the old one.  Drop the graph; the shape is captured again after its warm-up calls
+            del self.graphs[key]
+            self.seen[key] = 0
+            STATS["eager"] += 1
+            STATS["stale"] = STATS.get("stale", 0) + 1
+            return self.fn(*inputs)
         _STEP["replayed"] = True
         STATS["replays"] += 1
         _detach_static_grads(ent)
@@ -419,6 +429,25 @@ class GraphedSegment:
         # until this call's backward has replayed, the graph's buffers hold the activations it will read: a second call must not replay
         ent.busy = ent.bwd is not None and any(o.requires_grad for o in outs)
         return outs[0] if ent.single else outs
+
+    def _fresh(self, ent: _Entry) -> bool:
+        """What the eager path checks on every call and a replay would skip (round-5 ADVICE): the storages the graph was recorded against
+        are still the parameters' / buffers' storages -- else False -- and the bf16 compute shadows are current: a master written out of band
+        since (load_state_dict / resume_or_load in a process that already trained, init_, copy_: a version bump the fused SGD kernel does not
+        make) gets its shadow refreshed HERE, eagerly, before the replay reads it; the data-gradient layouts follow at the backward's refresh."""
+        params = list(self.params_fn())
+        tensors = params + (list(self.buffers_fn()) if self.buffers_fn is not None else [])
+        if [t.data_ptr() for t in tensors] != ent.ptrs:
+            return False
+        refreshed = False
+        for p in params:
+            e = L._SHADOWS.get(id(p))
+            if e is not None and e.ref() is p and (e.version != p._version or e.ptr != p.data_ptr()):
+                L._shadow_entry(p, e.tensor.dtype)
+                refreshed = True
+        if refreshed:
+            L.weights_updated()
+        return True
 
     # ---------------------------------------------------------------- capture
     def _capture(self, inputs) -> _Entry:
@@ -461,6 +490,7 @@ class GraphedSegment:
             self._record(ent, grad_mode)
         finally:
             ent.workspaces = K.take_stream_workspaces(cap)
+        ent.ptrs = [t.data_ptr() for t in list(self.params_fn()) + (list(self.buffers_fn()) if self.buffers_fn is not None else [])]
         return ent
 
     def _record(self, ent: _Entry, grad_mode: bool) -> None:

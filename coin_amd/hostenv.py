@@ -137,14 +137,31 @@ def rank_env(local_rank: int, local_world: int, base: Optional[Dict[str, str]] =
     return env
 
 
-def apply_rank_affinity(local_rank: Optional[int] = None, local_world: Optional[int] = None) -> Dict:
+def apply_rank_affinity(local_rank: Optional[int] = None, local_world: Optional[int] = None, cpu_compute: bool = False) -> Dict:
     """In a rank, before the HIP runtime starts: pin this process to its core set and cap the host thread pools.
-    A single-rank run (`local_world` 1) is left alone apart from an OMP cap of MAX_THREADS when none is set.
+    A single-rank run (`local_world` 1) is left alone apart from an OMP cap of MAX_THREADS when none is set (not even that with
+    `cpu_compute`: a run whose model lives on the CPU).
     -> {"cpus": cpulist or None, "threads": n}: what was applied (bench.py echoes it as `config.rank_affinity`)."""
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if local_rank is None else local_rank
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))) if local_world is None else local_world
+    if local_world is None:
+        # ranks on THIS node: the launcher's LOCAL_WORLD_SIZE; without it (srun / mpirun style launches) the GPUs visible here -- never the global
+        # WORLD_SIZE, which on two nodes of eight would hand every rank a sixteenth of the cores, all of them on the first socket (round-5 ADVICE)
+        lw = os.environ.get("LOCAL_WORLD_SIZE")
+        if lw is not None:
+            local_world = int(lw)
+        elif int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+            local_world = 1
+        else:
+            try:
+                import torch   # device_count() does not initialise the HIP runtime on this image
+
+                local_world = max(1, min(int(os.environ["WORLD_SIZE"]), torch.cuda.device_count()))
+            except Exception:
+                local_world = int(os.environ["WORLD_SIZE"])
     applied: Dict = {"cpus": None, "threads": None}
     if local_world <= 1:
+        if cpu_compute:   # MODEL.DEVICE cpu (the parity / plumbing mode of train_net.py): the host pools ARE the compute, leave them alone
+            return applied
         os.environ.setdefault("OMP_NUM_THREADS", str(MAX_THREADS))
         applied["threads"] = int(os.environ["OMP_NUM_THREADS"])
         return applied

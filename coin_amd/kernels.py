@@ -285,7 +285,9 @@ _RPOOL_UNSERVED: set = set()
 def capture_stream_value() -> int:
     """Raw handle of the stream torch.cuda.graph captures on (created here if no capture has happened yet)."""
     if torch.cuda.graph.default_capture_stream is None:
-        torch.cuda.graph.default_capture_stream = torch.cuda.Stream()
+        from . import streams
+
+        torch.cuda.graph.default_capture_stream = streams.role_stream(torch.cuda.current_device(), "capture")
     return int(torch.cuda.graph.default_capture_stream.cuda_stream)
 
 

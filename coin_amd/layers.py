@@ -299,6 +299,9 @@ class _ConvGemm(Function):
         ctx.ks = ks
         ctx.param = weakref.ref(weight)
         ctx.pool_tap = fork == "pool"
+        # the statistics partials are never differentiated: without this the engine materialises a zero tensor of their size for every
+        # backward call (35 fill launches per pre-train step, tools/opsites.py)
+        ctx.set_materialize_grads(False)
         if part is None:
             part = out.new_zeros(0, dtype=torch.float32)
         ctx.mark_non_differentiable(part)
@@ -316,6 +319,8 @@ class _ConvGemm(Function):
     @once_differentiable
     def backward(ctx, gy, _gpart, g_tap=None):
         x, wq = ctx.saved_tensors
+        if gy is None:   # the convolution's output reached no loss: only the other consumer's gradient of x (if any) flows on
+            return (g_tap if ctx.needs_input_grad[0] else None), None, None, None, None
         gyn = _as_nhwc(gy)
         if gyn.dtype != torch.bfloat16:
             gyn = gyn.to(torch.bfloat16)
@@ -636,11 +641,10 @@ def bn_act(x: torch.Tensor, bn: torch.nn.BatchNorm2d, relu: bool, residual: Opti
     # eval mode (teacher inference): a per-channel affine map with the running statistics
     if x.is_cuda and not (torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad)):
         # no gradient wanted: the fused apply kernel with (running_mean, 1/sqrt(running_var + eps)) as the statistics
-        xn = _as_nhwc(x)
-        rn = _as_nhwc(residual) if residual is not None else None
-        rstd = (bn.running_var.float() + bn.eps).rsqrt()
-        y = K.bn_apply_fwd(xn, bn.running_mean.float().contiguous(), rstd, bn.weight.detach().float().contiguous(),
-                           bn.bias.detach().float().contiguous(), rn, relu, pool)
+        # (the constants -- running mean, 1 / sqrt(running_var + eps), scale, shift in fp32 -- are cached per module and follow every
+        # write of their sources: `_bn_constants`.  Formed per call they were 2-4 small launches per norm: 110 per teacher pass.)
+        mean, rstd, g, b = _bn_constants(bn)
+        y = K.bn_apply_fwd(_as_nhwc(x), mean, rstd, g, b, _as_nhwc(residual) if residual is not None else None, relu, pool)
         return y.permute(0, 3, 1, 2)
     scale = bn.weight * (bn.running_var + bn.eps).rsqrt()
     shift = bn.bias - bn.running_mean * scale
@@ -658,6 +662,21 @@ _FROZEN_CONSTS: dict = {}
 _DERIVED_CACHES.append(_FROZEN_CONSTS)
 
 
+def _bn_constants(bn: torch.nn.Module):
+    """(running_mean, 1 / sqrt(running_var + eps), weight, bias) of a norm in fp32, cached per module; rebuilt when one of the four sources
+    was written (version bump or new storage) -- writers that bump no version (the EMA kernel) call `invalidate_storage`."""
+    src = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    key = tuple((t.data_ptr(), t._version) for t in src)
+    hit = _FROZEN_CONSTS.get(id(bn))
+    if hit is None or hit[0] != key or hit[1]() is not bn:
+        with torch.no_grad():
+            consts = (bn.running_mean.float().contiguous(), (bn.running_var.float() + bn.eps).rsqrt().contiguous(),
+                      bn.weight.float().contiguous(), bn.bias.float().contiguous())
+        hit = (key, weakref.ref(bn, lambda _r, k=id(bn): _FROZEN_CONSTS.pop(k, None)), consts)
+        _FROZEN_CONSTS[id(bn)] = hit
+    return hit[2]
+
+
 def frozen_bn_fusable(x: torch.Tensor, channels: int) -> bool:
     """The frozen stages in the throughput mode: no gradient flows through them and the channel count fits the streaming kernels'
     thread mapping (coin_bn_apply_fwd: 8 bf16 channels per lane, a row of channel groups divides or is a multiple of a workgroup)."""
@@ -672,16 +691,7 @@ def frozen_bn_act(x: torch.Tensor, bn: torch.nn.Module, relu: bool, residual: Op
     the norms converted, :243-284) as ONE pass over the convolution's output: the statistics slots of coin_bn_apply_fwd carry the
     frozen running statistics.  Replaces the library's bias add, ReLU, residual add and ReLU launches (4 passes) on the largest
     activations of the network.  Caller checked `frozen_bn_fusable`."""
-    src = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
-    key = tuple((t.data_ptr(), t._version) for t in src)
-    hit = _FROZEN_CONSTS.get(id(bn))
-    if hit is None or hit[0] != key or hit[1]() is not bn:
-        with torch.no_grad():
-            consts = (bn.running_mean.float().contiguous(), (bn.running_var.float() + bn.eps).rsqrt().contiguous(),
-                      bn.weight.float().contiguous(), bn.bias.float().contiguous())
-        hit = (key, weakref.ref(bn, lambda _r, k=id(bn): _FROZEN_CONSTS.pop(k, None)), consts)
-        _FROZEN_CONSTS[id(bn)] = hit
-    mean, rstd, g, b = hit[2]
+    mean, rstd, g, b = _bn_constants(bn)
     y = K.bn_apply_fwd(_as_nhwc(x), mean, rstd, g, b, _as_nhwc(residual) if residual is not None else None, relu, pool)
     return y.permute(0, 3, 1, 2)
 

@@ -79,6 +79,18 @@ def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, n
     return res, inds[keep][:, 0]
 
 
+def _gradient_discrepancy(loss_a, loss_b, params):
+    """1 - mean over theta of cos(d loss_a / d theta (a constant), d loss_b / d theta (differentiable)) -- coin/utils/losses.py:75-96.
+    The reference asks autograd for one parameter at a time (twelve backward walks over the same sub-graph for the six tensors of
+    `trans`, each retaining / re-creating the graph); the gradients do not depend on how many are requested per walk, so both sets are
+    taken in ONE walk each: the same values, a sixth of the launches (round 6, tools/opsites.py: this loss was ~700 of the targetDET
+    step's ~2 400 small launches and 6 ms of its device time)."""
+    ga = torch.autograd.grad(loss_a, params, retain_graph=True)
+    gb = torch.autograd.grad(loss_b, params, create_graph=True)
+    cos = [F.cosine_similarity(a, b, dim=1).mean() if prm.dim() > 1 else F.cosine_similarity(a, b, dim=0) for prm, a, b in zip(params, ga, gb)]
+    return (1.0 - torch.stack(cos)).mean()
+
+
 class FastRCNNOutputLayers(nn.Module):
     def __init__(self, input_shape, *, text_encoder, pooling_type, box2box_transform, text_dim, classes_weight, loss_type,
                  test_score_thresh=0.0, test_nms_thresh=0.5, test_topk_per_image=100, cls_agnostic_bbox_reg=False,
@@ -170,14 +182,7 @@ class FastRCNNOutputLayers(nn.Module):
             p = F.softmax(scores, dim=1)
             loss_a = F.mse_loss(p[:na], oh_a.float())
             loss_b = F.mse_loss(p[na:], m_b.float())
-            cos = []
-            for prm in t.parameters():
-                if not prm.requires_grad:
-                    continue
-                ga = torch.autograd.grad(loss_a, prm, retain_graph=True)[0]
-                gb = torch.autograd.grad(loss_b, prm, create_graph=True)[0]
-                cos.append(F.cosine_similarity(ga, gb, dim=1).mean() if prm.dim() > 1 else F.cosine_similarity(ga, gb, dim=0))
-            return (1.0 - torch.stack(cos)).mean()
+            return _gradient_discrepancy(loss_a, loss_b, [prm for prm in t.parameters() if prm.requires_grad])
 
     def prefetch_text(self):
         """Run the prompt-conditioned text encoder ahead of `forward` (it does not depend on the images): the caller puts it
@@ -201,14 +206,7 @@ class FastRCNNOutputLayers(nn.Module):
             fa, fb = m_a.float(), m_b.float()
             loss_a = (((p - oh_a.float()) ** 2).sum(1) * fa).sum() / (fa.sum().clamp(min=1) * kc)
             loss_b = (((p - merged.float()) ** 2).sum(1) * fb).sum() / (fb.sum().clamp(min=1) * kc)
-            cos = []
-            for prm in t.parameters():
-                if not prm.requires_grad:
-                    continue
-                ga = torch.autograd.grad(loss_a, prm, retain_graph=True)[0]
-                gb = torch.autograd.grad(loss_b, prm, create_graph=True)[0]
-                cos.append(F.cosine_similarity(ga, gb, dim=1).mean() if prm.dim() > 1 else F.cosine_similarity(ga, gb, dim=0))
-            return (1.0 - torch.stack(cos)).mean()
+            return _gradient_discrepancy(loss_a, loss_b, [prm for prm in t.parameters() if prm.requires_grad])
 
     _text_prefetch = None
     _share_text, _text_shared = False, None

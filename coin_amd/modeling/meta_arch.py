@@ -15,6 +15,7 @@ from torch import nn
 
 from .. import kernels as K
 from .. import layers as L
+from .. import streams as _streams
 from .._lib import COIN_NHWC
 from ..box_ops import detector_postprocess
 from ..registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY
@@ -114,7 +115,7 @@ class OpenVocabularyRCNN(nn.Module):
         if nxt is None or not self.overlap_streams or not self.pixel_mean.is_cuda or not hasattr(self.backbone, "frozen_forward"):
             return
         if getattr(self, "_look_stream", None) is None:  # its own stream: the main stream later waits on `_side_stream`
-            self._look_stream = torch.cuda.Stream(device=self.pixel_mean.device)
+            self._look_stream = _streams.role_stream(self.pixel_mean.device, "look")
         side, cur = self._look_stream, torch.cuda.current_stream()
         side.wait_stream(cur)  # starts once this step's backbone has run
         with torch.cuda.stream(side), torch.no_grad():
@@ -143,7 +144,7 @@ class OpenVocabularyRCNN(nn.Module):
         if not (self.overlap_streams and images.tensor.is_cuda and pg is not None and pg.sync_free and hasattr(self.backbone, "encoder")):
             return None
         if getattr(self, "_side_stream", None) is None:
-            self._side_stream = torch.cuda.Stream(device=images.tensor.device)
+            self._side_stream = _streams.role_stream(images.tensor.device, "side")
         side, cur = self._side_stream, torch.cuda.current_stream()
         side.wait_stream(cur)
         hw = self.backbone.encoder.visual.res4_hw(*images.tensor.shape[-2:])

@@ -133,6 +133,13 @@ class OpenVocabularyRes5ROIHeads(nn.Module):
         if not (self.step_graphs and self.training and torch.is_grad_enabled() and self.pooling_type == "meanpool" and len(self.in_features) == 1
                 and rois.is_cuda and rois.shape[0] > 0 and isinstance(res5, torch.nn.Sequential) and L._VALID_ROWS[0] is None):
             # (a padded pass -- the C boxes, whose count changes every step -- stays eager: each (count, padding) pair would be its own graph)
+            if (rois.is_cuda and rois.shape[0] > 0 and self.compute_dtype == torch.bfloat16 and isinstance(res5, torch.nn.Sequential)
+                    and self._res5_library_free(res5)):
+                # ... but on the hand-written kernels whatever its row count (round 6: the 128 x 128 small-map cores serve a 64-RoI pass as
+                # well as the library does): a RoI bucket the library has not met before cost a solver search of tens of milliseconds in
+                # the step where it first appeared -- step_two's groups of four steps read 64 ... 148 ms (tools/td_mode_check.sh)
+                with L.conv_gemm_everywhere():
+                    return self._pooled_rows(features, rois, res5, attnpool)
             return self._pooled_rows(features, rois, res5, attnpool)
         if self._trunk_segs is None:
             self._trunk_segs = {}
@@ -155,6 +162,10 @@ class OpenVocabularyRes5ROIHeads(nn.Module):
         if seg[1] is None:   # a width the hand-written weight-gradient kernel does not serve
             return self._pooled_rows(features, rois, res5, attnpool)
         return seg[1](features[self.in_features[0]], rois, key_extra=(res5.training, self.compute_dtype))
+
+    @staticmethod
+    def _res5_library_free(res5) -> bool:
+        return L.library_free([m for m in res5.modules() if isinstance(m, torch.nn.Conv2d)])
 
     def _pooled_rows(self, features, rois, res5, attnpool):
         if self.pooling_type == "meanpool" and isinstance(res5, torch.nn.Sequential) and len(res5) > 0 and hasattr(res5[-1], "conv3"):

@@ -143,6 +143,8 @@ class GradReducer:
     def set_flag(self, value: float) -> None:
         """This rank's contribution to `flag` (read it after `finalize()`: the sum over the ranks).  Call BEFORE the backward pass of the
         step: the last slice may be launched by a hook, on whichever stream that backward node runs."""
+        if self.flag is None:   # no trainable parameter: nothing is reduced, nothing carries a flag
+            return
         self.flag.fill_(float(value))
         if self.flag.is_cuda:
             ev = torch.cuda.Event()

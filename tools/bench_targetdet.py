@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--sync-free-step", action="store_true", help="(default since round 2) cfg.AMD.SYNC_FREE_STEP: fixed-shape samplers + packed losses")
     ap.add_argument("--reference-samplers", action="store_true", help="cfg.AMD.SYNC_FREE_STEP off: the reference-shaped nonzero / randperm samplers")
     ap.add_argument("--no-prefetch", action="store_true", help="cfg.AMD.TEACHER_PREFETCH off: the frozen teacher's pass follows the student's step (A/B measurement)")
+    ap.add_argument("--after-pretrain", type=int, default=0, help="first run this many PRETrainer steps in the same process (the round-5 64-vs-52 ms mode experiment)")
     ap.add_argument("--no-teacher-stream", action="store_true", help="cfg.AMD.TEACHER_STREAM off: teacher pass on the main stream (A/B measurement)")
     args = ap.parse_args()
     import torch
@@ -67,6 +68,18 @@ def main():
             with torch.cuda.stream(st):
                 torch.zeros(1024, device="cuda").add_(1)
         torch.cuda.synchronize()
+    if args.after_pretrain:   # what bench.py's process looked like in round 5: a PRETrainer has lived (and used its streams) here before
+        import bench
+        from coin_amd.engine import PRETrainer
+
+        pcfg = bench.build_cfg(1, "cuda:0", "bf16")
+        torch.manual_seed(pcfg.SEED)
+        ptr = PRETrainer(pcfg)
+        for _ in range(args.after_pretrain):
+            ptr.run_step()
+        torch.cuda.synchronize()
+        del ptr
+        torch.cuda.empty_cache()
     tr = build_trainer(args.config, args.images, args.step_two, reference_samplers=args.reference_samplers, teacher_stream=not args.no_teacher_stream,
                        extra=["AMD.TEACHER_PREFETCH", not args.no_prefetch])
     for _ in range(args.warmup):

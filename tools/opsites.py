@@ -20,6 +20,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--out", default="gpurun_out/opsites.txt")
+    ap.add_argument("--targetdet", action="store_true", help="the CoinTrainer step (tools/bench_targetdet.py's trainer, 3 images) instead of the pre-train step")
+    ap.add_argument("--step-two", action="store_true")
     args = ap.parse_args()
     import torch
     from torch.profiler import ProfilerActivity, profile
@@ -27,15 +29,27 @@ def main():
     import bench
     from coin_amd.engine import PRETrainer
 
-    cfg = bench.build_cfg(1, "cuda:0", "bf16")
-    torch.manual_seed(cfg.SEED)
-    tr = PRETrainer(cfg)
-    for _ in range(5):
-        tr.run_step()
+    if args.targetdet:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_targetdet
+
+        tr = bench_targetdet.build_trainer("foggy", 3, args.step_two)
+        step = lambda: (tr.run_step(), tr.prepare_next())
+    else:
+        cfg = bench.build_cfg(1, "cuda:0", "bf16")
+        torch.manual_seed(cfg.SEED)
+        tr = PRETrainer(cfg)
+        step = tr.run_step
+    for _ in range(6):
+        step()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+    try:
+        xc = {"experimental_config": torch._C._profiler._ExperimentalConfig(verbose=True)}   # python stacks in events() on this torch
+    except Exception:
+        xc = {}
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True, **xc) as prof:
         for _ in range(args.steps):
-            tr.run_step()
+            step()
         torch.cuda.synchronize()
     evs = prof.events()
     # parent chains: an aten op launched inside an autograd node's evaluation has that node ("XBackward", "autograd::engine::evaluate_function: X") as an ancestor
@@ -48,7 +62,7 @@ def main():
             continue
         site = None
         for f in (e.stack or []):
-            if ("coin_amd/" in f or "bench.py" in f) and "kernels.py" not in f:
+            if ("coin_amd/" in f or "bench.py" in f) and "kernels.py" not in f and "graphs.py" not in f:
                 site = f[f.index("coin_amd/"):] if "coin_amd/" in f else f
                 break
         if site is None:
@@ -59,6 +73,8 @@ def main():
                     break
                 p = p.cpu_parent
         shapes = str(getattr(e, "input_shapes", ""))[:60]
+        if args.targetdet:
+            shapes = ""
         a = agg[(e.name, site or "?", shapes)]
         a[0] += 1
         a[1] += dt

@@ -1,11 +1,15 @@
 #!/bin/bash
 # HBM-traffic counters of the bench's own launch mix (run on the GPU box):  bash tools/pmc_bench.sh <tag>
-# Two passes over a short bench run (3 steps, no warm-up: a stretch is captured at its 4th call, so every launch here is an eager one of the same kernels); per-kernel totals go to gpurun_out/prof_<tag>/pmc_bench_<COUNTER>.csv
+# Two passes over a short bench run (3 steps, no warm-up) with the step graphs OFF (COIN_STEP_GRAPHS=0, exported below: bench.py runs 5 more
+# steps after its timed region, enough for both stretches to be captured and replayed -- the per-kernel means would mix eager, dry-run and
+# replayed launches; round-5 ADVICE): every launch counted here is an eager one of the same kernels.
+# Per-kernel totals go to gpurun_out/prof_<tag>/pmc_bench_<COUNTER>.csv
 set -u
 tag=${1:-r1}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
+export COIN_STEP_GRAPHS=0
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcb_$ctr
   timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmcb_$ctr -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 0 --no-cpu-baseline --no-secondary > /tmp/pmcb_$ctr.log 2>&1

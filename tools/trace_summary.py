@@ -61,6 +61,55 @@ print(f"device occupied (union over streams) {union/1e6:.1f} ms = {100.0*union/(
 for n, (c, t) in items[:40]:
     print(f"{t/1e6:8.2f} ms {100.0*t/busy:5.1f}% n={c:5d} avg={t/c/1e3:9.1f}us {n[:100]}")
 
+# ---- per-category device time and per-queue occupancy (round 6: the account of the targetDET step)
+import re
+
+CATS = [("conv GEMM fwd + dgrad (hand-written)", r"conv_gemm_p8_kernel|conv_gemm_s4_kernel|conv_gemm_bf16_kernel|conv_gemm256|p8_slab_sum|p8_tail|s4_tail"),
+        ("weight gradient + its reductions (hand-written)", r"conv_wgrad|tn_reduce|wgrad_reduce|wgrad_s4"),
+        ("BatchNorm / pool streams (hand-written)", r"bn_apply|bn_bwd|bn_stats|bn_finalize|conv_stats_finalize|avgpool2"),
+        ("RoIAlign", r"roi_align"),
+        ("NMS + labelling + samplers (hand-written)", r"nms_|anchor_match|sample_labels|lowq|match_"),
+        ("box head GEMMs / losses / SGD / EMA (hand-written)", r"gemm_nt_bf16|bias_act|cosine_|mil_|kl_div|box_reg|l1_mean|rpn_losses|sgd_kernel|ema_kernel|weight_dgrad|normalize_pad|transpose_kernel|window_attn|aug_"),
+        ("library GEMMs + attention (hipBLASLt / SDPA)", r"^Cijk_|attn_fwd|attn_bwd|bwd_kernel|fmha|flash"),
+        ("library convolutions (MIOpen / CK)", r"igemm|ck::|kernel_grouped_conv|naive_conv|miopen|Conv|gridwise"),
+        ("runtime copies / fills", r"__amd_rocclr|fillBuffer|copyBuffer"),
+        ("torch elementwise / reduce / sort / index glue", r"at::native|at_cuda_detail|rocprim|hipcub|elementwise|reduce_kernel|sort|scan")]
+cat_t = collections.OrderedDict((c, [0, 0]) for c, _ in CATS)
+cat_t["other"] = [0, 0]
+for n, (c, t) in agg.items():
+    for name, rx in CATS:
+        if re.search(rx, n):
+            cat_t[name][0] += c
+            cat_t[name][1] += t
+            break
+    else:
+        cat_t["other"][0] += c
+        cat_t["other"][1] += t
+nsteps = sum(c for n, (c, t) in agg.items() if "sgd_kernel" in n) or 1   # one fused optimizer launch per step (the CKG's gated step shares it)
+print(f"-- device time by category over the window ({a.window_ms} ms = {nsteps} optimizer steps: {a.window_ms / nsteps:.2f} ms per step under the profiler; "
+      "kernels of concurrent streams add up to more than the wall time)")
+for name, (c, t) in cat_t.items():
+    print(f"{t/1e6:8.2f} ms {100.0*t/max(busy,1):5.1f}% n={c:6d}  | per step {t/1e6/nsteps:6.2f} ms, {c/nsteps:6.1f} launches  {name}")
+# per hardware queue: time during which that queue has a kernel running (union of its intervals)
+qiv = collections.defaultdict(list)
+for (s0, e0, _), q in zip(rows, queues):
+    if e0 > lo:
+        qiv[q].append((max(s0, lo), e0))
+print("-- per hardware queue: occupied ms (union of its kernels) / kernel count")
+for q, iv2 in sorted(qiv.items(), key=lambda kv: -sum(e - s for s, e in kv[1]))[:8]:
+    iv2.sort()
+    u, cs, ce = 0, None, None
+    for s0, e0 in iv2:
+        if ce is None or s0 > ce:
+            if ce is not None:
+                u += ce - cs
+            cs, ce = s0, e0
+        else:
+            ce = max(ce, e0)
+    if ce is not None:
+        u += ce - cs
+    print(f"   q{q}: {u/1e6:8.1f} ms occupied = {100.0*u/(a.window_ms*1e6):5.1f}% of the window, {len(iv2)} kernels")
+
 if a.list:
     # each matching dispatch of the last `list-ms`: start offset, duration, and how much OTHER kernel time overlaps it (side streams)
     lo2 = end - int(a.list_ms * 1e6)

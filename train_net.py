@@ -48,7 +48,8 @@ def setup(args):
 def main(args):
     from coin_amd.hostenv import apply_rank_affinity, cap_torch_threads
 
-    affinity = apply_rank_affinity()   # a disjoint, NUMA-local core set + thread caps per rank, before the HIP runtime starts
+    # a disjoint, NUMA-local core set + thread caps per rank, before the HIP runtime starts (a CPU-device run keeps its host pools)
+    affinity = apply_rank_affinity(cpu_compute=any(str(o).lower() == "cpu" for o in (getattr(args, "opts", None) or [])))
     import torch
     import torch.distributed as dist
 
