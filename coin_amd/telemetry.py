@@ -37,12 +37,35 @@ def _amd_cards() -> List[str]:
     return [d for _, d in sorted(set(cards))]
 
 
+def _card_of_hip_device(index: int, cards: List[str]) -> Optional[str]:
+    """The sysfs directory of HIP device `index`: matched by PCI address (a container usually sees ONE of the node's GPUs as device 0 while
+    sysfs lists all of them -- round 6: the first version read an idle neighbour's 120 MHz); by position only when torch cannot tell."""
+    try:
+        import torch
+
+        pr = torch.cuda.get_device_properties(index)
+        want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+        for d in cards:
+            if os.path.basename(os.path.realpath(d)).lower().startswith(want):
+                return d
+    except Exception:
+        pass
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+    if vis:
+        try:
+            phys = [int(x) for x in vis.split(",")][index]
+            return cards[phys] if phys < len(cards) else None
+        except (ValueError, IndexError):
+            return None
+    return cards[index] if index < len(cards) else None
+
+
 class GpuTelemetry:
     """with GpuTelemetry(local_rank) as t: ... ; t.summary() -> {"sclk_mhz": {"mean", "min", "max"}, "power_w": ..., "temp_c": ..., "samples"}"""
 
     def __init__(self, index: int = 0, period_s: float = 0.02):
         cards = _amd_cards()
-        self.dev = cards[index] if index < len(cards) else (cards[0] if cards else None)
+        self.dev = _card_of_hip_device(index, cards)
         self.period = period_s
         self.rows: List[tuple] = []
         self._stop = threading.Event()
