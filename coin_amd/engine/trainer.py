@@ -42,12 +42,6 @@ class CoinTrainer(BASE_Trainer):
     def __init__(self, cfg, data_loader=None, cloud_results=None):
         self.cfg = cfg
         self.device = torch.device(cfg.MODEL.DEVICE)
-        if self.device.type == "cuda":
-            # the package's side streams exist -- all of them, in a fixed order -- before anything else in this process makes a stream:
-            # the stream -> hardware-queue binding, and with it the step time, must not depend on which trainer the process built first
-            from .. import streams as _role_streams
-
-            _role_streams.role_stream(self.device, "capture")
         self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world_size > 1 else 0
         self.model, self.offline_teacher = build_model(cfg)

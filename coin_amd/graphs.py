@@ -262,7 +262,7 @@ class _no_hooks_inside:
         return False
 
 
-CHUNK_BYTES = 8 << 20   # parameter-gradient bytes (fp32) after which a data-parallel backward graph is cut
+CHUNK_BYTES = 16 << 20   # parameter-gradient bytes (fp32) after which a data-parallel backward graph is cut (half a reducer slice)
 
 
 class _ChunkedCapture:
@@ -354,7 +354,7 @@ class _Replay(torch.autograd.Function):
         _detach_static_grads(ent)
         early = set()
         if ent.bwd_chunks:
-            # Data-parallel mode: the backward was recorded as several graphs, cut where a few MiB of parameter gradients are final.  After
+            # Data-parallel mode: the backward was recorded as several graphs, cut where 16 MiB of parameter gradients are final.  After
             # each one the reducer is told at once (`deliver_early`): a slice whose gradients are complete is packed and its all-reduce
             # launched on the communicator's stream WHILE the next graph replays -- not after the stretch's last kernel (round-5 VERDICT,
             # weak 9: one graph per stretch delivered res5's 15 M gradients in a bunch at its end).
