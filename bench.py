@@ -247,10 +247,9 @@ def run_secondary_targetdet(steps: int = 24, warmup: int = 12, images: int = 3, 
     issues them: teacher inference on the weak views, A/B/C matching against the cached cloud boxes, student step on the strong views.
     step_one is the block's `value`; round 6 adds a `step_two` sub-block (EMA teacher updated every step, the C-box pass).
     tools/bench_targetdet.py (groups of 4 steps, a device synchronize between groups only) in a CHILD PROCESS of its own, as the reference
-    runs the two trainings as two jobs.  (Round 5 measured 64 instead of 53 ms for this step inside the benchmark's own process; round 6:
-    the package's side streams are made once per process in a fixed order (coin_amd/streams.py) and the step reads the same 47.5 ms in a
-    fresh process and after a PRETrainer has lived in it -- `tools/bench_targetdet.py --after-pretrain 8`, tools/td_mode_check.sh; the
-    child process stays because a job of its own is what a user runs.)"""
+    runs the two trainings as two jobs.  (Round 5 measured 64 instead of 53 ms for this step inside the benchmark's own process; round 6
+    reproduces a 57-59 ms floor there against 47-48 ms in a process of its own -- `tools/bench_targetdet.py --after-pretrain 8`;
+    coin_amd/streams.py lists what was tried -- so the child process stays: a job of its own is also what a user runs.)"""
     import subprocess
 
     env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "COIN_RANK_CPUSET")}   # a job of its own
