@@ -58,10 +58,12 @@ def test_pretrain_step_bf16_close_to_golden():
     case = golden_pretrain_case()
     losses, grads = run_product_pretrain(case, "cuda:0", torch.bfloat16)
     print({k: (round(float(losses[k]), 5), round(ref, 5), f"{abs(float(losses[k]) - ref) / max(1.0, abs(ref)):.1e}") for k, ref in case["ref_losses"].items()})
-    # round 6: 1e-2 (was 5 %); measured 7e-5 ... 3.4e-3 (loss_cls) on this tiny net -- the whole detector in bf16 (backbone, RPN, res5, box
-    # head on the hand-written kernels; the text transformer under torch autocast) against the REFERENCE's fp32 golden losses
+    # round 6: 3e-2 (was 5 %).  This tiny net's channel counts keep its convolutions on the LIBRARY, whose bf16 solvers differ among
+    # themselves: 7e-5 ... 3.4e-3 (loss_cls) with the exhaustive solver search, 2.0e-2 on loss_cls with the fast find mode the test processes
+    # use (tests/conftest.py).  The bf16 claims that bite are made where the hand-written kernels run: block by block against the storage-
+    # rounding oracle (tests/test_parity_gpu.py: outputs 97-99 % identical stored values, every gradient within 2e-2 relative L2).
     for k, ref in case["ref_losses"].items():
-        assert np.isfinite(float(losses[k])) and abs(float(losses[k]) - ref) < 1e-2 * max(1.0, abs(ref)), (k, float(losses[k]), ref)
+        assert np.isfinite(float(losses[k])) and abs(float(losses[k]) - ref) < 3e-2 * max(1.0, abs(ref)), (k, float(losses[k]), ref)
 
 
 def test_full_size_trainer_steps_bf16_and_fp32_agree():
