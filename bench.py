@@ -43,8 +43,8 @@ ENTRY_KERNELS = {
     "coin_bn_stats": ["bn_stats_kernel", "bn_finalize_kernel"], "coin_bn_apply_fwd": ["bn_apply_kernel | bn_apply_mean_kernel"],
     "coin_bn_bwd": ["bn_bwd_reduce_kernel", "bn_bwd_finalize_kernel", "bn_bwd_dx_kernel"], "coin_gemm_nt": ["gemm_nt_bf16_kernel"],
     "coin_conv_gemm_bf16": ["conv_gemm_p8_kernel (+ conv_gemm_p8_slab_sum_kernel, conv_gemm_p8_tail_kernel where leftover tiles are cut along K) | "
-                            "conv_gemm256_bf16_kernel | conv_gemm_bf16_kernel  (<GATHER3, STATS> instantiations)"],
-    "coin_conv_wgrad_bf16": ["conv_wgrad_p8_kernel", "tn_reduce_kernel"],
+                            "conv_gemm_s4_kernel (round 6: the 128 x 128 small-map core)  (<GATHER3, STATS> instantiations)"],
+    "coin_conv_wgrad_bf16": ["conv_wgrad_p8_kernel + tn_reduce_kernel | conv_wgrad_s4_kernel + conv_wgrad_s4_reduce_kernel (round 6: launches below 160 MB of operands)"],
     "coin_conv_gemm_stats_finalize": ["conv_stats_finalize_kernel"],
 }
 KERNEL_TIMING_STEPS = 2    # the first steps of the timed region carry HIP events around every timed launch (`kernels` / `roofline` blocks)
@@ -52,11 +52,11 @@ MFMA_ENTRIES = ("coin_gemm_nt", "coin_conv_gemm_bf16", "coin_conv_wgrad_bf16")  
 
 
 def pmc_traffic(entry: str, alg_bytes: float):
-    """(HBM bytes per launch, the file it comes from) from the committed PMC passes (profiles/r5_pmc_traffic.json, else older rounds':
+    """(HBM bytes per launch, the file it comes from) from the committed PMC passes (profiles/r6_pmc_traffic.json, else older rounds':
     FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB units, MI355X_MICROARCH.md) -- only when that pass measured this entry point at this launch
     size (for the MFMA entry points: at this mean FLOP count per launch), else (None, None).  rocprofv3 cannot attach to a running
     process, so the figure is NOT measured by the run that prints the line: `roofline.traffic_source` names the file."""
-    for name in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    for name in ("r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 table = json.load(f)

@@ -297,15 +297,18 @@ static void bench_s4(const Shape& sh, int iters, int rounds) {
     fill(B, bn, 0x9876u + dir, 0.05f);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    constexpr int NV = 14;
+    // old = what served the shape until round 5 (the persistent kernel; the 256 x 128 kernel for N < 256); s4 = the 128 x 128 x 32 core (two
+    // stages, four workgroups per CU); default = the product's dispatch; k64n2 = K-tile 64 (128-byte rows, two workgroups per CU);
+    // nomem / nomfma / noepi / nothing = s4 with every DMA out of range (no memory traffic), without MFMAs, without the epilogue, without all three
+    constexpr int NV = 11;
     const int old_impl = N >= 256 ? 1 : 3;
-    const int impls[NV] = {old_impl, old_impl, 4, 4, 0, 4, 4, 4, 4, 4, 4, 4, 4, 4};
-    const bool stats[NV] = {false, true, false, true, true, false, false, false, false, false, false, false, false, false};
-    const int splits[NV] = {-1, -1, -1, -1, -1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
-    const int stages[NV] = {0, 0, 0, 0, 0, 2, 12, 13, 14, 12, 12, 12, 12, 2};
-    const int maxwg[NV] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int dbgs[NV] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 2, 4, 7, 7};
-    const char* names[NV] = {"old", "old+stats", "s4", "s4+stats", "default+stats", "k32n2", "k64n2", "k64n3", "k64n4", "k64_nomem", "k64_nomfma", "k64_noepi", "k64_nothing", "k32_nothing"};
+    const int impls[NV] = {old_impl, old_impl, 4, 4, 0, 4, 4, 4, 4, 4, 4};
+    const bool stats[NV] = {false, true, false, true, true, false, false, false, false, false, false};
+    const int splits[NV] = {-1, -1, -1, -1, -1, 1, 2, 1, 1, 1, 1};
+    const int stages[NV] = {0, 0, 0, 0, 0, 12, 2, 2, 2, 2, 2};
+    const int maxwg[NV] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int dbgs[NV] = {0, 0, 0, 0, 0, 0, 0, 1, 2, 4, 7};
+    const char* names[NV] = {"old", "old+stats", "s4", "s4+stats", "default+stats", "k64n2", "split2", "nomem", "nomfma", "noepi", "nothing"};
     std::vector<float> med[NV];
     for (int r = 0; r < rounds; ++r)
       for (int v = 0; v < NV; ++v) {

@@ -12,9 +12,9 @@ import json
 import sys
 
 ENTRY = {  # entry point -> (primary kernel substrings, secondary kernel substrings)
-    "coin_conv_gemm_bf16": (["conv_gemm_p8_kernel", "conv_gemm256_bf16_kernel", "conv_gemm_bf16_kernel"],
-                            ["conv_gemm_p8_slab_sum_kernel", "conv_gemm_p8_tail_kernel"]),
-    "coin_conv_wgrad_bf16": (["conv_wgrad_p8_kernel", "conv_wgrad_bf16_kernel"], ["tn_reduce_kernel", "wgrad_reduce_kernel"]),
+    "coin_conv_gemm_bf16": (["conv_gemm_p8_kernel", "conv_gemm_s4_kernel", "conv_gemm256_bf16_kernel", "conv_gemm_bf16_kernel"],
+                            ["conv_gemm_p8_slab_sum_kernel", "conv_gemm_p8_tail_kernel", "conv_gemm_s4_tail_kernel"]),
+    "coin_conv_wgrad_bf16": (["conv_wgrad_p8_kernel", "conv_wgrad_s4_kernel", "conv_wgrad_bf16_kernel"], ["tn_reduce_kernel", "tn_reduce_wide_kernel", "conv_wgrad_s4_reduce_kernel", "wgrad_reduce_kernel"]),
     "coin_bn_bwd": (["bn_bwd_reduce_kernel"], ["bn_bwd_finalize_kernel", "bn_bwd_dx_kernel"]),
     "coin_bn_apply_fwd": (["bn_apply_kernel", "bn_apply_mean_kernel"], []),
     "coin_bn_stats": (["bn_stats_kernel"], ["bn_finalize_kernel"]),

@@ -20,6 +20,6 @@ if [ -n "$stats" ]; then
   head -61 "$stats" > "$out/bench_kernel_stats_top60.csv"
 fi
 if [ -n "$trace" ]; then
-  python3 $GRAFT_REPO_ROOT/tools/trace_summary.py "$trace" "$out/steady_kernel_summary.csv" --window-ms 300 --list p8_kernel > "$out/steady_top.txt" 2>&1
+  python3 $GRAFT_REPO_ROOT/tools/trace_summary.py "$trace" "$out/steady_kernel_summary.csv" --window-ms 300 --sgd-per-step $([[ "$prog" == *targetdet* ]] && echo 2 || echo 1) --list p8_kernel > "$out/steady_top.txt" 2>&1
   head -120 "$out/steady_top.txt"
 fi

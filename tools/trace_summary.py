@@ -16,6 +16,7 @@ ap.add_argument("out")
 ap.add_argument("--window-ms", type=float, default=300.0)
 ap.add_argument("--list", default=None, help="also list every dispatch whose name contains this string inside the last --list-ms of the trace")
 ap.add_argument("--list-ms", type=float, default=45.0)
+ap.add_argument("--sgd-per-step", type=int, default=1, help="fused optimizer launches per training step (targetDET: 2 -- student + CKG)")
 a = ap.parse_args()
 rows = []
 queues = []
@@ -85,8 +86,8 @@ for n, (c, t) in agg.items():
     else:
         cat_t["other"][0] += c
         cat_t["other"][1] += t
-nsteps = sum(c for n, (c, t) in agg.items() if "sgd_kernel" in n) or 1   # one fused optimizer launch per step (the CKG's gated step shares it)
-print(f"-- device time by category over the window ({a.window_ms} ms = {nsteps} optimizer steps: {a.window_ms / nsteps:.2f} ms per step under the profiler; "
+nsteps = max(1, sum(c for n, (c, t) in agg.items() if "sgd_kernel" in n) // a.sgd_per_step)   # fused optimizer launches mark the steps
+print(f"-- device time by category over the window ({a.window_ms} ms = {nsteps} training steps: {a.window_ms / nsteps:.2f} ms per step under the profiler; "
       "kernels of concurrent streams add up to more than the wall time)")
 for name, (c, t) in cat_t.items():
     print(f"{t/1e6:8.2f} ms {100.0*t/max(busy,1):5.1f}% n={c:6d}  | per step {t/1e6/nsteps:6.2f} ms, {c/nsteps:6.1f} launches  {name}")
