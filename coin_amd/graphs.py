@@ -68,7 +68,7 @@ WARM_CALLS = 2          # eager calls of a shape before it is captured
 MAX_GRAPHS = 3          # shapes per segment (real data: a few padded sizes); further shapes stay eager
 STATS = {"captures": 0, "replays": 0, "eager": 0, "busy": 0, "launch_ms": 0.0}   # launch_ms: host time spent inside hipGraphLaunch
 CAPTURE_MODE = {"fwd": "thread_local", "bwd": "thread_local"}   # other threads (image decoding) may touch the device meanwhile
-TRACE: Optional[list] = None   # diagnostics (tools/bb_bisect.py): a list here receives (node, incoming gradients, results) of every captured backward node
+TRACE: Optional[list] = None   # diagnostics (tools/bb_bisect.py (round 5; in the git history)): a list here receives (node, incoming gradients, results) of every captured backward node
 
 
 _SEGMENTS: "weakref.WeakSet[GraphedSegment]" = weakref.WeakSet()   # weak: a dropped model must release its graphs' memory pools

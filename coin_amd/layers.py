@@ -209,7 +209,7 @@ def compute_dtype_of(x: torch.Tensor) -> torch.dtype:
 def _no_library_conv_under_capture(what: str) -> None:
     """The library's convolutions must not be recorded into a HIP graph on this stack: replayed, single MIOpen launches (forward 1x1 on
     the res4 map, the backward-weights kernels of the 128-channel convolutions) produced garbage as soon as the process state differed
-    from the capture's (another allocation pattern, an empty_cache(), a bare replay) -- measured with tools/bb_bisect.py and
+    from the capture's (another allocation pattern, an empty_cache(), a bare replay) -- measured with tools/bb_bisect.py (round 5; in the git history) and
     tools/miopen_graph_probe.py, DESIGN.md section 3.17.  A stretch that is to be captured keeps every convolution on the hand-written
     kernels (`conv_gemm_everywhere`).  Every library convolution is counted here: coin_amd.graphs compares the count across the dry run
     that precedes a capture and refuses the capture when it moved (the stretch then stays eager, with a warning); reaching one UNDER a

@@ -128,7 +128,7 @@ class Bottleneck(nn.Module):
             return out.mean(dim=[2, 3], keepdim=True) if mean_pool else out
         # the product's stores (coin_amd/modeling/backbone.py:Bottleneck.forward + layers.conv_bn_act): every convolution output; BatchNorm +
         # ReLU fused with the anti-aliasing pool (the kernel rounds the un-pooled value "as nn.AvgPool2d sees it", then the pooled one --
-        # found with tools/round_debug.py: every other stage matched to 2e-5, this one to 2e-3 until the oracle rounded twice as well);
+        # found with tools/round_debug.py (round 5; in the git history): every other stage matched to 2e-5, this one to 2e-3 until the oracle rounded twice as well);
         # the downsample branch's pooled input, convolution and norm;
         # bn3 + identity + ReLU in one store -- or, for the last block of the RoI head, only the spatial mean of it
         x = rnd(x)

@@ -133,7 +133,7 @@ class ForcedLeaky(torch.nn.Module):
     """LeakyReLU whose branch decisions are given (a boolean mask of the pre-activation's shape) instead of taken from the sign: the
     fp64 run of the oracle then follows the fp32 product through the same linear pieces.  Of the ~10^6 pre-activations of `trans` a
     few lie within fp32 rounding of zero; there ANY two fp32 evaluations may decide differently, and one flipped element moves the
-    gradients of everything upstream by ~1e-4 of their maximum (measured: tools/debug_head.py)."""
+    gradients of everything upstream by ~1e-4 of their maximum (measured: tools/debug_head.py (round 5; in the git history))."""
 
     def __init__(self, mask: torch.Tensor, slope: float = 0.01):
         super().__init__()

@@ -328,7 +328,7 @@ def test_training_with_step_graphs_follows_the_eager_training_step_by_step(same_
     e2, w2, _ = run(False)
     g, wg, rg = run(True)
     assert r1 == 0 and rg == 2 * 4
-    # run-to-run spread of this step, measured over four separate processes (tools/traj_probe.py; proposals of a random-init RPN are decided by
+    # run-to-run spread of this step, measured over four separate processes (tools/traj_probe.py (round 5; in the git history); proposals of a random-init RPN are decided by
     # noise in the last bits of the library convolutions): loss_box_reg +-4 % from the first step on, the other terms +-2 %
     for i in range(8):
         for k in e1[i]:

@@ -199,7 +199,7 @@ def test_real_width_res5_bf16_kernels_vs_the_storage_rounding_oracle():
     e_plain, e_emul = RW.l2_err(y, y64), RW.l2_err(y, ye)
     print(f"res5 bf16 pooled features (3 blocks chained): L2 vs plain fp64 oracle {e_plain:.2e}, vs storage-rounding oracle {e_emul:.2e}, max-err {RW.rel_err(y, ye):.2e}")
     # Chained over three blocks the two agree only a little better than with the plain oracle: a 1-ulp difference in one stored value (an
-    # accumulation-order effect, 0.02 % of the elements per stage -- tools/round_debug.py) perturbs the next convolution's sums enough to flip
+    # accumulation-order effect, 0.02 % of the elements per stage -- tools/round_debug.py (round 5; in the git history)) perturbs the next convolution's sums enough to flip
     # the rounding of ~1 % of ITS outputs, and so on.  The claim that bites is therefore made per block, on the product's own block inputs:
     assert e_emul <= e_plain and RW.rel_err(y, ye) <= 8e-3
     L.CONV_GEMM.update(enabled=True, min_rows=0, wgrad=True)
