@@ -562,15 +562,35 @@ int stream_grid(int64_t work_items) {
 
 // Grid for the row-walk kernels: gridDim.x * BN_THREADS must be a multiple of ncg (bn_check guarantees ncg <= BN_THREADS and
 // a power-of-two-free divisor relation, or ncg = k * BN_THREADS), and enough workgroups to fill 256 CUs several times over.
+#ifdef COIN_LAB
+int g_bn_grid_cap = 0;   // lab hook (tools/bnbench_small.py): workgroups of the row-walk kernels
+int g_bn_parts_cap = 0;  // lab hook: workgroups (= partial sums) of the backward's reduction pass
+#else
+constexpr int g_bn_grid_cap = 0, g_bn_parts_cap = 0;
+#endif
+
 int walk_grid(int64_t rows, int ncg) {
   const int unit = ncg <= BN_THREADS ? 1 : ncg / BN_THREADS;  // blocks per full row of channel groups
   int64_t g = (rows * ncg + BN_THREADS - 1) / BN_THREADS;
-  if (g > 256 * 16) g = 256 * 16;
+  // Workgroups of the row-walk kernels.  Round 6 (tools/bnbench_small.py, lab hook): the res5 tensors (>= 16 M channel groups: 411 MB) stream
+  // 12-19 % faster in the apply pass and 4-8 % faster in the backward's dx pass with 24 576 workgroups than with 4 096 ([2048,14,14,512]:
+  // apply 178 -> 145 us, backward 420 -> 364 us together with 768 reduction workgroups; torch's own elementwise kernels, which launch one
+  // small workgroup per 16 KiB, move the same bytes at 5.9-6.0 TB/s) -- 4 096 equal workgroups are 2.7 rounds of the 1 536 the chip holds at
+  // this kernel's occupancy, and the last partial round idles a third of it.  Tensors below that size are faster with the coarser grid
+  // ([4,100,167,512]: 32.6 vs 35.9 us): their launch is ramp-bound, not tail-bound.
+  const int cap = g_bn_grid_cap > 0 ? g_bn_grid_cap : (rows * ncg >= (16LL << 20) ? 24576 : 256 * 16);
+  if (g > cap) g = cap;
   g = (g + unit - 1) / unit * unit;
   return (int)(g < unit ? unit : g);
 }
 
 }  // namespace
+
+#ifdef COIN_LAB
+extern "C" void coin_lab_set_bn_grid(int v) { g_bn_grid_cap = v; }
+extern "C" void coin_lab_set_bn_parts(int v) { g_bn_parts_cap = v; }
+extern "C" void coin_lab_set_bn_old(int v) { g_bn_grid_cap = v ? 4096 : 0; g_bn_parts_cap = v ? 512 : 0; }   // tools/ab_bench.py bn_old: round 5's launch shapes
+#endif
 
 #define BN_DISPATCH(dtype, EXPR_F32, EXPR_BF16) \
   do {                                          \
@@ -594,7 +614,7 @@ extern "C" int coin_bn_stats(const void* x, int N, int H, int W, int C, float ep
   const int v = dtype == COIN_F32 ? 4 : 8;
   const int ncg = C / v, tpr = ncg < BN_THREADS ? ncg : BN_THREADS, rpi = BN_THREADS / tpr;
   int64_t g = (M + rpi - 1) / rpi;
-  if (g > COIN_BN_MAX_PARTS) g = COIN_BN_MAX_PARTS;
+  if (g > 512) g = 512;   // (<= COIN_BN_MAX_PARTS: the workspace bound)
   const size_t lds = sizeof(float) * BN_THREADS * 2 * v;
 #define GO(T) bn_stats_kernel<T><<<(int)g, BN_THREADS, lds, st>>>((const T*)x, M, C, sums_workspace); \
   bn_finalize_kernel<T><<<(C + 63) / 64, 1024, 0, st>>>((const T*)x, sums_workspace, (int)g, M, C, eps, momentum, mean, rstd, running_mean, running_var, num_batches_tracked)
@@ -647,7 +667,9 @@ extern "C" int coin_bn_bwd(const void* x, const void* dy, const void* y, const u
   const int64_t M = (int64_t)N * H * W;
   const int ncg = C / v, tpr = ncg < BN_THREADS ? ncg : BN_THREADS, rpi = BN_THREADS / tpr;
   int64_t g = (M + rpi - 1) / rpi;
-  if (g > COIN_BN_MAX_PARTS) g = COIN_BN_MAX_PARTS;
+  // reduction workgroups: 768 (three per CU = one resident round at this kernel's 3 waves per SIMD) for the res5 tensors, 512 below
+  const int parts_cap = g_bn_parts_cap > 0 ? g_bn_parts_cap : (M * ncg >= (16LL << 20) ? COIN_BN_MAX_PARTS : 512);
+  if (g > parts_cap) g = parts_cap;
   const size_t lds = sizeof(float) * BN_THREADS * 2 * v;
   const int wg = walk_grid(M, ncg);
   const int mode = relu_mask ? ((relu ? 1 : 0) | 4) : ((relu ? 1 : 0) | (y ? 2 : 0));

@@ -626,7 +626,7 @@ def rpn_losses(logits: torch.Tensor, labels: torch.Tensor, deltas: torch.Tensor,
 
 
 # --------------------------------------------------------------------------- fused BatchNorm / pooling (NHWC)
-BN_MAX_PARTS = 512  # COIN_BN_MAX_PARTS in include/coin_hip.h
+BN_MAX_PARTS = 768  # COIN_BN_MAX_PARTS in include/coin_hip.h
 
 
 def _nhwc(t: torch.Tensor, name: str):

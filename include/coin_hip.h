@@ -154,7 +154,7 @@ int coin_bias_act_bwd(const void* dC, const void* C, void* dZ, int ld, int M, in
  *                     added a residual; pass y = NULL when it did not: the mask is then recomputed from x and the
  *                     output tensor is not read at all.
  * ---------------------------------------------------------------------------------------- */
-#define COIN_BN_MAX_PARTS 512
+#define COIN_BN_MAX_PARTS 768
 int coin_bn_stats(const void* x, int N, int H, int W, int C, float eps, float momentum, float* sums_workspace,
                   float* mean, float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, int dtype,
                   void* stream);
