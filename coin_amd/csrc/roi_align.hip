@@ -520,19 +520,35 @@ constexpr int LIST_CAP = 4096;  // RoIs per tile list (ordered compaction)
 //            entries.  Round 1's kernel (8x8 tile, wave-private tables) recomputed these per wave and per 128-channel block
 //            (32x redundant) inside its load -> use chain; now they are off the critical path and the inner loop is loads + FMAs;
 //   phase 2: each wave streams the gradient bins with non-zero weight on its row: 16 bytes per lane per bin (1 KiB per
-//            wave-instruction), four bins in flight, converted once and fanned out to the <= 3 tile columns they touch.
+//            wave-instruction), converted once and fanned out to the <= 3 tile columns they touch.
+// Round 6 (tools/roibwd_bench.py on the RoIs of a real step, profiles/r4_real_rois.pt; lab switches DBG): of 0.46 ms the lists + tables +
+// stores are 0.05, the loop skeleton + conversions 0.09, the loads +0.2 and the column fan-out +0.2 -- neither HBM (bf16 and f32 take
+// the same time at twice the bytes) nor FMA issue bound the launch but each wave's serial chain load -> wait -> branch ladder, at 2-4
+// waves per SIMD.  Hence ALG 1 (shipped for bf16): ALL bin rows with weight on a map row are combined first (py ascending, one fused
+// multiply-add each, starting from 0) and fanned out to the tile columns ONCE per bin column -- a real step's boxes put 2.9 bin rows on
+// a map row, so the ladder runs 2.9x less often -- with rounds of PYR x PXC = 2 x 7 bins in flight (70 % of the (RoI, row) pairs have
+// <= 2 bin rows: 4 x 4 rounds were half empty) and 16-byte lanes (half the bin visits per byte): 0.46 -> 0.35 ms.  Measured and
+// dropped (same tool): taller / wider tiles (8 x 8: 0.48, 8 x 16: 0.98 ms -- the column ladder and the table build grow with the tile
+// while the workgroup count shrinks; the 1.5x re-read of bins that straddle 4 x 8 tiles is served by L2 / Infinity Cache and is NOT
+// what bounds the launch); two map rows per wave (fewer bin visits, fewer waves: 0.51); a per-wave LDS ring filled by LDS-DMA with
+// producer / consumer cursors (prefetch depth independent of the box geometry: 0.43-0.55 ms -- deeper rings cost occupancy, and ~70
+// scalar + vector instructions per 1 KiB bin at 3 waves per SIMD bound it at any depth).
 // ------------------------------------------------------------------------------------------
-constexpr int BT_ROWS = 4, BT_COLS = 8, BT_LC = 32;
+// Tile shape = template parameters: BT_ROWS map rows (= waves of the workgroup) x BT_COLS columns; BT_LC list entries per table chunk.
 
 // VEC = channels per lane (4: 16-byte f32 / 8-byte bf16 loads; a wave covers 256 channels).  With 8 bf16 channels per lane the 1024-channel
 // res4 gradient gave 1 144 workgroups whose longest (the central tiles, touched by ~40 % of an image's boxes) bounded the launch.
-template <typename T, int VEC>
-__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
+template <typename T, int VEC, int NW /* waves */, int BT_COLS, int BT_LC, int DBG = 0 /* lab: 1 no gather phase, 2 no loads, 4 no fan-out, 8 stores only */,
+          int ALG = 0 /* 1: all bin rows of a map row are combined before the column fan-out */, int RPW = 1 /* map rows per wave (ALG 1) */,
+          int PYR = 4, int PXC = 4 /* ALG 1: bin rows x bin columns in flight per round */>
+__global__ __launch_bounds__(NW * 64) void roi_align_bwd_gather_kernel(
     const T* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gfeat, int C, int H, int W, int R, int ph, int pw,
     float scale, int sampling_ratio, int aligned, int tiles_x, int tiles_y, int ntiles, int nparts, const int* __restrict__ roi_level, int level) {
   typedef T vec_t __attribute__((ext_vector_type(VEC)));
   __shared__ unsigned short list[LIST_CAP];
-  __shared__ int wave_cnt[4];
+  constexpr int NT = NW * 64, BT_ROWS = NW * RPW;
+  static_assert(BT_LC * BT_ROWS + BT_LC <= NT && BT_COLS % 4 == 0 && BT_COLS <= 32 && (RPW == 1 || ALG == 1), "tile shape");
+  __shared__ int wave_cnt[NW];
   __shared__ int list_n;
   __shared__ __attribute__((aligned(16))) float wyt[BT_LC][16][BT_ROWS];
   __shared__ __attribute__((aligned(16))) float wxt[BT_LC][16][BT_COLS];
@@ -552,18 +568,21 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
   const int c0 = (part * 64 + lane) * VEC;
   const bool c_ok = c0 < C;
 
-  float acc[BT_COLS][VEC];
+  float accr[RPW][BT_COLS][VEC];   // [row of the wave][tile column][channel]
+  float (&acc)[BT_COLS][VEC] = accr[0];
 #pragma unroll
-  for (int t = 0; t < BT_COLS; ++t)
+  for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) acc[t][i] = 0.f;
+    for (int t = 0; t < BT_COLS; ++t)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) accr[rr][t][i] = 0.f;
 
-  for (int base = 0; base < R; base += LIST_CAP) {
+  for (int base = 0; base < ((DBG & 8) ? 0 : R); base += LIST_CAP) {
     const int lim = (R - base) < LIST_CAP ? (R - base) : LIST_CAP;
     // ---- phase 0: ordered compaction of the RoIs of image n whose footprint may touch this tile
     if (threadIdx.x == 0) list_n = 0;
     __syncthreads();
-    for (int i0 = 0; i0 < lim; i0 += 256) {
+    for (int i0 = 0; i0 < lim; i0 += NT) {
       const int i = i0 + threadIdx.x;
       bool hit = false;
       if (i < lim) {
@@ -584,14 +603,18 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
       for (int w = 0; w < wave; ++w) off += wave_cnt[w];
       if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
       __syncthreads();
-      if (threadIdx.x == 0) list_n += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+      if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < NW; ++w) tot += wave_cnt[w];
+        list_n += tot;
+      }
       __syncthreads();
     }
     const int nlist = list_n;
     for (int lb = 0; lb < nlist; lb += BT_LC) {
       const int lcn = (nlist - lb) < BT_LC ? (nlist - lb) : BT_LC;
       // ---- phase 1: weight tables of the chunk's RoIs on this tile; task = (list entry, axis, bin)
-      for (int task = threadIdx.x; task < lcn * 32; task += 256) {
+      for (int task = threadIdx.x; task < lcn * 32; task += NT) {
         const int li = task >> 5, b = task & 15, isx = (task >> 4) & 1;
         const RoiGeom g = roi_geom(rois + (size_t)(base + (int)list[lb + li]) * 5, ph, pw, scale, sampling_ratio, aligned);
         if (isx) {
@@ -645,8 +668,8 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
         unsigned m = 0;
         for (int py = 0; py < ph; ++py) m |= (wyt[li][py][r] != 0.f ? 1u : 0u) << py;
         ymk[li][r] = m;
-      } else if ((int)threadIdx.x >= 128 && (int)threadIdx.x < 128 + lcn) {
-        const int li = threadIdx.x - 128;
+      } else if ((int)threadIdx.x >= BT_LC * BT_ROWS && (int)threadIdx.x < BT_LC * BT_ROWS + lcn) {
+        const int li = threadIdx.x - BT_LC * BT_ROWS;
         int lo = pw, hi = 0;
         for (int px = 0; px < pw; ++px)
           if (xmk[li][px]) {
@@ -658,12 +681,84 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
       }
       __syncthreads();
       // ---- phase 2: wave w gathers for tile row w
-      for (int li = 0; li < lcn; ++li) {
-        unsigned ym = (unsigned)__builtin_amdgcn_readfirstlane((int)ymk[li][wave]);
+      for (int li = 0; li < ((DBG & 1) ? 0 : lcn); ++li) {
+        unsigned ymr[RPW];   // per row of the wave: the bin rows with weight on it
+        unsigned ym = 0;
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+          ymr[rr] = (unsigned)__builtin_amdgcn_readfirstlane((int)ymk[li][wave * RPW + rr]);
+          ym |= ymr[rr];
+        }
         const int pa = __builtin_amdgcn_readfirstlane(pxr[li][0]), pe = __builtin_amdgcn_readfirstlane(pxr[li][1]);
         if (ym == 0 || pa >= pe) continue;
         const int roi = base + (int)list[lb + li];
         const T* __restrict__ go = gout + (size_t)roi * ph * pw * C + (c_ok ? c0 : 0);
+        if constexpr (ALG == 1) {
+          const unsigned ym0 = ym;
+          for (int px = pa; px < pe; px += PXC) {
+            // tf[rr][j] = sum over the bin rows py with weight on map row rr of Wy[py][rr] * gout[py][px + j]  (py ascending, PYR per
+            // round: up to PYR * PXC gradient bins, one wave-instruction each, in flight), fanned out to the tile columns ONCE per bin column.
+            // With RPW = 2 a bin that touches both rows of the wave is loaded (and converted) once, and one column ladder serves both.
+            float tf[RPW][PXC][VEC];
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+              for (int j = 0; j < PXC; ++j)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) tf[rr][j][i] = 0.f;
+            ym = ym0;
+            while (ym) {
+              int py[PYR];
+              vec_t v[PYR][PXC];
+#pragma unroll
+              for (int k = 0; k < PYR; ++k) {
+                py[k] = ym ? __builtin_ctz(ym) : -1;
+                ym &= ym - 1;   // 0 stays 0
+                if (py[k] < 0) continue;
+                const T* __restrict__ grow = go + (size_t)py[k] * pw * C;
+#pragma unroll
+                for (int j = 0; j < PXC; ++j) {
+                  const int pp = px + j < pe ? px + j : pe - 1;
+                  v[k][j] = *reinterpret_cast<const vec_t*>(grow + (size_t)pp * C);
+                }
+              }
+#pragma unroll
+              for (int k = 0; k < PYR; ++k) {
+                if (py[k] < 0) continue;
+#pragma unroll
+                for (int rr = 0; rr < RPW; ++rr) {
+                  if (RPW > 1 && !(ymr[rr] & (1u << py[k]))) continue;   // no weight on this row: nothing is added (not even 0 * x)
+                  const float a = wyt[li][py[k]][wave * RPW + rr];
+#pragma unroll
+                  for (int j = 0; j < PXC; ++j)
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) tf[rr][j][i] += a * (float)v[k][j][i];
+                }
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < PXC; ++j) {
+              if (px + j >= pe) break;
+              const unsigned mk = (unsigned)__builtin_amdgcn_readfirstlane((int)xmk[li][px + j]);
+              if (mk == 0) continue;
+              f32x4 wq[BT_COLS / 4];
+#pragma unroll
+              for (int k = 0; k < BT_COLS / 4; ++k) wq[k] = *reinterpret_cast<const f32x4*>(&wxt[li][px + j][4 * k]);
+#pragma unroll
+              for (int t = 0; t < BT_COLS; ++t) {
+                if (mk & (1u << t)) {
+                  asm volatile("; col taken");  // a real wave-uniform branch (see the forward kernel)
+                  const float wt = wq[t >> 2][t & 3];
+#pragma unroll
+                  for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) accr[rr][t][i] += wt * tf[rr][j][i];
+                }
+              }
+            }
+          }
+          continue;
+        }
         while (ym) {
           // two bin rows per round: up to 8 gradient bins (one wave-instruction each) in flight
           const int py0 = __builtin_ctz(ym);
@@ -679,16 +774,27 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int pp = px + j < pe ? px + j : pe - 1;
+              if constexpr ((DBG & 2) != 0) {   // no loads
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) v[j][i] = v[4 + j][i] = (T)(float)(pp + i);
+                continue;
+              }
               v[j] = *reinterpret_cast<const vec_t*>(grow0 + (size_t)pp * C);
               if (py1 >= 0) v[4 + j] = *reinterpret_cast<const vec_t*>(grow1 + (size_t)pp * C);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               if (px + j >= pe) break;
-              const unsigned mk = (unsigned)__builtin_amdgcn_readfirstlane((int)xmk[li][px + j]);
+              unsigned mk = (unsigned)__builtin_amdgcn_readfirstlane((int)xmk[li][px + j]);
+              if constexpr ((DBG & 4) != 0) {   // no fan-out: the loaded values are consumed by one accumulator
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[0][i] += (float)v[j][i] + (float)v[4 + j][i];
+                mk = 0;
+              }
               if (mk == 0) continue;
-              const f32x4 w0 = *reinterpret_cast<const f32x4*>(&wxt[li][px + j][0]);
-              const f32x4 w1 = *reinterpret_cast<const f32x4*>(&wxt[li][px + j][4]);
+              f32x4 wq[BT_COLS / 4];
+#pragma unroll
+              for (int k = 0; k < BT_COLS / 4; ++k) wq[k] = *reinterpret_cast<const f32x4*>(&wxt[li][px + j][4 * k]);
               // the two rows are combined first (fixed order), then fanned out to the tile columns
               float vf[VEC];
 #pragma unroll
@@ -701,7 +807,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
               for (int t = 0; t < BT_COLS; ++t) {
                 if (mk & (1u << t)) {
                   asm volatile("; col taken");  // a real wave-uniform branch (see the forward kernel)
-                  const float wt = t < 4 ? w0[t & 3] : w1[t & 3];
+                  const float wt = wq[t >> 2][t & 3];
 #pragma unroll
                   for (int i = 0; i < VEC; ++i) acc[t][i] += wt * vf[i];
                 }
@@ -714,17 +820,21 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(
     }
     __syncthreads();  // list is rebuilt for the next chunk of RoIs
   }
-  const int y = ty0 + wave;
-  if (!c_ok || y >= H) return;
-  float* __restrict__ gmap = gfeat + (((size_t)n * H + y) * W) * C + c0;
+  if (!c_ok) return;
 #pragma unroll
-  for (int t = 0; t < BT_COLS; ++t) {
-    const int x = tx0 + t;
-    if (x < W) {
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int y = ty0 + wave * RPW + rr;
+    if (y >= H) break;
+    float* __restrict__ gmap = gfeat + (((size_t)n * H + y) * W) * C + c0;
 #pragma unroll
-      for (int i0 = 0; i0 < VEC; i0 += 4) {
-        const f32x4 o = {acc[t][i0], acc[t][i0 + 1], acc[t][i0 + 2], acc[t][i0 + 3]};
-        *reinterpret_cast<f32x4*>(gmap + (size_t)x * C + i0) = o;
+    for (int t = 0; t < BT_COLS; ++t) {
+      const int x = tx0 + t;
+      if (x < W) {
+#pragma unroll
+        for (int i0 = 0; i0 < VEC; i0 += 4) {
+          const f32x4 o = {accr[rr][t][i0], accr[rr][t][i0 + 1], accr[rr][t][i0 + 2], accr[rr][t][i0 + 3]};
+          *reinterpret_cast<f32x4*>(gmap + (size_t)x * C + i0) = o;
+        }
       }
     }
   }
@@ -876,6 +986,25 @@ extern "C" int coin_roi_align_fwd(const void* feat, int N, int C, int H, int W, 
   return coin_launch_status();
 }
 
+#ifdef COIN_LAB
+int g_roi_bwd_cfg = 0;   // lab hook (tools/roibwd_bench.py): tile shape of the backward gather
+extern "C" void coin_roi_align_lab_bwd_cfg(int v) { g_roi_bwd_cfg = v; }
+extern "C" void coin_lab_set_roi_bwd_old(int v) { g_roi_bwd_cfg = v ? 10 : 0; }   // tools/ab_bench.py roi_bwd_old: round 2's backward
+#else
+constexpr int g_roi_bwd_cfg = 0;
+#endif
+
+template <typename T, int VEC, int NW, int COLS, int LC, int DBG = 0, int ALG = 0, int RPW = 1, int PYR = 4, int PXC = 4>
+static void launch_bwd_gather(const T* grad_out, const float* rois, float* grad_feat, int N, int C, int H, int W, int R, int ph, int pw, float scale,
+                              int sampling_ratio, int aligned, const int* roi_level, int level, hipStream_t st) {
+  constexpr int ROWS = NW * RPW;
+  const int tiles_x = (W + COLS - 1) / COLS, tiles_y = (H + ROWS - 1) / ROWS;
+  const int ntiles = tiles_x * tiles_y * N;
+  const int nparts = (C + 64 * VEC - 1) / (64 * VEC);
+  roi_align_bwd_gather_kernel<T, VEC, NW, COLS, LC, DBG, ALG, RPW, PYR, PXC><<<ntiles * nparts, NW * 64, 0, st>>>(grad_out, rois, grad_feat, C, H, W, R, ph, pw, scale, sampling_ratio,
+                                                                                         aligned, tiles_x, tiles_y, ntiles, nparts, roi_level, level);
+}
+
 static int roi_align_bwd_impl(const void* grad_out, int N, int C, int H, int W, int layout, const float* rois,
                               int R, int ph, int pw, float spatial_scale, int sampling_ratio, int aligned,
                               float* grad_feat, int dtype, void* stream, const int* roi_level, int level) {
@@ -889,17 +1018,47 @@ static int roi_align_bwd_impl(const void* grad_out, int N, int C, int H, int W, 
   }
   if (layout == COIN_NHWC && ph <= 16 && pw <= 16) {
     // atomic-free gather per map tile: writes every element of grad_feat exactly once
-    const int tiles_x = (W + BT_COLS - 1) / BT_COLS, tiles_y = (H + BT_ROWS - 1) / BT_ROWS;
-    const int ntiles = tiles_x * tiles_y * N;
+    const int cfg = ROI_LAB(true) ? g_roi_bwd_cfg : 0;
+#define BWD_GO(T, VEC, ROWS, COLS, LC, ...)                                                                                             \
+  launch_bwd_gather<T, VEC, ROWS, COLS, LC, ##__VA_ARGS__>((const T*)grad_out, rois, grad_feat, N, C, H, W, R, ph, pw, spatial_scale, sampling_ratio, \
+                                            aligned, roi_level, level, st)
+#ifdef COIN_LAB   // tools/roibwd_bench.py: tile shapes, the two summation orders, rounds in flight, kernel minus its parts
+#define BWD_LAB_CASES(T)                                   \
+    case 1: BWD_GO(T, 4, 8, 8, 32); break;                 \
+    case 2: BWD_GO(T, 4, 8, 16, 16); break;                \
+    case 3: BWD_GO(T, 4, 4, 16, 32); break;                \
+    case 4: BWD_GO(T, 8, 8, 8, 32); break;                 \
+    case 10: BWD_GO(T, 4, 4, 8, 32); break;                \
+    case 11: BWD_GO(T, 4, 4, 8, 32, 1); break;             \
+    case 12: BWD_GO(T, 4, 4, 8, 32, 2); break;             \
+    case 14: BWD_GO(T, 4, 4, 8, 32, 4); break;             \
+    case 16: BWD_GO(T, 4, 4, 8, 32, 6); break;             \
+    case 20: BWD_GO(T, 4, 4, 8, 32, 0, 1); break;          \
+    case 22: BWD_GO(T, 8, 4, 8, 32, 0, 1); break;          \
+    case 23: BWD_GO(T, 8, 8, 8, 32, 0, 1); break;          \
+    case 24: BWD_GO(T, 4, 4, 8, 16, 0, 1, 2); break;       \
+    case 34: BWD_GO(T, 4, 4, 8, 32, 0, 1, 1, 2, 4); break; \
+    case 37: BWD_GO(T, 8, 4, 8, 32, 0, 1, 1, 2, 7); break; \
+    case 41: BWD_GO(T, 4, 4, 8, 32, 0, 1, 1, 2, 7); break;
+#else
+#define BWD_LAB_CASES(T)
+#endif
+    // shipped: bf16 -- 16-byte lanes (512 channels per workgroup), all bin rows of a map row combined before the column fan-out, rounds of
+    // 2 bin rows x 7 bin columns in flight; f32 -- round 2's pairs of bin rows x 4 bin columns (the wider rounds cost it registers:
+    // 0.51 vs 0.57 ms on a real step's boxes but 1.32 vs 1.23 ms on 300-800 px boxes)
     if (dtype == COIN_F32) {
-      const int nparts = (C + 64 * 4 - 1) / (64 * 4);
-      roi_align_bwd_gather_kernel<float, 4><<<ntiles * nparts, 256, 0, st>>>((const float*)grad_out, rois, grad_feat, C, H, W, R, ph, pw, spatial_scale,
-                                                                          sampling_ratio, aligned, tiles_x, tiles_y, ntiles, nparts, roi_level, level);
+      switch (cfg) {
+        BWD_LAB_CASES(float)
+        default: BWD_GO(float, 4, 4, 8, 32); break;
+      }
     } else {
-      const int nparts = (C + 64 * 4 - 1) / (64 * 4);
-      roi_align_bwd_gather_kernel<bf16_t, 4><<<ntiles * nparts, 256, 0, st>>>((const bf16_t*)grad_out, rois, grad_feat, C, H, W, R, ph, pw, spatial_scale,
-                                                                           sampling_ratio, aligned, tiles_x, tiles_y, ntiles, nparts, roi_level, level);
+      switch (cfg) {
+        BWD_LAB_CASES(bf16_t)
+        default: BWD_GO(bf16_t, 8, 4, 8, 32, 0, 1, 1, 2, 7); break;
+      }
     }
+#undef BWD_LAB_CASES
+#undef BWD_GO
   } else if (roi_level != nullptr) {
     return COIN_ESHAPE;   // the level filter exists in the tile-gather kernel only (channels-last, bins <= 16 x 16)
   } else if (layout == COIN_NHWC) {

@@ -125,6 +125,35 @@ def test_roi_align_bwd_many_rois_large_bins_and_reproducibility(K):
             assert torch.equal(gin, again)
 
 
+@pytest.mark.parametrize("c,bins", [(520, 14), (1024, 7), (8, 14)])
+def test_roi_align_bwd_bf16_tiny_and_huge_boxes_ragged_channel_slab(K, c, bins):
+    """The bf16 backward combines ALL bin rows that put weight on a map row before it fans out to the tile columns, two bin rows x
+    seven bin columns per round: boxes smaller than a map cell (all 14 bin rows land on one or two map rows -> seven rounds per bin
+    column), boxes as large as the image, boxes hanging over the border; C = 520 leaves the second 512-channel slab with 8 live
+    channels.  Against the fp64 oracle on the same bf16 values; twice, bit for bit."""
+    from oracle import d2
+
+    g = torch.Generator().manual_seed(61)
+    n, h, w = 2, 23, 37
+    per = 40
+    tiny = torch.rand(per, 2, generator=g) * torch.tensor([w * 16.0 - 20, h * 16.0 - 20])
+    tiny = torch.cat([tiny, tiny + torch.rand(per, 2, generator=g) * 14 + 1], 1)                      # 1-15 px: under one map cell
+    huge = torch.tensor([[0.0, 0.0, w * 16.0, h * 16.0], [-40.0, -30.0, w * 16.0 + 50, h * 16.0 + 20], [100.0, -64.0, 180.0, h * 16.0 + 64]])
+    mid = make_rois(1, 30, h * 16, w * 16, g)[:, 1:]
+    boxes = torch.cat([tiny, huge, mid])
+    rois = torch.cat([torch.cat([torch.full((len(boxes), 1), float(i)), boxes], 1) for i in range(n)])
+    r = len(rois)
+    go = torch.randn(r, bins, bins, c, generator=g).to(torch.bfloat16)
+    fd = torch.zeros(n, c, h, w, dtype=torch.float64, requires_grad=True)
+    d2.roi_align_torch(fd, rois.double(), (bins, bins), 1 / 16.0, 0, True).backward(go.double().permute(0, 3, 1, 2))
+    gin = K.roi_align_bwd(dev(go), dev(rois), (n, h, w, c), 1 / 16.0)
+    torch.testing.assert_close(gin.permute(0, 3, 1, 2).cpu().double(), fd.grad, rtol=2e-4, atol=2e-4)
+    assert torch.equal(gin, K.roi_align_bwd(dev(go), dev(rois), (n, h, w, c), 1 / 16.0))
+    # the f32 kernel on the same values (another summation order): agreement at f32 rounding
+    g32 = K.roi_align_bwd(dev(go.float()), dev(rois), (n, h, w, c), 1 / 16.0)
+    torch.testing.assert_close(gin, g32, rtol=1e-4, atol=1e-4)
+
+
 def test_roi_align_full_size_properties(K):
     """BASELINE size (4 views x 512 RoIs, C=1024, bf16): constant map -> 1 inside the image; adjointness."""
     g = torch.Generator().manual_seed(7)
