@@ -65,8 +65,11 @@ from . import layers as L
 
 ENABLED = {"on": os.environ.get("COIN_STEP_GRAPHS", "1") != "0"}
 WARM_CALLS = 2          # eager calls of a shape before it is captured
-MAX_GRAPHS = 3          # shapes per segment (real data: a few padded sizes); further shapes stay eager
-STATS = {"captures": 0, "replays": 0, "eager": 0, "busy": 0, "launch_ms": 0.0}   # launch_ms: host time spent inside hipGraphLaunch
+MAX_GRAPHS = 3          # captured shapes per segment (each holds a private pool with the stretch's activations and static gradients)
+EVICT_AFTER = 8         # a shape seen this often while the table is full may take the place of ...
+EVICT_IDLE = 16         # ... the captured shape not replayed for this many calls of the segment (least recently used first)
+# launch_ms: host time spent inside hipGraphLaunch; pool_bytes: device memory the allocator reserved for the captures that are alive
+STATS = {"captures": 0, "replays": 0, "eager": 0, "busy": 0, "launch_ms": 0.0, "evictions": 0, "pool_bytes": 0}
 CAPTURE_MODE = {"fwd": "thread_local", "bwd": "thread_local"}   # other threads (image decoding) may touch the device meanwhile
 TRACE: Optional[list] = None   # diagnostics (tools/bb_bisect.py (round 5; in the git history)): a list here receives (node, incoming gradients, results) of every captured backward node
 
@@ -318,7 +321,7 @@ class _ChunkedCapture:
 
 
 class _Entry:
-    __slots__ = ("fwd", "bwd", "static_in", "outs", "out_req", "static_gout", "grads_in", "grads_p", "params", "busy", "pool", "single", "workspaces", "ptrs", "bwd_chunks")
+    __slots__ = ("fwd", "bwd", "static_in", "outs", "out_req", "static_gout", "grads_in", "grads_p", "params", "busy", "pool", "single", "workspaces", "ptrs", "bwd_chunks", "last_used", "pool_bytes")
 
 
 class _Replay(torch.autograd.Function):
@@ -437,6 +440,7 @@ class GraphedSegment:
         self.graphs: Dict[tuple, _Entry] = {}
         self.seen: Dict[tuple, int] = {}
         self.failed = False
+        self.calls = 0          # eligible calls of this segment: the clock of the least-recently-used bookkeeping
         _SEGMENTS.add(self)
 
     # ---------------------------------------------------------------- eligibility
@@ -459,12 +463,15 @@ class GraphedSegment:
             STATS["eager"] += 1
             return self.fn(*inputs)
         key = self._key(inputs, key_extra)
+        self.calls += 1
         ent = self.graphs.get(key)
         if ent is None:
             n = self.seen.get(key, 0) + 1
             if len(self.seen) > 64 and key not in self.seen:   # variable-size data: the table of seen shapes stays bounded
                 self.seen.pop(next(iter(self.seen)))
             self.seen[key] = n
+            if n >= EVICT_AFTER and len(self.graphs) >= MAX_GRAPHS:
+                self._evict_idle()   # variable-size data (round-5 ADVICE): the first shapes to repeat are not pinned for good
             if n < WARM_CALLS or len(self.graphs) >= MAX_GRAPHS:
                 STATS["eager"] += 1
                 return self.fn(*inputs)
@@ -488,6 +495,7 @@ class GraphedSegment:
                 _recover_from_failed_capture()
                 STATS["eager"] += 1
                 return self.fn(*inputs)
+            ent.last_used = self.calls
             self.graphs[key] = ent
             STATS["captures"] += 1
         if ent.busy or _STEP["defer"]:
@@ -500,14 +508,30 @@ class GraphedSegment:
             self.seen[key] = 0
             STATS["eager"] += 1
             STATS["stale"] = STATS.get("stale", 0) + 1
+            STATS["pool_bytes"] -= getattr(ent, "pool_bytes", 0)
             return self.fn(*inputs)
         _STEP["replayed"] = True
         STATS["replays"] += 1
+        ent.last_used = self.calls
         _detach_static_grads(ent)
         outs = _Replay.apply(ent, len(inputs), *inputs, *ent.params)
         # until this call's backward has replayed, the graph's buffers hold the activations it will read: a second call must not replay
         ent.busy = ent.bwd is not None and any(o.requires_grad for o in outs)
         return outs[0] if ent.single else outs
+
+    def _evict_idle(self) -> bool:
+        """Drops the captured shape that has gone unreplayed the longest, if that is at least EVICT_IDLE calls of this segment (and its
+        backward is not pending): its graphs and their pool go back to the allocator, the newcomer is captured by the usual schedule.
+        A shape that comes back later warms up and is captured again -- the table follows the data instead of its first three sizes."""
+        idle = [(e.last_used, k) for k, e in self.graphs.items() if not e.busy and self.calls - e.last_used >= EVICT_IDLE]
+        if not idle:
+            return False
+        _, k = min(idle, key=lambda t: t[0])
+        ent = self.graphs.pop(k)
+        self.seen[k] = 0
+        STATS["evictions"] += 1
+        STATS["pool_bytes"] -= getattr(ent, "pool_bytes", 0)
+        return True
 
     def _fresh(self, ent: _Entry) -> bool:
         """What the eager path checks on every call and a replay would skip (round-5 ADVICE): the storages the graph was recorded against
@@ -565,10 +589,15 @@ class GraphedSegment:
         # stream, and what this capture allocates leaves the stream's cache with it (kernels.take_stream_workspaces)
         cap = K.capture_stream_value()
         K.take_stream_workspaces(cap)
+        reserved0 = torch.cuda.memory_reserved(inputs[0].device)
         try:
             self._record(ent, grad_mode)
         finally:
             ent.workspaces = K.take_stream_workspaces(cap)
+        # what the allocator had to reserve for this capture (its private pool; blocks the pool could reuse from the cache do not count)
+        ent.pool_bytes = max(0, torch.cuda.memory_reserved(inputs[0].device) - reserved0)
+        ent.last_used = self.calls
+        STATS["pool_bytes"] += ent.pool_bytes
         ent.ptrs = [t.data_ptr() for t in list(self.params_fn()) + (list(self.buffers_fn()) if self.buffers_fn is not None else [])]
         return ent
 

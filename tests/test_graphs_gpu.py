@@ -206,6 +206,59 @@ def test_a_busy_segment_and_foreign_streams_fall_back_to_the_eager_launches(monk
         assert G.STATS["eager"] == eager0 + 1 and torch.equal(y3.detach(), r1)
 
 
+def test_a_shape_that_keeps_coming_takes_the_place_of_the_least_recently_replayed_graph(monkeypatch):
+    """Variable-size data (round-5 ADVICE): with the table full, a shape seen EVICT_AFTER times evicts the captured shape that has not been
+    replayed for EVICT_IDLE calls (never one whose backward is pending), is captured by the usual schedule and replays; the evicted
+    shape's pool is released (STATS['pool_bytes']) and it is captured again when it comes back.  Every call, replayed or eager, equals
+    the eager module."""
+    from coin_amd import graphs as G
+    from coin_amd import layers as L
+
+    monkeypatch.setitem(L.CONV_GEMM, "enabled", True)
+    monkeypatch.setitem(L.CONV_GEMM, "min_rows", 0)
+    monkeypatch.setitem(G.ENABLED, "on", True)
+    monkeypatch.setattr(G, "MAX_GRAPHS", 1)
+    monkeypatch.setattr(G, "EVICT_AFTER", 3)
+    monkeypatch.setattr(G, "EVICT_IDLE", 4)
+    b = _blocks(11)
+    b.eval()
+    for p in b.parameters():
+        p.requires_grad_(False)
+    seg = G.GraphedSegment("test_evict", lambda x: b(x), lambda: [], lambda: list(b.buffers()))
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    mk = lambda n: torch.randn(n, 1024, 14, 14, device="cuda", generator=gen).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    key_of = lambda n: [k for k in seg.graphs if k[0][0][0][0] == n]
+    G.step_done()
+    st0 = dict(G.STATS)
+
+    def call(n):
+        x = mk(n)
+        with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+            y = seg(x)
+            ref = b(x)
+        assert torch.equal(y, ref)
+        G.step_done()
+
+    for _ in range(4):
+        call(8)                                  # eager, eager, captured, replayed
+    assert key_of(8) and G.STATS["replays"] == st0["replays"] + 1
+    pool_a = G.STATS["pool_bytes"] - st0["pool_bytes"]
+    assert pool_a >= 0
+    for i in range(3):
+        call(6)                                  # table full, shape 8 replayed < EVICT_IDLE calls ago: stays eager
+    assert key_of(8) and not key_of(6) and G.STATS["evictions"] == st0.get("evictions", 0)
+    for i in range(4):
+        call(6)                                  # now idle long enough: evicted, 6 captured and replayed
+    assert key_of(6) and not key_of(8) and G.STATS["evictions"] == st0.get("evictions", 0) + 1
+    r0 = G.STATS["replays"]
+    call(6)
+    assert G.STATS["replays"] == r0 + 1
+    for _ in range(8):
+        call(8)                                  # the first shape comes back: warms up, evicts 6 once that has idled, replays again
+    assert key_of(8) and not key_of(6) and G.STATS["evictions"] == st0.get("evictions", 0) + 2
+    assert G.STATS["pool_bytes"] - st0["pool_bytes"] >= 0
+
+
 def _pretrainer(graphs_on, steps, seed=7):
     from coin_amd import graphs as G
 
