@@ -67,6 +67,7 @@ ENABLED = {"on": os.environ.get("COIN_STEP_GRAPHS", "1") != "0"}
 WARM_CALLS = 2          # eager calls of a shape before it is captured
 MAX_GRAPHS = 3          # captured shapes per segment (each holds a private pool with the stretch's activations and static gradients)
 EVICT_AFTER = 8         # a shape seen this often while the table is full may take the place of ...
+EARLY_DELIVERY = [os.environ.get("COIN_EARLY_DELIVERY", "1") != "0"]   # A/B switch: chunk-by-chunk hand-over of a replayed backward's gradients to the reducer
 EVICT_IDLE = 16         # ... the captured shape not replayed for this many calls of the segment (least recently used first)
 # launch_ms: host time spent inside hipGraphLaunch; pool_bytes: device memory the allocator reserved for the captures that are alive
 STATS = {"captures": 0, "replays": 0, "eager": 0, "busy": 0, "launch_ms": 0.0, "evictions": 0, "pool_bytes": 0}
@@ -96,6 +97,7 @@ def step_done() -> None:
     ran under grad mode but whose output never reached a backward would otherwise stay busy, i.e. eager, for ever -- and the capture
     schedule advances (see `_STEP`)."""
     for seg in list(_SEGMENTS):
+        seg.outside_uses = 0
         for ent in seg.graphs.values():
             ent.busy = False
     _STEP["captured"], _STEP["replayed"], _STEP["defer"] = False, False, bool(_WANT_NEXT)
@@ -321,7 +323,7 @@ class _ChunkedCapture:
 
 
 class _Entry:
-    __slots__ = ("fwd", "bwd", "static_in", "outs", "out_req", "static_gout", "grads_in", "grads_p", "params", "busy", "pool", "single", "workspaces", "ptrs", "bwd_chunks", "last_used", "pool_bytes")
+    __slots__ = ("fwd", "bwd", "static_in", "outs", "out_req", "static_gout", "grads_in", "grads_p", "params", "busy", "pool", "single", "workspaces", "ptrs", "bwd_chunks", "last_used", "pool_bytes", "seg")
 
 
 class _Replay(torch.autograd.Function):
@@ -356,6 +358,8 @@ class _Replay(torch.autograd.Function):
                 s.copy_(g)
         _detach_static_grads(ent)
         early = set()
+        seg = ent.seg() if getattr(ent, "seg", None) is not None else None
+        exclusive = (seg is None or seg.outside_uses == 0) and EARLY_DELIVERY[0]   # no other differentiable pass over these parameters in this step (note_outside_use)
         if ent.bwd_chunks:
             # Data-parallel mode: the backward was recorded as several graphs, cut where 16 MiB of parameter gradients are final.  After
             # each one the reducer is told at once (`deliver_early`): a slice whose gradients are complete is packed and its all-reduce
@@ -368,7 +372,7 @@ class _Replay(torch.autograd.Function):
                     p, g = ent.params[j], ent.grads_p[j]
                     hooks = getattr(p, "_post_accumulate_grad_hooks", None)
                     owners = [getattr(h, "__self__", None) for h in hooks.values()] if hooks else []
-                    if (g is not None and p.grad is None and not getattr(p, "_backward_hooks", None) and owners
+                    if (exclusive and g is not None and p.grad is None and not getattr(p, "_backward_hooks", None) and owners
                             and all(hasattr(o, "deliver_early") for o in owners)):
                         p.grad = g
                         for o in owners:
@@ -441,6 +445,7 @@ class GraphedSegment:
         self.seen: Dict[tuple, int] = {}
         self.failed = False
         self.calls = 0          # eligible calls of this segment: the clock of the least-recently-used bookkeeping
+        self.outside_uses = 0   # this step: differentiable passes over the stretch's parameters that were NOT a replay (see note_outside_use)
         _SEGMENTS.add(self)
 
     # ---------------------------------------------------------------- eligibility
@@ -458,10 +463,15 @@ class GraphedSegment:
                 torch.is_autocast_enabled("cuda"), torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None,
                 (cg["enabled"], cg["wgrad"], cg["min_rows"]), L._VALID_ROWS[0], extra)
 
+    def _eager(self, inputs):
+        if torch.is_grad_enabled():
+            self.outside_uses += 1
+        return self.fn(*inputs)
+
     def __call__(self, *inputs, key_extra=()):
         if not self._eligible(inputs):
             STATS["eager"] += 1
-            return self.fn(*inputs)
+            return self._eager(inputs)
         key = self._key(inputs, key_extra)
         self.calls += 1
         ent = self.graphs.get(key)
@@ -474,12 +484,12 @@ class GraphedSegment:
                 self._evict_idle()   # variable-size data (round-5 ADVICE): the first shapes to repeat are not pinned for good
             if n < WARM_CALLS or len(self.graphs) >= MAX_GRAPHS:
                 STATS["eager"] += 1
-                return self.fn(*inputs)
+                return self._eager(inputs)
             if n == WARM_CALLS or _STEP["captured"] or _STEP["replayed"]:
                 # ready from the next call on -- or ready now, but another stretch was captured / replayed in this step: announce and wait
                 _WANT_NEXT.add((id(self), key))
                 STATS["eager"] += 1
-                return self.fn(*inputs)
+                return self._eager(inputs)
             _STEP["captured"] = True
             rng = torch.cuda.get_rng_state(inputs[0].device)   # a capture registers the generator with the graph and moves its offset: the
             try:                                                 # samplers' draws of the following eager code must not depend on it
@@ -494,13 +504,13 @@ class GraphedSegment:
                 self.failed = True
                 _recover_from_failed_capture()
                 STATS["eager"] += 1
-                return self.fn(*inputs)
+                return self._eager(inputs)
             ent.last_used = self.calls
             self.graphs[key] = ent
             STATS["captures"] += 1
         if ent.busy or _STEP["defer"]:
             STATS["busy" if ent.busy else "eager"] += 1
-            return self.fn(*inputs)     # (defer: another stretch captures in this step, nothing may be replayed around it)
+            return self._eager(inputs)     # (defer: another stretch captures in this step, nothing may be replayed around it)
         if not self._fresh(ent):
             # a parameter / buffer of the stretch lives in another storage than at capture (load_state_dict with assign, `.data =`, a
             # module moved): the recorded kernels point at the old one.  Drop the graph; the shape is captured again after its warm-up calls
@@ -509,7 +519,7 @@ class GraphedSegment:
             STATS["eager"] += 1
             STATS["stale"] = STATS.get("stale", 0) + 1
             STATS["pool_bytes"] -= getattr(ent, "pool_bytes", 0)
-            return self.fn(*inputs)
+            return self._eager(inputs)
         _STEP["replayed"] = True
         STATS["replays"] += 1
         ent.last_used = self.calls
@@ -518,6 +528,16 @@ class GraphedSegment:
         # until this call's backward has replayed, the graph's buffers hold the activations it will read: a second call must not replay
         ent.busy = ent.bwd is not None and any(o.requires_grad for o in outs)
         return outs[0] if ent.single else outs
+
+    def note_outside_use(self) -> None:
+        """The stretch's parameters take part in another differentiable pass of this step that is not a replay of this segment: an eager
+        fallback of the segment itself (busy, foreign stream, a shape that is not captured), or -- told by the caller -- a pass that bypasses
+        it (the roi heads' padded C-box pass runs res5 eagerly on the same weights).  Such a parameter's gradient is complete only when the
+        autograd engine has added the other pass's contribution, so a replayed backward must NOT hand it to the data-parallel reducer
+        chunk by chunk: found with two ranks on one GPU (tests/test_ddp_gpu.py, CoinTrainer): the early all-reduce carried the replay's
+        share only and the C-box share was added afterwards, per rank, to the reduced sum -- the ranks' weights drifted apart.  Until
+        `step_done()` the segment's replays deliver their gradients through the accumulator nodes, at the end of the stretch's backward."""
+        self.outside_uses += 1
 
     def _evict_idle(self) -> bool:
         """Drops the captured shape that has gone unreplayed the longest, if that is at least EVICT_IDLE calls of this segment (and its
@@ -595,6 +615,7 @@ class GraphedSegment:
         finally:
             ent.workspaces = K.take_stream_workspaces(cap)
         # what the allocator had to reserve for this capture (its private pool; blocks the pool could reuse from the cache do not count)
+        ent.seg = weakref.ref(self)
         ent.pool_bytes = max(0, torch.cuda.memory_reserved(inputs[0].device) - reserved0)
         ent.last_used = self.calls
         STATS["pool_bytes"] += ent.pool_bytes

@@ -133,6 +133,9 @@ class OpenVocabularyRes5ROIHeads(nn.Module):
         if not (self.step_graphs and self.training and torch.is_grad_enabled() and self.pooling_type == "meanpool" and len(self.in_features) == 1
                 and rois.is_cuda and rois.shape[0] > 0 and isinstance(res5, torch.nn.Sequential) and L._VALID_ROWS[0] is None):
             # (a padded pass -- the C boxes, whose count changes every step -- stays eager: each (count, padding) pair would be its own graph)
+            seg = (self._trunk_segs or {}).get(id(res5))
+            if seg is not None and seg[1] is not None and torch.is_grad_enabled():
+                seg[1].note_outside_use()   # res5's weights get a second gradient contribution in this step: no chunk-by-chunk hand-over
             if (rois.is_cuda and rois.shape[0] > 0 and self.compute_dtype == torch.bfloat16 and isinstance(res5, torch.nn.Sequential)
                     and self._res5_library_free(res5)):
                 # ... but on the hand-written kernels whatever its row count (round 6: the 128 x 128 small-map cores serve a 64-RoI pass as

@@ -32,7 +32,7 @@ import torch.distributed as dist
 
 
 class _Slice:
-    __slots__ = ("params", "views", "flat", "arrived", "launched", "work", "events", "seen")
+    __slots__ = ("params", "views", "flat", "arrived", "launched", "work", "events", "seen", "stamp")
 
 
 class GradReducer:
@@ -111,7 +111,7 @@ class GradReducer:
             # optimizer sees the layout it expects
             s.views.append(s.flat[off:off + p.numel()].as_strided(p.shape, p.stride()) if _dense(p) else s.flat[off:off + p.numel()].view(p.shape))
             off += p.numel()
-        s.arrived, s.launched, s.work, s.events, s.seen = 0, False, None, [], set()
+        s.arrived, s.launched, s.work, s.events, s.seen, s.stamp = 0, False, None, [], set(), None
         idx = len(self.slices)
         self.slices.append(s)
         for p in params:
@@ -137,6 +137,15 @@ class GradReducer:
     def _on_grad(self, p: torch.nn.Parameter):
         if self._early and id(p) in self._early:
             self._early.discard(id(p))
+            # The engine's accumulator node has run for a parameter that was handed over early.  It must have had nothing to add: if the
+            # slice's collective is already launched and the arena was written since (the accumulator adds in place into p.grad = the arena
+            # view), another pass's contribution reached this rank's copy AFTER the all-reduce -- the ranks would drift apart silently
+            # (found with two ranks on one GPU; coin_amd.graphs.GraphedSegment.note_outside_use is what prevents it).  Fail loudly.
+            s = self.slices[self._slice_of[id(p)]]
+            if s.launched and s.stamp is not None and s.flat._version != s.stamp:
+                raise RuntimeError("GradReducer: a parameter whose gradient was delivered early (a replayed step graph) received another "
+                                   "contribution after its slice was all-reduced; the other pass must be announced with "
+                                   "GraphedSegment.note_outside_use() before the backward")
             return
         self._arrive(p)
 
@@ -180,6 +189,7 @@ class GradReducer:
         s.launched = True
         if self.world_size > 1 or _FORCE[0]:
             s.work = dist.all_reduce(s.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        s.stamp = s.flat._version   # (views share their base's version counter: any later in-place write of a p.grad of this slice moves it)
         if s.flat.is_cuda:   # whoever consumes the arena (finalize, on the caller's stream) waits for this pack
             done = torch.cuda.Event()
             done.record(torch.cuda.current_stream(s.flat.device))
@@ -214,7 +224,7 @@ class GradReducer:
             if s.work is not None:
                 s.work.wait()
                 s.work = None
-            s.arrived, s.launched, s.events = 0, False, []
+            s.arrived, s.launched, s.events, s.stamp = 0, False, [], None
             s.seen.clear()
         self._next = 0
         if self._early:

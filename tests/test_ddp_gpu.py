@@ -144,7 +144,168 @@ def test_replayed_stretches_hand_their_gradients_to_the_reducer_chunk_by_chunk()
     assert first_ar < last_replay, order
     assert any(order[i] == "replay" and order[i + 1] == "allreduce" and "replay" in order[i + 2:] for i in range(len(order) - 2)), order
     assert "replay" not in off["last_step_order"]
+    # the RoI losses depend on which proposals get sampled: two runs of the SAME setting differ by up to 2.5e-2 in loss_cls on this tiny
+    # bf16 configuration (measured: graphs on twice, 2.0623 vs 2.0374 at step 1 -- the library's solver choice for the RPN / stem
+    # convolutions differs from process to process under MIOPEN_FIND_MODE=2 and a proposal whose IoU crosses 0.5 flips a label); the RPN
+    # and text losses do not depend on the sampling and agree to 1e-3
     for a, b in zip(on["losses"], off["losses"]):
         for k in a:
-            tol = (5e-3 if k in ("loss_cls", "loss_box_reg") else 1e-3) * max(1.0, abs(a[k]))
+            tol = (5e-2 if k in ("loss_cls", "loss_box_reg") else 1e-3) * max(1.0, abs(a[k]))
             assert abs(a[k] - b[k]) <= tol, (k, a[k], b[k])
+
+
+_SCRIPT_TWO = r"""
+import hashlib, json, os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+dist.init_process_group("gloo")      # two ranks on ONE GPU: gloo moves CUDA tensors through the host -- RCCL refuses two ranks per device
+rank = dist.get_rank()
+from coin_amd import graphs as G
+from coin_amd.config import get_cfg
+from coin_amd.engine import PRETrainer
+cfg = get_cfg()
+cfg.merge_from_file(os.path.join({root!r}, "configs", "coin", "PRETRAINS", "CLIPDET_synthetic.yaml"))
+cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", 2, "AMD.SYNTHETIC.NUM_IMAGES", 2, "AMD.SYNTHETIC.HEIGHT", 384, "AMD.SYNTHETIC.WIDTH", 640,
+                     "AMD.TEXT_TEMPLATES", 2, "MODEL.DEVICE", "cuda:0", "AMD.COMPUTE_DTYPE", "bf16"])
+G.set_enabled(True)
+torch.manual_seed(5 + 17 * rank)     # different initial weights per rank: the constructor's broadcast must make them rank 0's
+tr = PRETrainer(cfg)
+assert tr.reducer is not None and tr.world_size == 2
+out = []
+for i in range(7):
+    rec = tr.run_step()
+    out.append({{k: float(v) for k, v in rec.items()}})
+torch.cuda.synchronize()
+h = hashlib.sha256()
+for p in tr.optimizer.params:
+    h.update(p.detach().float().cpu().numpy().tobytes())
+order = [[int(p.numel()) for p in s.params] for s in tr.reducer.slices]
+chunks = [len(e.bwd_chunks or []) for seg in G._SEGMENTS for e in seg.graphs.values()]
+dist.barrier()
+dist.destroy_process_group()
+print("RESULT " + json.dumps({{"rank": rank, "losses": out, "weights": h.hexdigest(), "slices": order, "chunks": chunks, "stats": dict(G.STATS)}}))
+"""
+
+
+def test_two_ranks_on_one_gpu_over_gloo_train_the_same_weights_with_replayed_stretches():
+    """N > 1 on the hardware that exists here: TWO ranks share the one MI355X of the test box over gloo (RCCL refuses two ranks per device;
+    gloo carries the same torch.distributed calls through the host).  What it covers that the one-rank RCCL tests cannot: the constructor's
+    parameter broadcast (the ranks are seeded differently on purpose), rank 0's arrival-order slicing reaching rank 1, collectives
+    issued in the same order on both ranks while the stretches replay their chunked backward graphs, different images per rank.  After 7
+    steps both ranks hold bit-identical weights (each applied the same summed gradient), cut the same slices, replayed the same number
+    of graphs, and their losses are finite and differ (their data does)."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", LOCAL_WORLD_SIZE="2",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="4")   # (two processes share the GPU's hardware queues: see the CoinTrainer test)
+        procs.append(subprocess.Popen([sys.executable, "-c", _SCRIPT_TWO.format(root=ROOT)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = []
+    try:
+        for p in procs:
+            o, e = p.communicate(timeout=900)
+            assert p.returncode == 0, o[-1500:] + e[-2500:]
+            res.append(json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    a, b = sorted(res, key=lambda d: d["rank"])
+    assert a["weights"] == b["weights"]
+    assert a["slices"] == b["slices"] and len(a["slices"]) >= 2
+    assert a["stats"]["replays"] == b["stats"]["replays"] >= 4 and a["chunks"] == b["chunks"] and all(c >= 2 for c in a["chunks"]), (a["stats"], a["chunks"])
+    import math
+
+    assert all(math.isfinite(v) for d in (a, b) for rec in d["losses"] for v in rec.values())
+    assert a["losses"][0] != b["losses"][0]
+
+
+_SCRIPT_TWO_COIN = r"""
+import hashlib, json, os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+from coin_amd import graphs as G
+from coin_amd.config import get_cfg
+from coin_amd.data.synthetic import synthetic_offline_detections
+from coin_amd.engine import CoinTrainer
+burned = os.environ["TEST_BURNED_UP"] == "1"
+cfg = get_cfg()
+cfg.merge_from_file(os.path.join({root!r}, "configs", "coin", "GDINO", "foggy_synthetic.yaml"))
+cfg.merge_from_list(["SOLVER.IMG_PER_BATCH_UNLABEL", 2, "AMD.SYNTHETIC.NUM_IMAGES", 2, "AMD.SYNTHETIC.HEIGHT", 384, "AMD.SYNTHETIC.WIDTH", 640,
+                     "AMD.TEXT_TEMPLATES", 2, "MODEL.DEVICE", "cuda:0", "CLOUD.BURN_UP_STEP", 0 if burned else 100,
+                     "CLOUD.OFFLINE_TEACHER_UPDATE_ITER", 1, "CLOUD.PROTOTYPE_UPDATE_START", 0, "CLOUD.CLS_B_THRESH", 0.2])
+G.set_enabled(True)
+torch.manual_seed(11)   # (the same constructor seed on both ranks: like the reference, trainer.py:55-72, the trainer does not broadcast the
+tr = CoinTrainer(cfg)   #  TEACHER -- it is identical across ranks because every rank loads the same checkpoint)
+assert tr.reducer is not None and tr.reducer_merge is not None and tr.world_size == 2
+real_forward, g_det = tr.offline_teacher.forward, torch.Generator().manual_seed(7 + rank)
+def teacher(batched_inputs, branch=None, **kw):   # the real inference runs; the matcher gets CLIPDET-like detections (different per rank)
+    out = real_forward(batched_inputs, branch=branch, **kw)
+    return [synthetic_offline_detections(tr.model_CLOUD.entry(d["file_name"]), g_det, device="cuda:0") for d in batched_inputs]
+tr.offline_teacher.forward = teacher
+out = []
+for i in range(5):
+    rec = tr.run_step()
+    out.append({{k: float(v) for k, v in rec.items()}})
+    tr.prepare_next()
+torch.cuda.synchronize()
+def digest(params):
+    h = hashlib.sha256()
+    for p in params:
+        h.update(p.detach().float().cpu().numpy().tobytes())
+    return h.hexdigest()
+res = {{"rank": rank, "losses": out, "student": digest(tr.optimizer.params), "merge": digest(tr.optimizer_merge.params),
+       "teacher": digest(list(tr.offline_teacher.parameters())), "stats": dict(G.STATS)}}
+dist.barrier()
+dist.destroy_process_group()
+print("RESULT " + json.dumps(res))
+"""
+
+
+@pytest.mark.parametrize("burned_up", [False, True])
+def test_two_ranks_on_one_gpu_over_gloo_cointrainer_step_one_and_step_two(burned_up):
+    """The adaptation trainer (coin/engine/trainer.py:141-286 under DDP) with two ranks on the one GPU over gloo: student and CKG each own
+    a reducer, the CKG's step is gated by a flag that is all-reduced with its gradients (a rank without matched A/B boxes must still
+    take part), the EMA teacher follows the student on every rank.  After 5 `run_step` + `prepare_next` iterations -- different images and
+    different offline detections per rank -- student, CKG and teacher weights are bit-identical across
+    the ranks and every loss is finite.
+
+    What this test found (round 6): (1) res5's weights take part in TWO differentiable passes of a step (the replayed proposal pass and the
+    eager C-box pass); a replayed backward that handed their gradients to the reducer chunk by chunk all-reduced the replay's share
+    only, the C-box share was added per rank afterwards and the ranks' weights drifted apart from the first replayed step on
+    (GraphedSegment.note_outside_use + the reducer's late-contribution guard are the fix); (2) two processes with 8 hardware queues each
+    on ONE GPU stall for minutes in step_two (student graphs + teacher graph + gloo's copy streams oversubscribe the chip's queues; one
+    process per GPU, the supported layout, does not share them) -- the ranks of this test run with GPU_MAX_HW_QUEUES=4."""
+    import math
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", LOCAL_WORLD_SIZE="2",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", TEST_BURNED_UP="1" if burned_up else "0", GPU_MAX_HW_QUEUES="4")
+        procs.append(subprocess.Popen([sys.executable, "-c", _SCRIPT_TWO_COIN.format(root=ROOT)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = []
+    try:
+        for p in procs:
+            o, e = p.communicate(timeout=900)
+            assert p.returncode == 0, o[-1500:] + e[-2500:]
+            res.append(json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    a, b = sorted(res, key=lambda d: d["rank"])
+    assert a["student"] == b["student"] and a["merge"] == b["merge"] and a["teacher"] == b["teacher"]
+    assert all(math.isfinite(v) for d in (a, b) for rec in d["losses"] for v in rec.values())
+    assert a["losses"][0] != b["losses"][0]
