@@ -590,6 +590,15 @@ int walk_grid(int64_t rows, int ncg) {
 extern "C" void coin_lab_set_bn_grid(int v) { g_bn_grid_cap = v; }
 extern "C" void coin_lab_set_bn_parts(int v) { g_bn_parts_cap = v; }
 extern "C" void coin_lab_set_bn_old(int v) { g_bn_grid_cap = v ? 4096 : 0; g_bn_parts_cap = v ? 512 : 0; }   // tools/ab_bench.py bn_old: round 5's launch shapes
+extern "C" void coin_lab_set_no_s4(int v);         // conv_gemm.hip
+extern "C" void coin_lab_set_roi_bwd_old(int v);   // roi_align.hip
+// tools/ab_bench.py round5_kernels: every kernel-level change of round 6 off at once (GEMM dispatch, BatchNorm launch shapes, RoIAlign
+// backward).  Defined here because tools/gemm_lab links the GEMM objects only.
+extern "C" void coin_lab_set_round5_kernels(int v) {
+  coin_lab_set_no_s4(v);
+  coin_lab_set_bn_old(v);
+  coin_lab_set_roi_bwd_old(v);
+}
 #endif
 
 #define BN_DISPATCH(dtype, EXPR_F32, EXPR_BF16) \
