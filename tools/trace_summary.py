@@ -111,6 +111,37 @@ for q, iv2 in sorted(qiv.items(), key=lambda kv: -sum(e - s for s, e in kv[1]))[
         u += ce - cs
     print(f"   q{q}: {u/1e6:8.1f} ms occupied = {100.0*u/(a.window_ms*1e6):5.1f}% of the window, {len(iv2)} kernels")
 
+# ---- gaps between consecutive kernels of the busiest queue (late round 6): how much of a step is the queue's own launch-to-launch dead time?
+# A gap of a few microseconds after a kernel is the device's (drain, dependency resolution, dispatch ramp -- inside a HIP-graph replay the host
+# is not involved); gaps of tens of microseconds and more are the host (under the profiler more than without it) or a cross-stream wait.
+if qiv:
+    qmain = max(qiv.items(), key=lambda kv: sum(e - s for s, e in kv[1]))[0]
+    seq = sorted((s0, e0, n) for (s0, e0, n), q in zip(rows, queues) if q == qmain and e0 > lo)
+    edges = [0.5, 1, 2, 3, 4, 6, 10, 20, 50, 1e9]
+    cnt, tot = [0] * len(edges), [0.0] * len(edges)
+    after = collections.defaultdict(lambda: [0, 0.0])
+    for (s0, e0, n0), (s1, e1, n1) in zip(seq, seq[1:]):
+        g = (s1 - e0) / 1e3
+        if g <= 0:
+            continue
+        k = next(i for i, x in enumerate(edges) if g <= x)
+        cnt[k] += 1
+        tot[k] += g
+        if g <= 10:
+            key = n0.split("(")[0].split("<")[0][-60:]
+            after[key][0] += 1
+            after[key][1] += g
+    print(f"-- gaps between consecutive kernels of queue q{qmain} in the window ({len(seq)} kernels, {nsteps} steps): count / total ms / ms per step, by gap length")
+    lo_e = 0
+    for x, c, t in zip(edges, cnt, tot):
+        print(f"   {lo_e:5g} - {x if x < 1e9 else float('inf'):5g} us: {c:6d} gaps {t/1e3:8.2f} ms  {t/1e3/nsteps:6.2f} ms/step")
+        lo_e = x
+    small = sum(t for x, t in zip(edges, tot) if x <= 10)
+    print(f"   gaps <= 10 us: {small/1e3/nsteps:.2f} ms per step over {sum(c for x, c in zip(edges, cnt) if x <= 10)/nsteps:.0f} kernel boundaries per step")
+    print("   ... of which, by the kernel BEFORE the gap (top 12 by total):")
+    for key, (c, t) in sorted(after.items(), key=lambda kv: -kv[1][1])[:12]:
+        print(f"      {t/1e3/nsteps:6.3f} ms/step  n/step={c/nsteps:6.1f}  mean {t/c:5.2f} us  {key}")
+
 if a.list:
     # each matching dispatch of the last `list-ms`: start offset, duration, and how much OTHER kernel time overlaps it (side streams)
     lo2 = end - int(a.list_ms * 1e6)
