@@ -261,3 +261,47 @@ def test_collection_loop_unions_the_ranks_shards(tmp_path):
     world, port = 2, _free_port()
     mp.start_processes(_collect_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
     assert all(torch.load(tmp_path / f"col{r}.pt")["ok"] for r in range(world))
+
+
+def test_grad_reducer_refuses_a_contribution_that_arrives_after_an_early_delivery_was_reduced():
+    """Round 6 (found with two ranks on one GPU, tests/test_ddp_gpu.py): a replayed step graph hands a parameter's gradient to the reducer
+    EARLY (`deliver_early`); if another differentiable pass of the same step also feeds that parameter, the autograd engine adds its share
+    in place AFTER the slice was all-reduced -- per rank, on top of the reduced sum.  The reducer notices when the engine's hook for that
+    parameter arrives (the arena's version counter moved since the collective was launched) and raises; a contribution that lands while
+    the slice is still open is simply part of what gets packed.  One process, no process group (the collective is skipped at world size
+    1, the bookkeeping is the same)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from coin_amd.parallel import GradReducer
+
+    a = torch.nn.Linear(4, 3)
+    b = torch.nn.Linear(3, 2)
+    params = list(a.parameters()) + list(b.parameters())
+    red = GradReducer(params, slice_mb=0.00005)   # ~13 floats per slice; slices follow the expected arrival order (last layer first)
+    assert len(red.slices) >= 2
+    first = list(red.slices[0].params)             # launched first: collectives leave in slice order
+    w = first[0]
+    # (1) late contribution AFTER the launch: refused
+    for p in first:
+        p.grad = torch.ones_like(p)
+        red.deliver_early(p)                       # the replay's share is in place; the last one completes the slice: launched at once
+    s = red.slices[0]
+    assert s.launched and w.grad.data_ptr() == s.views[0].data_ptr()
+    w.grad.add_(1.0)                               # what the engine's accumulator does with the other pass's share
+    with pytest.raises(RuntimeError, match="delivered early"):
+        red._on_grad(w)                            # the engine's post-accumulate hook for w
+    red.finalize()
+    # (2) no late contribution: the engine's hook for an early parameter is swallowed silently
+    for p in params:
+        p.grad = None
+    for p in first:
+        p.grad = torch.ones_like(p)
+        red.deliver_early(p)
+    for p in first:
+        red._on_grad(p)
+    for p in params:
+        if all(p is not q for q in first):
+            p.grad = torch.zeros_like(p)
+            red._on_grad(p)
+    assert red.finalize() == 1.0
+    assert torch.equal(w.grad, torch.ones_like(w))
+    red.remove()
