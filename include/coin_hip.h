@@ -30,7 +30,8 @@ extern "C" {
 #endif
 
 /* Bumped whenever a prototype below changes (2: round 4's signature changes -- coin_sgd_step gate, coin_bn_* ReLU mask, coin_anchor_match
- * candidate sets, ... -- and round 5's additions).  The Python binding refuses a library whose version differs (coin_amd/_lib.py). */
+ * candidate sets, ... -- and round 5's additions; 3: round 6 -- coin_conv_gemm_stats_tile_rows, the tile height argument of
+ * coin_conv_gemm_stats_finalize, COIN_BN_MAX_PARTS 768).  The Python binding refuses a library whose version differs (coin_amd/_lib.py). */
 #define COIN_ABI_VERSION 3
 
 enum { COIN_F32 = 0, COIN_BF16 = 1 };
@@ -154,7 +155,7 @@ int coin_bias_act_bwd(const void* dC, const void* C, void* dZ, int ld, int M, in
  *                     added a residual; pass y = NULL when it did not: the mask is then recomputed from x and the
  *                     output tensor is not read at all.
  * ---------------------------------------------------------------------------------------- */
-#define COIN_BN_MAX_PARTS 768
+#define COIN_BN_MAX_PARTS 768   /* ABI 3 (round 6): 512 before -- coin_bn_bwd reduces res5-sized tensors over 768 partial sums; workspaces are sized by this constant */
 int coin_bn_stats(const void* x, int N, int H, int W, int C, float eps, float momentum, float* sums_workspace,
                   float* mean, float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, int dtype,
                   void* stream);
