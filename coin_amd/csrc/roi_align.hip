@@ -527,7 +527,9 @@ constexpr int LIST_CAP = 4096;  // RoIs per tile list (ordered compaction)
 // waves per SIMD.  Hence ALG 1 (shipped for bf16): ALL bin rows with weight on a map row are combined first (py ascending, one fused
 // multiply-add each, starting from 0) and fanned out to the tile columns ONCE per bin column -- a real step's boxes put 2.9 bin rows on
 // a map row, so the ladder runs 2.9x less often -- with rounds of PYR x PXC = 2 x 7 bins in flight (70 % of the (RoI, row) pairs have
-// <= 2 bin rows: 4 x 4 rounds were half empty) and 16-byte lanes (half the bin visits per byte): 0.46 -> 0.35 ms.  Measured and
+// <= 2 bin rows: 4 x 4 rounds were half empty) and 16-byte lanes (half the bin visits per byte): 0.46 -> 0.35 ms; with the weight tables of
+// a list entry held one bin per LANE and turned into scalars by v_readlane (LT: no LDS read + wait + v_readfirstlane per bin column and
+// bin row in the inner loops; same bits) 0.335 ms.  Measured and
 // dropped (same tool): taller / wider tiles (8 x 8: 0.48, 8 x 16: 0.98 ms -- the column ladder and the table build grow with the tile
 // while the workgroup count shrinks; the 1.5x re-read of bins that straddle 4 x 8 tiles is served by L2 / Infinity Cache and is NOT
 // what bounds the launch); two map rows per wave (fewer bin visits, fewer waves: 0.51); a per-wave LDS ring filled by LDS-DMA with
@@ -540,7 +542,8 @@ constexpr int LIST_CAP = 4096;  // RoIs per tile list (ordered compaction)
 // res4 gradient gave 1 144 workgroups whose longest (the central tiles, touched by ~40 % of an image's boxes) bounded the launch.
 template <typename T, int VEC, int NW /* waves */, int BT_COLS, int BT_LC, int DBG = 0 /* lab: 1 no gather phase, 2 no loads, 4 no fan-out, 8 stores only */,
           int ALG = 0 /* 1: all bin rows of a map row are combined before the column fan-out */, int RPW = 1 /* map rows per wave (ALG 1) */,
-          int PYR = 4, int PXC = 4 /* ALG 1: bin rows x bin columns in flight per round */>
+          int PYR = 4, int PXC = 4 /* ALG 1: bin rows x bin columns in flight per round */,
+          bool LT = false /* ALG 1: the weight tables of a list entry in registers, one bin per lane, read with v_readlane */>
 __global__ __launch_bounds__(NW * 64) void roi_align_bwd_gather_kernel(
     const T* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gfeat, int C, int H, int W, int R, int ph, int pw,
     float scale, int sampling_ratio, int aligned, int tiles_x, int tiles_y, int ntiles, int nparts, const int* __restrict__ roi_level, int level) {
@@ -695,6 +698,24 @@ __global__ __launch_bounds__(NW * 64) void roi_align_bwd_gather_kernel(
         const T* __restrict__ go = gout + (size_t)roi * ph * pw * C + (c_ok ? c0 : 0);
         if constexpr (ALG == 1) {
           const unsigned ym0 = ym;
+          // LT: lane p holds bin p's entries of this list entry's tables -- the inner loops then turn them into scalars with v_readlane
+          // instead of one LDS round trip (read, wait, v_readfirstlane) per bin column and bin row
+          unsigned xml = 0;
+          float wxl[BT_COLS], wyl[RPW];
+          if constexpr (LT) {
+            const int pb = lane & 15;
+            xml = xmk[li][pb];
+#pragma unroll
+            for (int k = 0; k < BT_COLS / 4; ++k) {
+              const f32x4 q4 = *reinterpret_cast<const f32x4*>(&wxt[li][pb][4 * k]);
+              wxl[4 * k] = q4[0];
+              wxl[4 * k + 1] = q4[1];
+              wxl[4 * k + 2] = q4[2];
+              wxl[4 * k + 3] = q4[3];
+            }
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr) wyl[rr] = wyt[li][pb][wave * RPW + rr];
+          }
           for (int px = pa; px < pe; px += PXC) {
             // tf[rr][j] = sum over the bin rows py with weight on map row rr of Wy[py][rr] * gout[py][px + j]  (py ascending, PYR per
             // round: up to PYR * PXC gradient bins, one wave-instruction each, in flight), fanned out to the tile columns ONCE per bin column.
@@ -728,7 +749,9 @@ __global__ __launch_bounds__(NW * 64) void roi_align_bwd_gather_kernel(
 #pragma unroll
                 for (int rr = 0; rr < RPW; ++rr) {
                   if (RPW > 1 && !(ymr[rr] & (1u << py[k]))) continue;   // no weight on this row: nothing is added (not even 0 * x)
-                  const float a = wyt[li][py[k]][wave * RPW + rr];
+                  float a;
+                  if constexpr (LT) a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wyl[rr]), py[k]));
+                  else a = wyt[li][py[k]][wave * RPW + rr];
 #pragma unroll
                   for (int j = 0; j < PXC; ++j)
 #pragma unroll
@@ -739,16 +762,22 @@ __global__ __launch_bounds__(NW * 64) void roi_align_bwd_gather_kernel(
 #pragma unroll
             for (int j = 0; j < PXC; ++j) {
               if (px + j >= pe) break;
-              const unsigned mk = (unsigned)__builtin_amdgcn_readfirstlane((int)xmk[li][px + j]);
+              unsigned mk;
+              if constexpr (LT) mk = (unsigned)__builtin_amdgcn_readlane((int)xml, px + j);
+              else mk = (unsigned)__builtin_amdgcn_readfirstlane((int)xmk[li][px + j]);
               if (mk == 0) continue;
               f32x4 wq[BT_COLS / 4];
+              if constexpr (!LT) {
 #pragma unroll
-              for (int k = 0; k < BT_COLS / 4; ++k) wq[k] = *reinterpret_cast<const f32x4*>(&wxt[li][px + j][4 * k]);
+                for (int k = 0; k < BT_COLS / 4; ++k) wq[k] = *reinterpret_cast<const f32x4*>(&wxt[li][px + j][4 * k]);
+              }
 #pragma unroll
               for (int t = 0; t < BT_COLS; ++t) {
                 if (mk & (1u << t)) {
                   asm volatile("; col taken");  // a real wave-uniform branch (see the forward kernel)
-                  const float wt = wq[t >> 2][t & 3];
+                  float wt;
+                  if constexpr (LT) wt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wxl[t]), px + j));
+                  else wt = wq[t >> 2][t & 3];
 #pragma unroll
                   for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
@@ -994,14 +1023,14 @@ extern "C" void coin_lab_set_roi_bwd_old(int v) { g_roi_bwd_cfg = v ? 10 : 0; } 
 constexpr int g_roi_bwd_cfg = 0;
 #endif
 
-template <typename T, int VEC, int NW, int COLS, int LC, int DBG = 0, int ALG = 0, int RPW = 1, int PYR = 4, int PXC = 4>
+template <typename T, int VEC, int NW, int COLS, int LC, int DBG = 0, int ALG = 0, int RPW = 1, int PYR = 4, int PXC = 4, bool LT = false>
 static void launch_bwd_gather(const T* grad_out, const float* rois, float* grad_feat, int N, int C, int H, int W, int R, int ph, int pw, float scale,
                               int sampling_ratio, int aligned, const int* roi_level, int level, hipStream_t st) {
   constexpr int ROWS = NW * RPW;
   const int tiles_x = (W + COLS - 1) / COLS, tiles_y = (H + ROWS - 1) / ROWS;
   const int ntiles = tiles_x * tiles_y * N;
   const int nparts = (C + 64 * VEC - 1) / (64 * VEC);
-  roi_align_bwd_gather_kernel<T, VEC, NW, COLS, LC, DBG, ALG, RPW, PYR, PXC><<<ntiles * nparts, NW * 64, 0, st>>>(grad_out, rois, grad_feat, C, H, W, R, ph, pw, scale, sampling_ratio,
+  roi_align_bwd_gather_kernel<T, VEC, NW, COLS, LC, DBG, ALG, RPW, PYR, PXC, LT><<<ntiles * nparts, NW * 64, 0, st>>>(grad_out, rois, grad_feat, C, H, W, R, ph, pw, scale, sampling_ratio,
                                                                                          aligned, tiles_x, tiles_y, ntiles, nparts, roi_level, level);
 }
 
@@ -1039,12 +1068,15 @@ static int roi_align_bwd_impl(const void* grad_out, int N, int C, int H, int W, 
     case 24: BWD_GO(T, 4, 4, 8, 16, 0, 1, 2); break;       \
     case 34: BWD_GO(T, 4, 4, 8, 32, 0, 1, 1, 2, 4); break; \
     case 37: BWD_GO(T, 8, 4, 8, 32, 0, 1, 1, 2, 7); break; \
-    case 41: BWD_GO(T, 4, 4, 8, 32, 0, 1, 1, 2, 7); break;
+    case 41: BWD_GO(T, 4, 4, 8, 32, 0, 1, 1, 2, 7); break; \
+    case 47: BWD_GO(T, 8, 4, 8, 32, 0, 1, 1, 2, 7, true); break; \
+    case 48: BWD_GO(T, 4, 4, 8, 32, 0, 1, 1, 2, 7, true); break; \
+    case 49: BWD_GO(T, 4, 4, 8, 32, 0, 1, 1, 2, 4, true); break;
 #else
 #define BWD_LAB_CASES(T)
 #endif
     // shipped: bf16 -- 16-byte lanes (512 channels per workgroup), all bin rows of a map row combined before the column fan-out, rounds of
-    // 2 bin rows x 7 bin columns in flight; f32 -- round 2's pairs of bin rows x 4 bin columns (the wider rounds cost it registers:
+    // 2 bin rows x 7 bin columns in flight, the tables of a list entry held one bin per lane (v_readlane instead of LDS round trips); f32 -- round 2's pairs of bin rows x 4 bin columns (the wider rounds cost it registers:
     // 0.51 vs 0.57 ms on a real step's boxes but 1.32 vs 1.23 ms on 300-800 px boxes)
     if (dtype == COIN_F32) {
       switch (cfg) {
@@ -1054,7 +1086,7 @@ static int roi_align_bwd_impl(const void* grad_out, int N, int C, int H, int W, 
     } else {
       switch (cfg) {
         BWD_LAB_CASES(bf16_t)
-        default: BWD_GO(bf16_t, 8, 4, 8, 32, 0, 1, 1, 2, 7); break;
+        default: BWD_GO(bf16_t, 8, 4, 8, 32, 0, 1, 1, 2, 7, true); break;
       }
     }
 #undef BWD_LAB_CASES
