@@ -91,15 +91,21 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long*
     if (t == blk) s_rw = remv;
     __syncthreads();
     if (wave == 0) {
-      unsigned long long rw = s_rw;
+      // The greedy order inside the block on the SCALAR unit (round 6): the running word and the kept bits are wave-uniform, so the 64
+      // dependent steps are s_bitcmp / s_cbranch / s_or on SGPRs, and a diagonal word is fetched (two v_readlane) only for a box that is
+      // kept.  Before: 64-bit vector arithmetic per step and two ds_bpermute per box -- ~2 500 cycles of a ~7 000-cycle block.
+      const unsigned long long rw0 = s_rw;
+      unsigned long long rw = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rw0 >> 32)) << 32) |
+                              (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rw0);
+      const int dlo = (int)(unsigned)diag_cur, dhi = (int)(unsigned)(diag_cur >> 32);
       const int row = blk * 64 + lane;
       unsigned long long kept = 0ull;
       const int lim = (n - blk * 64) < 64 ? (n - blk * 64) : 64;
-      for (int j = 0; j < lim; ++j) {
-        const unsigned long long dj = __shfl(diag_cur, j, 64);
-        if (!((rw >> j) & 1ull)) {
+#pragma unroll
+      for (int j = 0; j < 64; ++j) {
+        if (j < lim && !((rw >> j) & 1ull)) {
           kept |= 1ull << j;
-          rw |= dj;
+          rw |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, j) << 32) | (unsigned)__builtin_amdgcn_readlane(dlo, j);
         }
       }
       if ((kept >> lane) & 1ull) {
