@@ -247,11 +247,19 @@ def find_top_rpn_proposals(proposals: torch.Tensor, logits: torch.Tensor, image_
     boxes = torch.minimum(boxes.clamp(min=0), lim)                         # clip: the same two operations per coordinate as before
     valid = ((boxes[..., 2:] - boxes[..., :2]) > min_box_size).all(dim=-1)
     valid &= torch.isfinite(boxes).all(dim=-1) & torch.isfinite(top_logits)
-    # stable partition: valid boxes first, still in descending score order
-    order = torch.argsort((~valid).to(torch.int8), dim=1, stable=True)
+    # stable partition: valid boxes first, still in descending score order.  By prefix sums instead of a stable argsort of the flags (the
+    # partition is unique, so the order is the same): element i goes to slot (number of valid before it) if valid, else to
+    # (number of valid in the row) + (number of invalid before it); `order` is the inverse of that permutation.  On the GPU the segmented
+    # sort of [4, 12 000] flags took 80 us of the proposal chain per step, the scan + scatter take ~25.
+    kk = valid.shape[1]
+    cv = torch.cumsum(valid.to(torch.int64), dim=1)
+    nv = cv[:, -1:] if kk else cv.new_zeros((valid.shape[0], 1))
+    ar = torch.arange(kk, device=valid.device, dtype=torch.int64).unsqueeze(0)
+    dest = torch.where(valid, cv - 1, nv + ar - cv)          # (ar + 1 - cv) invalid up to and including i, minus one
+    order = torch.empty_like(dest).scatter_(1, dest, ar.expand_as(dest))
     boxes = torch.gather(boxes, 1, order.unsqueeze(-1).expand(-1, -1, 4)).contiguous()
     top_logits = torch.gather(top_logits, 1, order)
-    counts = valid.sum(dim=1).to(torch.int32)
+    counts = nv.squeeze(1).to(torch.int32)
     if lvl is None:
         keep, num = K.nms_batched(boxes, counts, nms_thresh, post_nms_topk)
     else:   # level-wise NMS: boxes of level l are moved by l * (largest image extent + 1), so that levels cannot overlap
