@@ -261,11 +261,17 @@ __global__ __launch_bounds__(256) void rpn_losses_kernel(
   }
 }
 
-__global__ __launch_bounds__(64) void rpn_losses_sum_kernel(const float* __restrict__ part, int nblk, float* __restrict__ loss_cls,
-                                                            float* __restrict__ loss_loc) {
+// The partials are added in block order by ONE thread per total (the order is the contract: bit-reproducible) -- but they are brought
+// into LDS by the whole workgroup first: read one by one from global memory by the adding thread, ~1 000 dependent loads took 88 us
+// on the main stream of every step (round 6, tools/chain_gap.py); from LDS the same chain is ~2 us.
+__global__ __launch_bounds__(256) void rpn_losses_sum_kernel(const float* __restrict__ part, int nblk, float* __restrict__ loss_cls,
+                                                             float* __restrict__ loss_loc) {
+  __shared__ float sh[2 * COIN_RPN_LOSS_MAX_BLOCKS];
+  for (int i = threadIdx.x; i < 2 * nblk; i += 256) sh[i] = part[i];
+  __syncthreads();
   if (threadIdx.x < 2) {
     float t = 0.f;
-    for (int b = 0; b < nblk; ++b) t += part[2 * b + threadIdx.x];
+    for (int b = 0; b < nblk; ++b) t += sh[2 * b + threadIdx.x];
     *(threadIdx.x == 0 ? loss_cls : loss_loc) = t;
   }
 }
@@ -333,6 +339,6 @@ extern "C" int coin_rpn_losses_fwd_bwd(const float* logits, const int8_t* labels
   if (grid > 0)
     rpn_losses_kernel<<<grid, 256, 0, st>>>(logits, labels, deltas, anchors, matched_gt, A_total, A_per_image, min_label,
                                             (float*)workspace, grad_logits, grad_deltas);
-  rpn_losses_sum_kernel<<<1, 64, 0, st>>>((const float*)workspace, grid, loss_cls, loss_loc);
+  rpn_losses_sum_kernel<<<1, 256, 0, st>>>((const float*)workspace, grid, loss_cls, loss_loc);
   return coin_launch_status();
 }
